@@ -1,0 +1,365 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (read-only).
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Nothing from the reference is copied: the reference's modules are instantiated at small sizes with
+seeded non-trivial weights, run on seeded inputs, and the (weights, inputs, outputs) triples are stored
+as .npz data files.  These pin oracle/ (tests/test_oracle_golden.py) and, through it, the HIP path.
+
+Reference symbols exercised (file:line under /root/reference):
+  modules/visinger/encoder.py:130-213   WaveNet + gate
+  modules/visinger/encoder.py:76-101    PosteriorEncoder
+  modules/visinger/encoder.py:58-73     FramePriorNetwork
+  modules/visinger/encoder.py:14-55     TextEncoder
+  modules/visinger/flow.py:15-95        ResidualCouplingBlock / Layer / Flip
+  modules/visinger/decoder.py:13-137    Generator / ResBlock1 / ResBlock2
+  modules/visinger/predictor.py:7-35    PitchPredictor / PhonemePredictor
+  modules/rel_transformer.py:24-345     LayerNorm, SinusoidalPositionalEmbedding, MultiHeadAttention,
+                                        RelativeEncoder, FFN
+  modules/commons/utils.py:86-110       slice_segments, rand_slice_segments, get_padding
+  models/commons/align_ops.py:22-26     expand_states
+  models/visinger.py:18-112             VISinger (state-dict manifest + tiny infer forward)
+"""
+import json
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REF = os.environ.get("VISINGER_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+for name in ("librosa", "librosa.filters", "pyloudnorm", "webrtcvad", "skimage", "skimage.transform",
+             "parselmouth", "pyworld", "torchaudio"):
+    sys.modules.setdefault(name, MagicMock())
+sys.path.insert(0, REF)
+
+from modules.visinger.encoder import WaveNet, PosteriorEncoder, FramePriorNetwork, TextEncoder  # noqa: E402
+from modules.visinger.flow import ResidualCouplingBlock, ResidualCouplingLayer, Flip  # noqa: E402
+from modules.visinger.decoder import Generator, ResBlock1, ResBlock2  # noqa: E402
+from modules.visinger.predictor import PitchPredictor, PhonemePredictor  # noqa: E402
+from modules.rel_transformer import (LayerNorm, SinusoidalPositionalEmbedding, MultiHeadAttention,  # noqa: E402
+                                     RelativeEncoder, FFN)
+from modules.commons.utils import slice_segments, rand_slice_segments, get_padding  # noqa: E402
+from models.commons.align_ops import expand_states  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(4)
+
+
+def randomize(module, seed, scale=1.0):
+    """Seeded non-trivial weights: every parameter ~ N(0, s) with s set per parameter kind so that
+    activations stay O(1).  (Zero-initialised `post` convs would make the flow an identity.)"""
+    g = torch.Generator().manual_seed(seed)
+    for name, p in module.named_parameters():
+        if name.endswith("weight_g"):
+            p.copy_(0.5 + torch.rand(p.shape, generator=g))
+        elif name.endswith("gamma"):
+            p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+        elif name.endswith("beta") or name.endswith("bias"):
+            p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        elif "emb_rel" in name:
+            p.copy_(torch.randn(p.shape, generator=g) * (p.shape[-1] ** -0.5))
+        else:
+            fan = max(1, int(np.prod(p.shape[1:])))
+            p.copy_(scale * torch.randn(p.shape, generator=g) / np.sqrt(fan))
+    return module
+
+
+def sd_np(module, prefix="w."):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def ragged_mask(B, T, lens):
+    m = torch.zeros(B, 1, T)
+    for b, l in enumerate(lens):
+        m[b, 0, :l] = 1.0
+    return m
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+class CaptureRandn:
+    """Record what torch.randn_like / torch.rand return while the reference runs, so the sampled noise can
+    be injected into the oracle and the HIP path (CPU and GPU generators differ)."""
+    def __enter__(self):
+        self.draws, self.uniform = [], []
+        self._randn_like, self._rand = torch.randn_like, torch.rand
+
+        def randn_like(*a, **k):
+            out = self._randn_like(*a, **k)
+            self.draws.append(out.clone().contiguous())
+            return out
+
+        def rand(*a, **k):
+            out = self._rand(*a, **k)
+            self.uniform.append(out.clone())
+            return out
+        torch.randn_like, torch.rand = randn_like, rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.rand = self._randn_like, self._rand
+        return False
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_wavenet():
+    for tag, (H, k, dr, L, gin, B, T, lens) in {
+        "wavenet_g": (16, 5, 1, 3, 8, 2, 37, [37, 29]),
+        "wavenet_nog_dil2": (8, 3, 2, 4, 0, 2, 41, [33, 41]),
+        "wavenet_1layer": (8, 5, 1, 1, 4, 1, 19, [19]),
+    }.items():
+        m = randomize(WaveNet(H, k, dr, L, gin_channels=gin).eval(), 11)
+        x = rnd(1, B, H, T)
+        mask = ragged_mask(B, T, lens)
+        g = rnd(2, B, gin, 1) if gin else None
+        y = m(x, mask, g=g)
+        arrs = dict(sd_np(m), x=x, mask=mask, y=y,
+                    cfg=np.array([H, k, dr, L, gin], dtype=np.int64))
+        if g is not None:
+            arrs["g"] = g
+        save(tag, **arrs)
+
+
+def gen_posterior():
+    cin, cout, H, k, dr, L, gin, B, T = 21, 12, 16, 5, 1, 3, 8, 2, 33
+    m = randomize(PosteriorEncoder(cin, cout, H, k, dr, L, gin).eval(), 12)
+    x = rnd(3, B, cin, T).abs()
+    mask = ragged_mask(B, T, [33, 20])
+    g = rnd(4, B, gin, 1)
+    torch.manual_seed(777)
+    with CaptureRandn() as cap:   # the only RNG draw inside forward (encoder.py:97)
+        z, mu, logs = m(x, mask, g=g)
+    noise = cap.draws[0]
+    save("posterior", **sd_np(m), x=x, mask=mask, g=g, noise=noise, z=z, mu=mu, logs=logs,
+         cfg=np.array([cin, cout, H, k, dr, L, gin], dtype=np.int64))
+
+
+def gen_flow():
+    C, H, k, dr, L, gin, B, T = 12, 16, 5, 1, 2, 8, 2, 35
+    mask = ragged_mask(B, T, [35, 22])
+    x = rnd(5, B, C, T)
+    g = rnd(6, B, gin, 1)
+    for mean_only in (False, True):
+        m = randomize(ResidualCouplingLayer(C, H, k, dr, L, gin_channels=gin, mean_only=mean_only).eval(), 13,
+                      scale=0.5)
+        y, logdet = m(x, mask, g=g, reverse=False)
+        xr = m(y, mask, g=g, reverse=True)     # inverse of the forward output
+        yi = m(x, mask, g=g, reverse=True)     # inverse applied to x itself
+        save(f"coupling_meanonly{int(mean_only)}", **sd_np(m), x=x, mask=mask, g=g, y=y, logdet=logdet,
+             x_roundtrip=xr, y_inv=yi, cfg=np.array([C, H, k, dr, L, gin, int(mean_only)], dtype=np.int64))
+    xf, ld = Flip()(x, mask, reverse=False)
+    save("flip", x=x, y=xf, logdet=ld, y_rev=Flip()(x, reverse=True))
+    blk = randomize(ResidualCouplingBlock(C, H, k, dr, L, n_flows=4, gin_channels=gin).eval(), 14, scale=0.5)
+    y = blk(x, mask, g=g, reverse=False)
+    yi = blk(x, mask, g=g, reverse=True)
+    xr = blk(y, mask, g=g, reverse=True)
+    save("flow_block", **sd_np(blk), x=x, mask=mask, g=g, y=y, y_inv=yi, x_roundtrip=xr,
+         cfg=np.array([C, H, k, dr, L, 4, gin], dtype=np.int64))
+    # no-conditioning variant
+    blk = randomize(ResidualCouplingBlock(C, H, 3, 2, 3, n_flows=2, gin_channels=0).eval(), 15, scale=0.5)
+    y = blk(x, mask, reverse=False)
+    yi = blk(x, mask, reverse=True)
+    save("flow_block_nog", **sd_np(blk), x=x, mask=mask, y=y, y_inv=yi,
+         cfg=np.array([C, H, 3, 2, 3, 2, 0], dtype=np.int64))
+
+
+def gen_generator():
+    # (tag, init_ch, resblock, rb_kernels, rb_dils, rates, up_init, up_kernels, gin, B, T)
+    cases = [
+        ("generator_hop256_like", 12, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 2, 2], 64, [16, 16, 4, 4], 8, 2, 9),
+        ("generator_hop300_like", 12, "1", [3, 7], [[1, 3, 5]] * 2, [5, 3, 2], 32, [11, 7, 4], 8, 2, 11),
+        ("generator_rb2_nog", 10, "2", [3, 5], [[1, 3]] * 2, [4, 2], 16, [8, 4], 0, 1, 13),
+    ]
+    for tag, ic, rb, rk, rd, rates, ui, uk, gin, B, T in cases:
+        m = Generator(ic, rb, rk, rd, rates, ui, uk, gin_channels=gin).eval()
+        randomize(m, 21, scale=1.0)
+        x = rnd(7, B, ic, T)
+        g = rnd(8, B, gin, 1) if gin else None
+        y = m(x, g=g)
+        arrs = dict(sd_np(m), x=x, y=y, rb=np.array(int(rb)), rk=np.array(rk), rd=np.array(rd),
+                    rates=np.array(rates), uk=np.array(uk), cfg=np.array([ic, ui, gin], dtype=np.int64))
+        if g is not None:
+            arrs["g"] = g
+        save(tag, **arrs)
+    # stand-alone resblocks (with and without mask; decoder.py:91-104,124-133)
+    for tag, cls, C, k, d in (("resblock1", ResBlock1, 8, 7, (1, 3, 5)), ("resblock2", ResBlock2, 8, 5, (1, 3))):
+        m = randomize(cls(C, k, d).eval(), 22)
+        x = rnd(9, 2, C, 45)
+        mask = ragged_mask(2, 45, [45, 30])
+        save(tag, **sd_np(m), x=x, mask=mask, y=m(x), y_masked=m(x, mask),
+             cfg=np.array([C, k] + list(d), dtype=np.int64))
+
+
+def gen_transformer():
+    C, nh, ws, B, T = 16, 2, 4, 2, 23
+    mask = ragged_mask(B, T, [23, 14])
+    attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    x = rnd(10, B, C, T)
+    ln = randomize(LayerNorm(C).eval(), 31)
+    save("layernorm", **sd_np(ln), x=x, y=ln(x))
+    mha = randomize(MultiHeadAttention(C, C, nh, window_size=ws).eval(), 32)
+    y = mha(x, x, attn_mask)
+    save("mha_rel", **sd_np(mha), x=x, attn_mask=attn_mask, mask=mask, y=y, p_attn=mha.attn,
+         cfg=np.array([C, nh, ws], dtype=np.int64))
+    # short sequence: T <= window (rel_transformer.py:199-212 slice path)
+    xs = rnd(11, 1, C, 3)
+    ms = torch.ones(1, 1, 3)
+    ys = mha(xs, xs, ms.unsqueeze(2) * ms.unsqueeze(-1))
+    save("mha_rel_short", **sd_np(mha), x=xs, mask=ms, y=ys, p_attn=mha.attn, cfg=np.array([C, nh, ws]))
+    # fully masked rows -> uniform attention, not NaN (rel_transformer.py:167)
+    ffn = randomize(FFN(C, C, 24, 9).eval(), 33)
+    save("ffn", **sd_np(ffn), x=x, mask=mask, y=ffn(x, mask), cfg=np.array([C, C, 24, 9]))
+    for tag, gin, ks, nl in (("rel_encoder_g", 1, 9, 2), ("rel_encoder_nog", None, 3, 3), ("rel_encoder_spk", 8, 5, 1)):
+        enc = randomize(RelativeEncoder(C, 24, nh, nl, kernel_size=ks, gin_channels=gin).eval(), 34)
+        arrs = dict(sd_np(enc), x=x, mask=mask, cfg=np.array([C, 24, nh, nl, ks, -1 if gin is None else gin]))
+        if gin is None:
+            arrs["y"] = enc(x, mask)
+        else:
+            g = rnd(12, B, gin, T if gin == 1 else 1)
+            arrs["g"] = g
+            arrs["y"] = enc(x, mask, g)
+        save(tag, **arrs)
+
+
+def gen_wrappers():
+    C, F_, nh, B, T = 16, 24, 2, 2, 21
+    mask = ragged_mask(B, T, [21, 13])
+    x = rnd(13, B, C, T) * mask
+    fp = randomize(FramePriorNetwork(C, F_, nh, 2, 5, gin_channels=1, p_dropout=0.0).eval(), 41)
+    mu, logs = fp(x, mask, None)
+    # NB: with g given the reference transposes it (encoder.py:68-69) -> g must arrive as [B, T, 1]
+    gT = rnd(14, B, T, 1)
+    mu_g, logs_g = fp(x, mask, gT)
+    save("frame_prior", **sd_np(fp), x=x, mask=mask, mu=mu, logs=logs, g_BT1=gT, mu_g=mu_g, logs_g=logs_g,
+         cfg=np.array([C, F_, nh, 2, 5, 1]))
+    pp = randomize(PitchPredictor(C, F_, nh, 2, 5, 0.0, gin_channels=8, out_dim=2).eval(), 42)
+    spk = rnd(15, B, 8, 1)
+    save("pitch_predictor", **sd_np(pp), x=x, mask=mask, spk=spk, y=pp(x, mask, spk), cfg=np.array([C, F_, nh, 2, 5, 8, 2]))
+    ph = randomize(PhonemePredictor(11, C, F_, nh, 1, 3, 0.0).eval(), 43)
+    save("phoneme_predictor", **sd_np(ph), x=x, mask=mask, y=ph(x, mask), cfg=np.array([11, C, F_, nh, 1, 3]))
+    # TextEncoder (use_pos_embed True as models/visinger.py:40 instantiates it)
+    te = randomize(TextEncoder(13, 9, 7, C, F_, nh, 2, 3, 0.0, True).eval(), 44)
+    Tph = 6
+    gi = torch.Generator().manual_seed(45)
+    text = torch.randint(1, 13, (B, Tph), generator=gi)
+    pitch = torch.randint(1, 9, (B, Tph), generator=gi)
+    dur = torch.randint(1, 7, (B, Tph), generator=gi)
+    text[1, 4:] = 0
+    pitch[1, 4:] = 0
+    dur[1, 4:] = 0
+    mel2ph = torch.zeros(B, T, dtype=torch.long)
+    mel2ph[0] = torch.tensor([1] * 3 + [2] * 4 + [3] * 2 + [4] * 5 + [5] * 3 + [6] * 4)
+    mel2ph[1, :13] = torch.tensor([1] * 4 + [2] * 3 + [3] * 2 + [4] * 4)
+    y = te(text, pitch, dur, mel2ph)
+    save("text_encoder", **sd_np(te), text=text, pitch=pitch, dur=dur, mel2ph=mel2ph, y=y,
+         cfg=np.array([13, 9, 7, C, F_, nh, 2, 3]))
+
+
+def gen_integer():
+    gi = torch.Generator().manual_seed(51)
+    B, Tph, T, H = 3, 7, 29, 5
+    h = rnd(16, B, Tph, H)
+    mel2ph = torch.randint(0, Tph + 1, (B, T), generator=gi)
+    mel2ph[2, 20:] = 0
+    save("expand_states", h=h, mel2ph=mel2ph, y=expand_states(h, mel2ph))
+    # make_positions / sinusoidal embedding (rel_transformer.py:59-100)
+    inp = rnd(17, B, T)
+    inp[0, 5] = 0.0
+    inp[1, 10:] = 0.0
+    inp[2, :3] = 0.0
+    pos = SinusoidalPositionalEmbedding.make_positions(inp, 0)
+    emb = SinusoidalPositionalEmbedding(12, 0, init_size=16)   # forces the auto-grow path (T=29 > 16)
+    y = emb(B, T, inp)
+    emb_odd = SinusoidalPositionalEmbedding.get_embedding(9, 7, 0)
+    save("positions", x=inp, positions=pos, y=y, table=emb.weights, table_odd=emb_odd)
+    # slice_segments / rand_slice_segments (modules/commons/utils.py:86-100)
+    x = rnd(18, B, H, T)
+    ids = torch.tensor([0, 11, 21])
+    torch.manual_seed(1234)
+    rs, rids = rand_slice_segments(x, 8)
+    torch.manual_seed(1234)
+    u = torch.rand([B])
+    save("slice_segments", x=x, ids=ids, y=slice_segments(x, ids, 8), rand_u=u, rand_ids=rids, rand_y=rs,
+         pads=np.array([get_padding(k, d) for k in (3, 5, 7, 11) for d in (1, 3, 5)]))
+
+
+def gen_model():
+    """State-dict manifest of the full-size reference model + a tiny end-to-end infer forward
+    (use_pitch_embed=False: the shipped default raises in FramePriorNetwork)."""
+    from models.visinger import VISinger
+    hp = dict(enc_layers=6, dec_blocks="1", hidden_size=192, use_pos_embed=True, segment_size=32, num_mel_bins=128,
+              use_spk_id=True, use_spk_embed=False, num_spk=1, gin_channels=256, ffn_filter_channels=768,
+              num_heads=2, ffn_kernel_size=9, p_dropout=0.1, use_pitch_embed=True, pitch_predictor_layers=6,
+              use_phoneme_pred=True, phoneme_predictor_layers=2, frame_prior_layers=4, num_linear_bins=1025,
+              dec_kernel_size=[3, 7, 11], dec_dilation_sizes=[[1, 3, 5]] * 3, upsample_rates=[5, 5, 3, 2, 2],
+              initial_upsample_channels=512, upsample_kernel_sizes=[11, 11, 7, 4, 4], predictor_grad=1.0)
+    m = VISinger(64, 117, 131, hp)
+    manifest = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "visinger_state_dict_manifest.json"), "w") as f:
+        json.dump({"hparams": hp, "ph_dict_size": 64, "pitch_size": 117, "dur_size": 131,
+                   "state_dict": manifest}, f, indent=0, sort_keys=True)
+    print("manifest:", len(manifest), "tensors,", sum(int(np.prod(s)) for s in manifest.values()), "params")
+
+    hp_t = dict(hp, enc_layers=2, hidden_size=16, segment_size=4, gin_channels=8, ffn_filter_channels=24,
+                ffn_kernel_size=3, use_pitch_embed=False, use_phoneme_pred=True, phoneme_predictor_layers=1,
+                frame_prior_layers=2, num_linear_bins=21, dec_kernel_size=[3, 5], dec_dilation_sizes=[[1, 3, 5]] * 2,
+                upsample_rates=[4, 2], initial_upsample_channels=32, upsample_kernel_sizes=[8, 4], p_dropout=0.0)
+    m = VISinger(13, 9, 7, hp_t).eval()
+    randomize(m, 61, scale=0.7)
+    B, T, Tph = 2, 21, 6
+    gi = torch.Generator().manual_seed(62)
+    text = torch.randint(1, 13, (B, Tph), generator=gi)
+    pitch = torch.randint(1, 9, (B, Tph), generator=gi)
+    dur = torch.randint(1, 7, (B, Tph), generator=gi)
+    text[1, 4:] = 0
+    pitch[1, 4:] = 0
+    dur[1, 4:] = 0
+    mel2ph = torch.zeros(B, T, dtype=torch.long)
+    mel2ph[0] = torch.tensor([1] * 3 + [2] * 4 + [3] * 2 + [4] * 5 + [5] * 3 + [6] * 4)
+    mel2ph[1, :13] = torch.tensor([1] * 4 + [2] * 3 + [3] * 2 + [4] * 4)
+    spk_id = torch.zeros(B, dtype=torch.long)
+    torch.manual_seed(4321)
+    with CaptureRandn() as cap:      # randn_like(mu_p) at models/visinger.py:107
+        ret = m(text, pitch, dur, mel2ph, spk_id=spk_id, infer=True)
+    noise = cap.draws[0]
+    # training-side forward (posterior + flow fwd + segment decode)
+    lin = rnd(63, B, T, 21).abs()
+    torch.manual_seed(999)
+    with CaptureRandn() as cap:      # encoder.py:97 (randn_like) then modules/commons/utils.py:98 (rand)
+        ret_t = m(text, pitch, dur, mel2ph, spk_id=spk_id, mel=lin, infer=False)
+    noise_q = cap.draws[0]
+    u_slice = cap.uniform[0]
+    save("visinger_tiny", **sd_np(m), text=text, pitch=pitch, dur=dur, mel2ph=mel2ph, spk_id=spk_id,
+         noise=noise, wav_out=ret["wav_out"], lin=lin, noise_q=noise_q, u_slice=u_slice,
+         t_wav_out=ret_t["wav_out"], t_z_p=ret_t["z_p"], t_kl=ret_t["kl"], t_ids_slice=ret_t["ids_slice"],
+         t_ph_pred=ret_t["ph_pred"])
+    with open(os.path.join(OUT, "visinger_tiny_hparams.json"), "w") as f:
+        json.dump(hp_t, f, sort_keys=True)
+
+
+if __name__ == "__main__":
+    gen_wavenet()
+    gen_posterior()
+    gen_flow()
+    gen_generator()
+    gen_transformer()
+    gen_wrappers()
+    gen_integer()
+    gen_model()

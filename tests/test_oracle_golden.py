@@ -1,0 +1,189 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerances: fp64 oracle vs the reference's fp32 outputs -> the
+difference is the reference's own fp32 rounding, a few 1e-6 relative; integer paths bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+F64 = np.float64
+
+
+def close(a, b, atol=2e-5, rtol=2e-5):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"max err {err.max():.3e} (ref max {np.abs(b).max():.3e})"
+
+
+@pytest.mark.parametrize("tag", ["wavenet_g", "wavenet_nog_dil2", "wavenet_1layer"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_wavenet(oracle, tag, dtype):
+    w, a = load_golden(tag)
+    H, k, dr, L, gin = (int(v) for v in a["cfg"])
+    y = oracle.wavenet(w, a["x"], a["mask"], a.get("g"), hidden_channels=H, kernel_size=k, dilation_rate=dr,
+                       n_layers=L, dtype=dtype)
+    assert y.dtype == dtype
+    close(y, a["y"])
+
+
+def test_posterior(oracle):
+    w, a = load_golden("posterior")
+    cin, cout, H, k, dr, L, gin = (int(v) for v in a["cfg"])
+    z, mu, logs = oracle.posterior_encoder(w, a["x"], a["mask"], a["g"], a["noise"], out_channels=cout,
+                                           hidden_channels=H, kernel_size=k, dilation_rate=dr, n_layers=L)
+    close(mu, a["mu"])
+    close(logs, a["logs"])
+    close(z, a["z"])
+
+
+@pytest.mark.parametrize("mean_only", [0, 1])
+def test_coupling(oracle, mean_only):
+    w, a = load_golden(f"coupling_meanonly{mean_only}")
+    C, H, k, dr, L, gin, mo = (int(v) for v in a["cfg"])
+    kw = dict(channels=C, hidden_channels=H, kernel_size=k, dilation_rate=dr, n_layers=L, mean_only=bool(mo))
+    y, logdet = oracle.coupling_layer(w, a["x"], a["mask"], a["g"], False, **kw)
+    close(y, a["y"])
+    if mo:
+        assert (logdet == 0).all() and (a["logdet"] == 0).all()   # exactly zero with mean_only (flow.py:73-75,80)
+    else:
+        close(logdet, a["logdet"], atol=0, rtol=1e-5)
+    close(oracle.coupling_layer(w, a["x"], a["mask"], a["g"], True, **kw), a["y_inv"])
+    xr = oracle.coupling_layer(w, y, a["mask"], a["g"], True, **kw)
+    close(xr, a["x_roundtrip"])
+    # round trip restores x on valid frames (x1 is masked, x0 passes through)
+    half = C // 2
+    close(xr[:, :half], a["x"][:, :half], atol=1e-12)
+    close(xr[:, half:], a["x"][:, half:] * a["mask"], atol=1e-9)
+
+
+def test_flip_golden():
+    _, a = load_golden("flip")
+    assert np.array_equal(a["x"][:, ::-1], a["y"]) and np.array_equal(a["x"][:, ::-1], a["y_rev"])
+    assert (a["logdet"] == 0).all()
+
+
+@pytest.mark.parametrize("tag", ["flow_block", "flow_block_nog"])
+def test_flow_block(oracle, tag):
+    w, a = load_golden(tag)
+    C, H, k, dr, L, nf, gin = (int(v) for v in a["cfg"])
+    kw = dict(channels=C, hidden_channels=H, kernel_size=k, dilation_rate=dr, n_layers=L, n_flows=nf)
+    g = a.get("g")
+    y = oracle.flow_block(w, a["x"], a["mask"], g, False, **kw)
+    close(y, a["y"])
+    close(oracle.flow_block(w, a["x"], a["mask"], g, True, **kw), a["y_inv"])
+    xr = oracle.flow_block(w, y, a["mask"], g, True, **kw)
+    if "x_roundtrip" in a:
+        close(xr, a["x_roundtrip"])
+    _, ld = oracle.flow_block(w, a["x"], a["mask"], g, False, return_logdet=True, **kw)
+    assert (ld == 0).all()
+
+
+@pytest.mark.parametrize("tag", ["generator_hop256_like", "generator_hop300_like", "generator_rb2_nog"])
+def test_generator(oracle, tag):
+    w, a = load_golden(tag)
+    y = oracle.generator(w, a["x"], a.get("g"), resblock=str(int(a["rb"])), resblock_kernel_sizes=a["rk"].tolist(),
+                         resblock_dilation_sizes=a["rd"].tolist(), upsample_rates=a["rates"].tolist(),
+                         upsample_kernel_sizes=a["uk"].tolist())
+    assert y.shape[-1] == a["x"].shape[-1] * int(np.prod(a["rates"]))
+    close(y, a["y"], atol=2e-5, rtol=1e-4)
+
+
+def test_resblocks(oracle):
+    w, a = load_golden("resblock1")
+    C, k, *d = (int(v) for v in a["cfg"])
+    close(oracle.resblock1(w, a["x"], kernel_size=k, dilation=tuple(d)), a["y"])
+    close(oracle.resblock1(w, a["x"], a["mask"], kernel_size=k, dilation=tuple(d)), a["y_masked"])
+    w, a = load_golden("resblock2")
+    C, k, *d = (int(v) for v in a["cfg"])
+    close(oracle.resblock2(w, a["x"], kernel_size=k, dilation=tuple(d)), a["y"])
+    close(oracle.resblock2(w, a["x"], a["mask"], kernel_size=k, dilation=tuple(d)), a["y_masked"])
+
+
+def test_layernorm(oracle):
+    w, a = load_golden("layernorm")
+    close(oracle.layer_norm_c(a["x"], w["gamma"], w["beta"]), a["y"])
+
+
+@pytest.mark.parametrize("tag", ["mha_rel", "mha_rel_short"])
+def test_mha(oracle, tag):
+    w, a = load_golden(tag)
+    C, nh, ws = (int(v) for v in a["cfg"])
+    y, p = oracle.mha_rel(w, a["x"], a["x"], a["mask"], n_heads=nh, window_size=ws, return_attn=True)
+    close(p, a["p_attn"], atol=1e-6)
+    close(y, a["y"])
+    # fully masked query rows are uniform (-1e4 fill), never NaN (rel_transformer.py:167)
+    assert np.isfinite(p).all()
+    m = a["mask"].reshape(a["mask"].shape[0], -1)
+    for b in range(m.shape[0]):
+        for i in np.where(m[b] == 0)[0]:
+            assert np.allclose(p[b, :, i, :], 1.0 / m.shape[1])
+
+
+def test_ffn(oracle):
+    w, a = load_golden("ffn")
+    close(oracle.ffn(w, a["x"], a["mask"], kernel_size=int(a["cfg"][3])), a["y"])
+
+
+@pytest.mark.parametrize("tag", ["rel_encoder_g", "rel_encoder_nog", "rel_encoder_spk"])
+def test_rel_encoder(oracle, tag):
+    w, a = load_golden(tag)
+    C, F, nh, nl, ks, gin = (int(v) for v in a["cfg"])
+    y = oracle.rel_encoder(w, a["x"], a["mask"], a.get("g"), n_heads=nh, n_layers=nl, kernel_size=ks)
+    close(y, a["y"], atol=5e-5)
+
+
+def test_wrappers(oracle):
+    w, a = load_golden("frame_prior")
+    C, F, nh, nl, ks, gin = (int(v) for v in a["cfg"])
+    mu, logs = oracle.frame_prior(w, a["x"], a["mask"], None, hidden_channels=C, n_heads=nh, n_layers=nl, kernel_size=ks)
+    close(mu, a["mu"], atol=5e-5)
+    close(logs, a["logs"], atol=5e-5)
+    mu, logs = oracle.frame_prior(w, a["x"], a["mask"], a["g_BT1"], hidden_channels=C, n_heads=nh, n_layers=nl,
+                                  kernel_size=ks)
+    close(mu, a["mu_g"], atol=5e-5)
+    close(logs, a["logs_g"], atol=5e-5)
+    w, a = load_golden("pitch_predictor")
+    C, F, nh, nl, ks, gin, od = (int(v) for v in a["cfg"])
+    close(oracle.pitch_predictor(w, a["x"], a["mask"], a["spk"], n_heads=nh, n_layers=nl, kernel_size=ks), a["y"], atol=5e-5)
+    w, a = load_golden("phoneme_predictor")
+    D, C, F, nh, nl, ks = (int(v) for v in a["cfg"])
+    close(oracle.phoneme_predictor(w, a["x"], a["mask"], n_heads=nh, n_layers=nl, kernel_size=ks), a["y"], atol=5e-5)
+
+
+def test_text_encoder(oracle):
+    w, a = load_golden("text_encoder")
+    nph, npi, ndu, C, F, nh, nl, ks = (int(v) for v in a["cfg"])
+    y = oracle.text_encoder(w, a["text"], a["pitch"], a["dur"], a["mel2ph"], hidden_channels=C, n_heads=nh,
+                            n_layers=nl, kernel_size=ks)
+    close(y, a["y"], atol=5e-5)
+
+
+def test_integer_paths_bit_exact(oracle):
+    _, a = load_golden("expand_states")
+    assert np.array_equal(oracle.expand_states(a["h"], a["mel2ph"]), a["y"])
+    _, a = load_golden("positions")
+    pos = oracle.make_positions(a["x"], 0)
+    assert pos.dtype == np.int64 and np.array_equal(pos, a["positions"])
+    tab = oracle.sinusoid_table(a["table"].shape[0], a["table"].shape[1], 0)
+    close(tab, a["table"], atol=2e-6, rtol=0)
+    close(oracle.sinusoid_table(9, 7, 0), a["table_odd"], atol=2e-6, rtol=0)
+    close(oracle.sinusoidal_positional_embedding(a["x"], 12, 0, init_size=16), a["y"], atol=2e-6, rtol=0)
+    _, a = load_golden("slice_segments")
+    assert np.array_equal(oracle.slice_segments(a["x"], a["ids"], 8), a["y"])
+    ids = oracle.rand_slice_ids(a["rand_u"], a["x"].shape[2], 8)
+    assert np.array_equal(ids, a["rand_ids"])
+    assert np.array_equal(oracle.slice_segments(a["x"], ids, 8), a["rand_y"])
+    assert [oracle.get_padding(k, d) for k in (3, 5, 7, 11) for d in (1, 3, 5)] == a["pads"].tolist()
+
+
+def test_visinger_tiny_infer(oracle):
+    w, a = load_golden("visinger_tiny")
+    hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_hparams.json")))
+    wav = oracle.visinger_infer(w, hp, a["text"], a["pitch"], a["dur"], a["mel2ph"], a["spk_id"], a["noise"])
+    close(wav, a["wav_out"], atol=5e-5, rtol=1e-4)
