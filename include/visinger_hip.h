@@ -1,0 +1,112 @@
+/*
+ * visinger_hip.h -- C ABI of the MI355X-native (gfx950) VISinger variational-inference hot path.
+ *
+ * The reference (jisang93/VISinger) has no FFI: its boundary for this path is the Python nn.Module API of
+ * modules/visinger/{encoder,flow,decoder,predictor}.py and modules/rel_transformer.py.  This header
+ * is the C ABI that sits directly under that API: every entry point below is what one reference
+ * ``nn.Module.forward`` (cited file:line, paths under the reference tree) binds to.  The Python mirror of the
+ * module API that calls it through ctypes lives in visinger_amd/modules/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous, device (HBM) pointers unless stated; layout [B, C, T] (T fastest);
+ *   - frame masks are fp32 [B, T] (the reference's [B, 1, T] nonpadding mask);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing here synchronises the device;
+ *   - handles own their packed weights and workspaces in HBM (hipMalloc at create / first use of a shape, never
+ *     on the steady-state path);  weights are handed over in the reference's own state_dict layout
+ *     (``weight_v`` / ``weight_g`` / ``bias``) and are folded (g * v / ||v||) and re-packed into MFMA fragment
+ *     order on the device by the *_set_weights call;
+ *   - every function returns VS_OK (0) or an error code; vs_last_error() returns a thread-local message.
+ *     Nothing aborts, nothing falls back to a CPU path.
+ */
+#ifndef VISINGER_HIP_H
+#define VISINGER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_API __attribute__((visibility("default")))
+
+enum vs_status { VS_OK = 0, VS_EINVAL = 1, VS_EHIP = 2, VS_EUNSUPPORTED = 3, VS_ENOMEM = 4 };
+
+VS_API const char *vs_last_error(void);
+VS_API int vs_abi_version(void);
+/* number of HIP devices visible / name of device 0 written into buf (diagnostics for the loader) */
+VS_API int vs_device_info(char *buf, size_t buf_bytes);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a12  weight-norm fold: w[r, :] = g[r] * v[r, :] / ||v[r, :]||_2
+ *      (torch.nn.utils.weight_norm at modules/visinger/encoder.py:147,154,164; decoder.py:24,72-87)          */
+VS_API int vs_weightnorm_fold(const float *v, const float *g, float *w, int64_t rows, int64_t cols, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Conv1d / ConvTranspose1d operator handle -- every nn.Conv1d / nn.ConvTranspose1d site of the path
+ * (encoder.py:88,90,152,163; flow.py:60,62; decoder.py:19,24-26,34,72-87; rel_transformer.py:120-128,332-333).
+ * Implicit GEMM on the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32).                                */
+typedef struct vs_conv vs_conv_t;
+
+enum vs_conv_kind {
+    VS_CONV1D = 0,           /* y[b,co,t] = bias[co] + sum w[co,ci,k] x[b,ci,t + k*dil - pad]                  */
+    VS_CONV_TRANSPOSE1D = 1, /* nn.ConvTranspose1d, w is [c_in, c_out, k]; `dilation` carries the stride        */
+    VS_CONV1D_PAIRED = 2     /* Conv1d whose c_out = 2*H rows are consumed as (row c, row H+c) pairs by a fused
+                                epilogue: WaveNet gate (encoder.py:206-213) or affine coupling (flow.py:71-85) */
+};
+enum vs_in_act { VS_IN_NONE = 0, VS_IN_LRELU = 1 /* leaky_relu(x, 0.1) */, VS_IN_MASK = 2 /* x * mask[b,t] */ };
+enum vs_out_act { VS_OUT_NONE = 0, VS_OUT_TANH = 1, VS_OUT_RELU = 2 };
+enum vs_pair_mode { VS_PAIR_GATE = 0, VS_PAIR_COUPLING_FWD = 1, VS_PAIR_COUPLING_INV = 2 };
+enum vs_out_mode {
+    VS_OUT_LINEAR = 0,            /* y = act((v + res + acc) * scale) [* mask]                                  */
+    VS_OUT_COUPLING_MEAN_FWD = 1, /* y = v*mask + res*mask                 (flow.py:74,78 with mean_only)        */
+    VS_OUT_COUPLING_MEAN_INV = 2  /* y = (res - v*mask) * mask             (flow.py:74,83 with mean_only)        */
+};
+
+/* flags for vs_conv_create */
+#define VS_CONV_FLIP_IN 1u  /* read input channels in reversed order  (folds flow.py:88-95 Flip into the weights) */
+#define VS_CONV_FLIP_OUT 2u /* write output rows in reversed order (within each half for PAIRED)                 */
+
+VS_API int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int dilation_or_stride, int padding,
+                          unsigned flags);
+VS_API void vs_conv_destroy(vs_conv_t *h);
+/* w: [c_out, c_in, k] ([c_in, c_out, k] for transpose).  g == NULL: w is the effective weight;
+ * g != NULL: w is weight_v and g is weight_g ([dim0,1,1]) -> folded on the device.  bias may be NULL.          */
+VS_API int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const float *bias, void *stream);
+
+/* One output destination of a conv launch.  Strides are in floats; row stride is always the time length. */
+typedef struct vs_conv_out {
+    float *y;            /* [B, rows, T_out] with batch stride y_bs                                              */
+    const float *res;    /* optional residual input, same indexing as y (batch stride res_bs); may alias y       */
+    const float *acc;    /* optional accumulate input, same indexing as y (batch stride acc_bs); may alias y     */
+    int64_t y_bs, res_bs, acc_bs;
+    float scale;         /* applied after the adds; 0.0f means unset (= 1.0f)                                    */
+    int out_act;         /* enum vs_out_act                                                                      */
+    int out_mask;        /* != 0: multiply by mask[b, t]                                                         */
+    int mode;            /* enum vs_out_mode                                                                     */
+} vs_conv_out_t;
+
+typedef struct vs_conv_io {
+    const float *x;      /* [B, c_in, T] with batch stride x_bs (0 -> c_in*T)                                    */
+    int64_t x_bs;
+    int64_t B, T;
+    int in_act;          /* enum vs_in_act, applied while staging x into LDS                                     */
+    const float *mask;   /* [B, T] frame mask for VS_IN_MASK / out_mask / coupling modes (NULL if unused)        */
+    const float *bias_b; /* optional per-item bias [B, c_out] (conditioning), row stride bias_b_bs               */
+    int64_t bias_b_bs;
+    int split_row;       /* rows [0, split_row) go to out[0], rows [split_row, c_out) to out[1] (row - split_row);
+                            0 or >= c_out: everything goes to out[0]                                             */
+    vs_conv_out_t out[2];
+    int pair_mode;       /* PAIRED only: enum vs_pair_mode; result rows = c_out/2, written through out[0]
+                            (res = x1 for the coupling modes)                                                    */
+    float *logdet;       /* PAIRED + COUPLING_FWD: [B] accumulated (+=) with sum(logs * mask); may be NULL       */
+} vs_conv_io_t;
+
+VS_API int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream);
+/* length of the time axis produced for an input of length T */
+VS_API int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISINGER_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libvisinger_hip.so (the C ABI declared in include/visinger_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing or no MI355X is
+visible, importing callers get a loud RuntimeError instead of a silently different code path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvisinger_hip.so")
+
+VS_OK = 0
+# enum vs_conv_kind
+CONV1D, CONV_TRANSPOSE1D, CONV1D_PAIRED = 0, 1, 2
+# enum vs_in_act / vs_out_act / vs_pair_mode / vs_out_mode
+IN_NONE, IN_LRELU, IN_MASK = 0, 1, 2
+OUT_NONE, OUT_TANH, OUT_RELU = 0, 1, 2
+PAIR_GATE, PAIR_COUPLING_FWD, PAIR_COUPLING_INV = 0, 1, 2
+MODE_LINEAR, MODE_COUPLING_MEAN_FWD, MODE_COUPLING_MEAN_INV = 0, 1, 2
+FLIP_IN, FLIP_OUT = 1, 2
+
+_f32p = ctypes.c_void_p
+
+
+class ConvOut(ctypes.Structure):
+    _fields_ = [("y", _f32p), ("res", _f32p), ("acc", _f32p),
+                ("y_bs", ctypes.c_int64), ("res_bs", ctypes.c_int64), ("acc_bs", ctypes.c_int64),
+                ("scale", ctypes.c_float), ("out_act", ctypes.c_int), ("out_mask", ctypes.c_int),
+                ("mode", ctypes.c_int)]
+
+
+class ConvIO(ctypes.Structure):
+    _fields_ = [("x", _f32p), ("x_bs", ctypes.c_int64), ("B", ctypes.c_int64), ("T", ctypes.c_int64),
+                ("in_act", ctypes.c_int), ("mask", _f32p), ("bias_b", _f32p), ("bias_b_bs", ctypes.c_int64),
+                ("split_row", ctypes.c_int), ("out", ConvOut * 2), ("pair_mode", ctypes.c_int),
+                ("logdet", _f32p)]
+
+
+_lib = None
+
+
+class VisingerHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libvisinger_hip.so.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VisingerHipError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m visinger_amd.csrc.build, or "
+            f"__graft_entry__.build()).  visinger_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.vs_last_error.restype = ctypes.c_char_p
+    L.vs_abi_version.restype = ctypes.c_int
+    L.vs_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    L.vs_weightnorm_fold.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.vs_conv_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
+    L.vs_conv_destroy.argtypes = [ctypes.c_void_p]
+    L.vs_conv_destroy.restype = None
+    L.vs_conv_set_weights.argtypes = [ctypes.c_void_p, _f32p, _f32p, _f32p, ctypes.c_void_p]
+    L.vs_conv_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(ConvIO), ctypes.c_void_p]
+    L.vs_conv_out_len.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.vs_conv_out_len.restype = ctypes.c_int64
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != VS_OK:
+        raise VisingerHipError(f"libvisinger_hip error {rc}: {lib().vs_last_error().decode()}")
+
+
+def require_gpu():
+    """Fail loudly when the HIP path cannot run (no GPU / library not built)."""
+    import torch
+    L = lib()
+    if not torch.cuda.is_available():
+        raise VisingerHipError("visinger_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU path.")
+    return L
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    import torch
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise VisingerHipError(f"expected a contiguous fp32 tensor on the GPU, got {t.dtype} {t.device} "
+                               f"contiguous={t.is_contiguous()}")
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,700 @@
+// conv_engine.hip -- the implicit-GEMM 1-D convolution engine of the VISinger hot path on gfx950.
+//
+// One kernel family serves every nn.Conv1d / nn.ConvTranspose1d of the path (reference sites listed in
+// include/visinger_hip.h).  It is an implicit GEMM on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (bit-identical to a k-ordered fmaf chain, 64 FLOP/clk/SIMD = the fp32 peak of the chip):
+//
+//     D[m, n] = sum_{tap} sum_{ci}  Wp[tap][m][ci] * f(x[b, ci, n + off(tap)])
+//
+//   * A operand = weights, pre-packed ONCE on the device into fragment order Wp[m_tile][tap][ci_pair][64 lanes]
+//     (lane l holds W[m_tile*32 + (l&31)][2*ci_pair + (l>>5)]) so a wave fetches one fragment with a single
+//     coalesced 256-B load (served by L2/L1: the weights of a conv are <= 3 MB and shared by every workgroup);
+//   * B operand = activations, staged ONCE per (ci-chunk, time tile + halo) into LDS as Xs[ci][n]; every tap reads
+//     a shifted window of the same LDS rows (conflict-free ds_read_b32: 32 consecutive dwords per half-wave), so
+//     HBM/L2 sees each activation once per M-block no matter how many taps the conv has;
+//   * transposed convs run as a polyphase conv over "virtual rows" m = phase*C_out + co with per-tile tap
+//     ranges (no multiplies by structural zeros) and an interleaving store;
+//   * the input transform (leaky-relu / mask) is applied while staging; bias, conditioning bias, residual add,
+//     accumulate, scale, tanh, mask, WaveNet gate, res/skip split and the affine-coupling update (+ log-det
+//     wave-shuffle reduction) are fused into the epilogue, so no elementwise kernel ever touches HBM.
+//
+// Tile: 4 waves (256 threads), each wave owns MT_W x NT_W accumulator tiles of 32x32 (16 VGPRs each); two
+// workgroups per CU (2 waves/SIMD) hide the staging of one behind the MFMAs of the other.
+#include "vs_internal.h"
+
+#include <algorithm>
+#include <new>
+
+namespace vs {
+
+thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 16;        // input channels staged per LDS chunk
+constexpr int MAX_SPAN = 64;  // max (taps-1)*dilation supported by the LDS window
+constexpr int MT_ALLOC = 8;   // packed weights are zero-padded to a multiple of this many M tiles
+
+struct OutSpec {
+    float *y;
+    const float *res;
+    const float *acc;
+    long long y_bs, res_bs, acc_bs;
+    float scale;
+    int out_act, out_mask, mode;
+};
+
+struct ConvParams {
+    const float *x;
+    long long x_bs;
+    const float *wp;      // packed weights
+    const float *biasp;   // packed bias over virtual rows (always present, zeros if no bias)
+    const float *bias_b;  // optional per-item bias over ORIGINAL rows
+    long long bias_b_bs;
+    const float *mask;    // [B, Tin]
+    float *logdet;
+    OutSpec out[2];
+    int split_row;
+    int kind, pair_mode, in_act;
+    int B, Cin, Tin;
+    int M;        // valid virtual rows
+    int MT;       // virtual M tiles
+    int N;        // virtual columns (time positions computed)
+    int Tout;     // true output length (row stride of y)
+    int c_out;    // original output rows
+    int Hh;       // PAIRED: half rows
+    int KT, CP, nchunks;
+    int off0, tstep, lo, W;
+    int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
+    int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
+};
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// tanh via one exp: t = e^{-2|x|} in (0,1], tanh|x| = (1-t)/(1+t).  Branch-free; absolute error <= ~1e-7 (the
+// subtraction is exact, the error is t's rounding), which is what a tanh-bounded output needs.  The device
+// library's tanhf is branchy and would be inlined once per accumulator register.
+__device__ __forceinline__ float tanh_fast(float v) {
+    const float t = expf(-2.0f * fabsf(v));
+    return copysignf((1.0f - t) / (1.0f + t), v);
+}
+
+template <int MT_W, int NT_W, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(const ConvParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BN = 32 * NT_W * WAVES_N;
+    constexpr int MAXW = BN + MAX_SPAN;
+    constexpr int RPW = CK / NW;                 // LDS rows staged per wave
+    constexpr int CIT = (MAXW + 63) / 64;        // column iterations per row
+    static_assert(CK % NW == 0, "CK must be a multiple of the wave count");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M;
+    const int wn = wave / WAVES_M;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * BN;
+    const int mt0 = (blockIdx.y * WAVES_M + wm) * MT_W;
+    const int W = p.W;
+    float *const buf0 = smem;
+    float *const buf1 = smem + CK * W;
+    const float *const xb = p.x + (long long)b * p.x_bs;
+    const float *const maskb = p.mask ? p.mask + (long long)b * p.Tin : nullptr;
+
+    // ---- tap range of this wave (polyphase transposed conv: skip the structurally-zero taps) ----
+    int tap_b = 0, tap_e = p.KT;
+    if (p.kind == VS_CONV_TRANSPOSE1D && (p.c_out & 31) == 0) {
+        // every 32-row tile has one phase; MT_W tiles of a wave may differ -> union
+        int lo_t = p.KT, hi_t = 0;
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i) {
+            const int phase = ((mt0 + i) * 32) / p.c_out;
+            if (phase < p.up) {
+                // delta range with 0 <= delta*up + phase + pad < K
+                const int num_lo = -(phase + p.uppad);                    // delta >= ceil(num_lo / up)
+                const int dlo = (num_lo >= 0) ? (num_lo + p.up - 1) / p.up : -((-num_lo) / p.up);
+                const int num_hi = p.upK - 1 - phase - p.uppad;           // delta <= floor(num_hi / up)
+                const int dhi = (num_hi >= 0) ? num_hi / p.up : -((-num_hi + p.up - 1) / p.up);
+                lo_t = min(lo_t, dlo - p.dmin);
+                hi_t = max(hi_t, dhi - p.dmin + 1);
+            }
+        }
+        tap_b = max(0, lo_t);
+        tap_e = min(p.KT, hi_t);
+    }
+
+    f32x16 acc[MT_W][NT_W];
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float st[RPW][CIT];
+    float mk[CIT];
+    const int in_act = p.in_act;
+
+    // Staging loads are UNCONDITIONAL (clamped addresses) and the zero-fill is applied when the registers are
+    // written to LDS: a predicated load makes hipcc branch around every load and drain vmcnt(0) per element.
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+            const int n = n0 + p.lo + lane + 64 * i;
+            const int nc = min(max(n, 0), p.Tin - 1);
+            if (in_act == VS_IN_MASK) mk[i] = maskb[nc];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const int ci = min(chunk * CK + wave + NW * j, p.Cin - 1);
+                st[j][i] = xb[(long long)ci * p.Tin + nc];
+            }
+        }
+    };
+    auto stage_store = [&](float *buf, int chunk) {
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+            const int col = lane + 64 * i;
+            const int n = n0 + p.lo + col;
+            const bool okn = (n >= 0) && (n < p.Tin);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const bool ok = okn && (chunk * CK + wave + NW * j < p.Cin);
+                float v = ok ? st[j][i] : 0.f;
+                v = (in_act == VS_IN_LRELU) ? lrelu(v) : v;
+                v = (in_act == VS_IN_MASK) ? v * mk[i] : v;
+                if (col < W) buf[(wave + NW * j) * W + col] = v;
+            }
+        }
+    };
+
+    const int lhalf = lane >> 5;
+    const int l31 = lane & 31;
+
+    stage_load(0);
+    stage_store(buf0, 0);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const float *cur = (chunk & 1) ? buf1 : buf0;
+        const bool more = (chunk + 1 < p.nchunks);
+        if (more) stage_load(chunk + 1);
+
+        // Software pipeline (hipcc does not build one by itself): the 8 A fragments of tap t+1 are requested from
+        // L2 while tap t computes, and the B fragments of k-step s+1 are read from LDS under the MFMAs of step s.
+        const float *const xs0 = cur + lhalf * W + wn * (NT_W * 32) + l31 - p.lo;
+        const float *wbase[MT_W];
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i)
+            wbase[i] = p.wp + ((long long)(mt0 + i) * p.KT * p.CP + chunk * (CK / 2)) * 64 + lane;
+        float a_cur[MT_W][CK / 2], a_nxt[MT_W][CK / 2];
+        if (tap_b < tap_e) {
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+                for (int cp = 0; cp < CK / 2; ++cp) a_cur[i][cp] = wbase[i][((long long)tap_b * p.CP + cp) * 64];
+        }
+        for (int tap = tap_b; tap < tap_e; ++tap) {
+            if (tap + 1 < tap_e) {
+#pragma unroll
+                for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+                    for (int cp = 0; cp < CK / 2; ++cp)
+                        a_nxt[i][cp] = wbase[i][((long long)(tap + 1) * p.CP + cp) * 64];
+            }
+            const float *xs = xs0 + (p.off0 + tap * p.tstep);
+            float bf[NT_W], bn[NT_W];
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j) bf[j] = xs[j * 32];
+#pragma unroll
+            for (int cp = 0; cp < CK / 2; ++cp) {
+                if (cp + 1 < CK / 2) {
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j) bn[j] = xs[(cp + 1) * 2 * W + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][cp], bf[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) bf[j] = bn[j];
+            }
+#pragma unroll
+            for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+                for (int cp = 0; cp < CK / 2; ++cp) a_cur[i][cp] = a_nxt[i][cp];
+        }
+
+        if (more) stage_store((chunk & 1) ? buf0 : buf1, chunk + 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // All loops have constant trip counts and no early exits (acc[][][] must stay in registers); every global
+    // LOAD is unconditional on a clamped address and issued NT_W at a time ahead of its uses, only the STORES are
+    // predicated -- a predicated load would cost a branch and a full vmcnt(0) drain per element.
+    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
+    int ncol[NT_W];
+#pragma unroll
+    for (int j = 0; j < NT_W; ++j) ncol[j] = n0 + (wn * NT_W + j) * 32 + l31;
+
+    if (p.kind == VS_CONV1D_PAIRED) {
+        if constexpr (MT_W == 2) {
+            // tiles (2i, 2i+1) of this wave hold rows c (first half) and Hh + c (second half)
+            const OutSpec o = p.out[0];
+            const int pair = mt0 >> 1;
+            const int pmode = p.pair_mode;
+            float ld_sum = 0.f;
+            float mval[NT_W];
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j) mval[j] = maskb ? maskb[min(ncol[j], p.Tin - 1)] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rt = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int c = pair * 32 + rt;
+                const bool okc = c < p.Hh;
+                const int cc = min(c, p.Hh - 1);
+                const int cm = pair * 64 + rt;   // virtual row of the first half
+                float b0 = p.biasp[cm], b1 = p.biasp[cm + 32];
+                if (bbias) { b0 += bbias[cc]; b1 += bbias[p.Hh + cc]; }
+                float x1[NT_W];
+                if (pmode != VS_PAIR_GATE) {
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j)
+                        x1[j] = o.res[(long long)b * o.res_bs + (long long)cc * p.Tout + min(ncol[j], p.Tout - 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) {
+                    const float v0 = acc[0][j][r] + b0, v1 = acc[1][j][r] + b1;
+                    const bool ok = okc && ncol[j] < p.N;
+                    float outv;
+                    if (pmode == VS_PAIR_GATE) {
+                        outv = tanh_fast(v0) * sigmoidf_(v1);
+                    } else {
+                        const float m = v0 * mval[j], logs = v1 * mval[j];
+                        if (pmode == VS_PAIR_COUPLING_FWD) {
+                            outv = m + x1[j] * expf(logs) * mval[j];
+                            ld_sum += ok ? logs : 0.f;
+                        } else {
+                            outv = (x1[j] - m) * expf(-logs) * mval[j];
+                        }
+                    }
+                    if (ok) o.y[(long long)b * o.y_bs + (long long)c * p.Tout + ncol[j]] = outv;
+                }
+            }
+            if (pmode == VS_PAIR_COUPLING_FWD && p.logdet) {
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) ld_sum += __shfl_xor(ld_sum, s);
+                if (lane == 0) atomicAdd(p.logdet + b, ld_sum);
+            }
+        }
+        return;
+    }
+
+    // Every 32-row tile goes to exactly one output spec (the host guarantees split_row % 32 == 0 or launches the
+    // two specs separately with a row window), so the spec, its null-checks and its mode are wave-uniform.
+    const bool transposed = (p.kind == VS_CONV_TRANSPOSE1D);
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i) {
+        const int tile_row0 = (mt0 + i) * 32;
+        const bool s1 = (p.split_row > 0) && (tile_row0 >= p.split_row);
+        const OutSpec o = s1 ? p.out[1] : p.out[0];
+        const int row_sub = s1 ? p.split_row : 0;
+        const bool has_res = o.res != nullptr, has_acc = o.acc != nullptr;
+        const bool use_mask = (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            const int mc = min(m, p.M - 1);
+            int row = mc, phase = 0;
+            if (transposed) { phase = mc / p.c_out; row = mc - phase * p.c_out; }
+            const bool okm = (m < p.M) && (row >= p.row_lo) && (row < p.row_hi);
+            float badd = p.biasp[mc];
+            if (bbias) badd += bbias[row];
+            const long long roff = (long long)(row - row_sub) * p.Tout;
+            float *const y = o.y + (long long)b * o.y_bs + roff;
+            int col[NT_W], cc[NT_W];
+            float rv[NT_W], av[NT_W], mv[NT_W];
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j) {
+                col[j] = transposed ? ncol[j] * p.up + phase : ncol[j];
+                cc[j] = min(col[j], p.Tout - 1);
+                rv[j] = 0.f; av[j] = 0.f; mv[j] = 1.f;
+            }
+            if (has_res) {
+                const float *res = o.res + (long long)b * o.res_bs + roff;
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) rv[j] = res[cc[j]];
+            }
+            if (has_acc) {
+                const float *ac = o.acc + (long long)b * o.acc_bs + roff;
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) av[j] = ac[cc[j]];
+            }
+            if (use_mask) {
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) mv[j] = maskb[cc[j]];
+            }
+            float outv[NT_W];
+            if (o.mode == VS_OUT_LINEAR) {
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) outv[j] = (acc[i][j][r] + badd + rv[j] + av[j]) * o.scale;
+                if (o.out_act == VS_OUT_TANH) {
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j) outv[j] = tanh_fast(outv[j]);
+                } else if (o.out_act == VS_OUT_RELU) {
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j) outv[j] = fmaxf(outv[j], 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) outv[j] *= mv[j];
+            } else if (o.mode == VS_OUT_COUPLING_MEAN_FWD) {
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) outv[j] = (acc[i][j][r] + badd) * mv[j] + rv[j] * mv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) outv[j] = (rv[j] - (acc[i][j][r] + badd) * mv[j]) * mv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j)
+                if (okm && ncol[j] < p.N && col[j] < p.Tout) y[col[j]] = outv[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight-norm row scales and packing
+
+// scale[r] = g[r] / ||v[r, :]||_2 ; one wave per row
+__global__ void rownorm_scale_kernel(const float *__restrict__ v, const float *__restrict__ g, float *__restrict__ scale,
+                                     long long rows, long long cols) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *vr = v + row * cols;
+    float ss = 0.f;
+    for (long long c = lane; c < cols; c += 64) ss += vr[c] * vr[c];
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) ss += __shfl_xor(ss, s);
+    if (lane == 0) scale[row] = g[row] / sqrtf(ss);
+}
+
+__global__ void weightnorm_apply_kernel(const float *__restrict__ v, const float *__restrict__ scale, float *__restrict__ w,
+                                        long long rows, long long cols) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) w[i] = v[i] * scale[i / cols];
+}
+
+struct PackParams {
+    const float *w;      // source weight (or weight_v)
+    const float *scale;  // per-dim0 scale (weight norm) or null
+    const float *bias;   // source bias or null
+    float *wp;
+    float *biasp;
+    int kind, c_in, c_out, k, up, pad, dmin, KT, CP, MT_alloc, Hh;
+    unsigned flags;
+};
+
+__global__ void pack_conv_kernel(const PackParams q) {
+    const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (long long)q.MT_alloc * 32) {   // bias over virtual rows
+        const int m = (int)e;
+        float bv = 0.f;
+        int row = -1;
+        if (q.kind == VS_CONV1D) {
+            if (m < q.c_out) row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
+        } else if (q.kind == VS_CONV1D_PAIRED) {
+            const int pair = m >> 6, which = (m >> 5) & 1, c = pair * 32 + (m & 31);
+            if (c < q.Hh) row = which * q.Hh + ((q.flags & VS_CONV_FLIP_OUT) ? q.Hh - 1 - c : c);
+        } else {
+            const int phase = m / q.c_out;
+            if (phase < q.up) row = m - phase * q.c_out;
+        }
+        if (row >= 0 && q.bias) bv = q.bias[row];
+        q.biasp[m] = bv;
+    }
+    if (e >= total) return;
+    const int lane = (int)(e & 63);
+    long long t = e >> 6;
+    const int cp = (int)(t % q.CP);
+    t /= q.CP;
+    const int tap = (int)(t % q.KT);
+    const int mt = (int)(t / q.KT);
+    const int m = mt * 32 + (lane & 31);
+    int ci = cp * 2 + (lane >> 5);
+    float val = 0.f;
+    if (ci < q.c_in) {
+        if (q.flags & VS_CONV_FLIP_IN) ci = q.c_in - 1 - ci;
+        if (q.kind == VS_CONV1D) {
+            if (m < q.c_out) {
+                const int row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
+                val = q.w[((long long)row * q.c_in + ci) * q.k + tap];
+                if (q.scale) val *= q.scale[row];
+            }
+        } else if (q.kind == VS_CONV1D_PAIRED) {
+            const int pair = mt >> 1, which = mt & 1, c = pair * 32 + (lane & 31);
+            if (c < q.Hh) {
+                const int row = which * q.Hh + ((q.flags & VS_CONV_FLIP_OUT) ? q.Hh - 1 - c : c);
+                val = q.w[((long long)row * q.c_in + ci) * q.k + tap];
+                if (q.scale) val *= q.scale[row];
+            }
+        } else {  // transposed: w is [c_in, c_out, k]; virtual row m = phase*c_out + co; tap <-> delta = dmin + tap
+            const int phase = m / q.c_out;
+            if (phase < q.up) {
+                const int co = m - phase * q.c_out;
+                const int kk = (q.dmin + tap) * q.up + phase + q.pad;
+                if (kk >= 0 && kk < q.k) {
+                    val = q.w[((long long)ci * q.c_out + co) * q.k + kk];
+                    if (q.scale) val *= q.scale[ci];
+                }
+            }
+        }
+    }
+    q.wp[e] = val;
+}
+
+static inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+static inline int ceil_div_i(int a, int b) { return -floor_div(-a, b); }
+
+}  // namespace vs
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+
+struct vs_conv {
+    int kind, c_in, c_out, k, dil, pad;   // dil = stride for transposed
+    unsigned flags;
+    int M, MT, MT_alloc, KT, CP, nchunks, off0, tstep, lo, span, dmin, Hh;
+    bool weights_set = false;
+    vs::DevBuf wp, biasp, scale;
+};
+
+using namespace vs;
+
+template <int MT_W, int NT_W, int WAVES_M, int WAVES_N>
+static int launch_cfg(const ConvParams &p, hipStream_t s) {
+    constexpr int BN = 32 * NT_W * WAVES_N;
+    constexpr int BM_TILES = MT_W * WAVES_M;
+    auto kern = conv_mfma_kernel<MT_W, NT_W, WAVES_M, WAVES_N>;
+    const size_t lds = (size_t)2 * CK * p.W * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, BM_TILES), (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+extern "C" {
+
+const char *vs_last_error(void) { return g_err; }
+int vs_abi_version(void) { return 1; }
+
+int vs_device_info(char *buf, size_t n) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) cnt = 0;
+    if (buf && n) {
+        buf[0] = 0;
+        if (cnt > 0) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, 0) == hipSuccess) snprintf(buf, n, "%s (%s)", pr.name, pr.gcnArchName);
+        }
+    }
+    return cnt;
+}
+
+int vs_weightnorm_fold(const float *v, const float *g, float *w, int64_t rows, int64_t cols, void *stream) {
+    VS_REQUIRE(v && g && w && rows > 0 && cols > 0, "vs_weightnorm_fold: bad arguments");
+    hipStream_t s = as_stream(stream);
+    float *scale = nullptr;
+    VS_CHECK_HIP(hipMallocAsync((void **)&scale, sizeof(float) * rows, s));
+    hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, v, g, scale,
+                       (long long)rows, (long long)cols);
+    hipLaunchKernelGGL(weightnorm_apply_kernel, dim3((unsigned)ceil_div(rows * cols, 256)), dim3(256), 0, s, v, scale, w,
+                       (long long)rows, (long long)cols);
+    VS_CHECK_HIP(hipGetLastError());
+    VS_CHECK_HIP(hipFreeAsync(scale, s));
+    return VS_OK;
+}
+
+int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int dil, int pad, unsigned flags) {
+    VS_REQUIRE(out, "vs_conv_create: out is NULL");
+    *out = nullptr;
+    VS_REQUIRE(kind >= VS_CONV1D && kind <= VS_CONV1D_PAIRED, "vs_conv_create: unknown kind %d", kind);
+    VS_REQUIRE(c_in > 0 && c_out > 0 && k > 0 && dil > 0 && pad >= 0, "vs_conv_create: bad dims");
+    VS_REQUIRE(kind != VS_CONV1D_PAIRED || (c_out % 2 == 0), "vs_conv_create: PAIRED needs even c_out");
+    vs_conv *h = new (std::nothrow) vs_conv();
+    if (!h) { set_error("out of host memory"); return VS_ENOMEM; }
+    h->kind = kind; h->c_in = c_in; h->c_out = c_out; h->k = k; h->dil = dil; h->pad = pad; h->flags = flags;
+    h->Hh = c_out / 2;
+    if (kind == VS_CONV_TRANSPOSE1D) {
+        const int u = dil;
+        h->M = u * c_out;
+        h->dmin = ceil_div_i(-(u - 1) - pad, u);
+        const int dmax = floor_div(k - 1 - pad, u);
+        h->KT = dmax - h->dmin + 1;
+        h->off0 = -h->dmin;      // x index = q - delta = q - dmin - tap
+        h->tstep = -1;
+    } else {
+        h->M = (kind == VS_CONV1D_PAIRED) ? 2 * 32 * (int)ceil_div(h->Hh, 32) : c_out;
+        h->KT = k;
+        h->off0 = -pad;
+        h->tstep = dil;
+        h->dmin = 0;
+    }
+    const int off_last = h->off0 + (h->KT - 1) * h->tstep;
+    h->lo = std::min(h->off0, off_last);
+    h->span = std::max(h->off0, off_last) - h->lo;
+    if (h->span > MAX_SPAN) {
+        set_error("vs_conv_create: receptive span %d exceeds the LDS window (%d)", h->span, MAX_SPAN);
+        delete h;
+        return VS_EUNSUPPORTED;
+    }
+    h->MT = (int)ceil_div(h->M, 32);
+    h->MT_alloc = (int)ceil_div(h->MT, MT_ALLOC) * MT_ALLOC;
+    h->nchunks = (int)ceil_div(c_in, CK);
+    h->CP = h->nchunks * (CK / 2);
+    *out = h;
+    return VS_OK;
+}
+
+void vs_conv_destroy(vs_conv_t *h) { delete h; }
+
+int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T) {
+    if (!h) return -1;
+    if (h->kind == VS_CONV_TRANSPOSE1D) return (T - 1) * h->dil - 2 * h->pad + h->k;
+    return T + 2 * h->pad - (int64_t)h->dil * (h->k - 1);
+}
+
+int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const float *bias, void *stream) {
+    VS_REQUIRE(h && w, "vs_conv_set_weights: NULL handle or weight");
+    hipStream_t s = as_stream(stream);
+    const size_t n = (size_t)h->MT_alloc * h->KT * h->CP * 64;
+    VS_TRY(h->wp.reserve(n * sizeof(float)));
+    VS_TRY(h->biasp.reserve((size_t)h->MT_alloc * 32 * sizeof(float)));
+    const float *scale = nullptr;
+    if (g) {
+        // weight_norm(dim=0): rows = dim 0 of the weight (c_out for Conv1d, c_in for ConvTranspose1d)
+        const long long rows = (h->kind == VS_CONV_TRANSPOSE1D) ? h->c_in : h->c_out;
+        const long long cols = (long long)h->c_in * h->c_out * h->k / rows;
+        VS_TRY(h->scale.reserve(rows * sizeof(float)));
+        hipLaunchKernelGGL(rownorm_scale_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, w, g,
+                           h->scale.as<float>(), rows, cols);
+        scale = h->scale.as<float>();
+    }
+    PackParams q;
+    q.w = w; q.scale = scale; q.bias = bias; q.wp = h->wp.as<float>(); q.biasp = h->biasp.as<float>();
+    q.kind = h->kind; q.c_in = h->c_in; q.c_out = h->c_out; q.k = h->k; q.up = h->dil; q.pad = h->pad; q.dmin = h->dmin;
+    q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags;
+    const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
+    VS_CHECK_HIP(hipGetLastError());
+    h->weights_set = true;
+    return VS_OK;
+}
+
+int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
+    VS_REQUIRE(h && io, "vs_conv_forward: NULL handle or io");
+    VS_REQUIRE(h->weights_set, "vs_conv_forward: weights not set");
+    VS_REQUIRE(io->x && io->B > 0 && io->T > 0, "vs_conv_forward: bad input");
+    VS_REQUIRE(io->out[0].y, "vs_conv_forward: out[0].y is NULL");
+    const int64_t Tout = vs_conv_out_len(h, io->T);
+    VS_REQUIRE(Tout > 0, "vs_conv_forward: empty output");
+    VS_REQUIRE(io->B <= 65535, "vs_conv_forward: B too large for grid.z");
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = io->x;
+    p.x_bs = io->x_bs ? io->x_bs : (long long)h->c_in * io->T;
+    p.wp = h->wp.as<float>();
+    p.biasp = h->biasp.as<float>();
+    p.bias_b = io->bias_b;
+    p.bias_b_bs = io->bias_b_bs ? io->bias_b_bs : h->c_out;
+    p.mask = io->mask;
+    p.logdet = io->logdet;
+    p.kind = h->kind;
+    p.pair_mode = io->pair_mode;
+    p.in_act = io->in_act;
+    p.B = (int)io->B; p.Cin = h->c_in; p.Tin = (int)io->T;
+    p.M = h->M; p.MT = h->MT; p.c_out = h->c_out; p.Hh = h->Hh;
+    p.Tout = (int)Tout;
+    p.N = (h->kind == VS_CONV_TRANSPOSE1D) ? (int)ceil_div(Tout, h->dil) : (int)Tout;
+    p.KT = h->KT; p.CP = h->CP; p.nchunks = h->nchunks;
+    p.off0 = h->off0; p.tstep = h->tstep; p.lo = h->lo;
+    p.up = (h->kind == VS_CONV_TRANSPOSE1D) ? h->dil : 1;
+    p.upK = h->k; p.uppad = h->pad; p.dmin = h->dmin;
+    const int rows_out = (h->kind == VS_CONV1D_PAIRED) ? h->Hh : h->c_out;
+    p.split_row = (io->split_row > 0 && io->split_row < rows_out && h->kind != VS_CONV1D_PAIRED) ? io->split_row : 0;
+    bool need_mask = (io->in_act == VS_IN_MASK);
+    for (int s = 0; s < 2; ++s) {
+        const vs_conv_out_t &o = io->out[s];
+        OutSpec &d = p.out[s];
+        const int rows = (s == 0) ? (p.split_row ? p.split_row : rows_out) : (rows_out - p.split_row);
+        const long long dflt = (long long)rows * Tout;
+        d.y = o.y; d.res = o.res; d.acc = o.acc;
+        d.y_bs = o.y_bs ? o.y_bs : dflt; d.res_bs = o.res_bs ? o.res_bs : dflt; d.acc_bs = o.acc_bs ? o.acc_bs : dflt;
+        d.scale = (o.scale == 0.f) ? 1.f : o.scale;   // 0 = unset
+        d.out_act = o.out_act; d.out_mask = o.out_mask; d.mode = o.mode;
+        if (s == 0 || p.split_row) {
+            need_mask |= (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
+            VS_REQUIRE(o.mode == VS_OUT_LINEAR || o.res, "vs_conv_forward: coupling mode needs res (x1)");
+        }
+    }
+    VS_REQUIRE(!p.split_row || io->out[1].y, "vs_conv_forward: split_row set but out[1].y is NULL");
+    if (h->kind == VS_CONV1D_PAIRED) {
+        VS_REQUIRE(io->pair_mode >= VS_PAIR_GATE && io->pair_mode <= VS_PAIR_COUPLING_INV, "bad pair_mode");
+        if (io->pair_mode != VS_PAIR_GATE) {
+            VS_REQUIRE(io->out[0].res, "vs_conv_forward: coupling pair mode needs out[0].res (x1)");
+            need_mask = true;
+        }
+    }
+    VS_REQUIRE(!need_mask || io->mask, "vs_conv_forward: mask required but NULL");
+    VS_REQUIRE(Tout == io->T || !need_mask || h->kind != VS_CONV_TRANSPOSE1D, "mask with transposed conv unsupported");
+    hipStream_t s = as_stream(stream);
+
+    if (h->kind == VS_CONV1D_PAIRED) {
+        p.row_lo = 0;
+        p.row_hi = h->c_out;
+        if (h->MT >= 4) { p.W = 128 + h->span; return launch_cfg<2, 2, 2, 2>(p, s); }
+        p.W = 256 + h->span;
+        return launch_cfg<2, 2, 1, 4>(p, s);
+    }
+    auto launch = [&](const ConvParams &q) -> int {
+        if (h->MT >= 3) return launch_cfg<1, 8, 4, 1>(q, s);
+        if (h->MT == 2) return launch_cfg<1, 8, 2, 2>(q, s);
+        return launch_cfg<1, 4, 1, 4>(q, s);
+    };
+    p.W = ((h->MT >= 3) ? 256 : 512) + h->span;
+    p.row_lo = 0;
+    p.row_hi = h->c_out;
+    if (p.split_row && (p.split_row % 32) != 0) {
+        // a 32-row tile would straddle the two destinations: store them in two passes (odd sizes only; the
+        // production split is hidden_channels = 192 = 6 tiles)
+        ConvParams q = p;
+        q.split_row = 0;
+        q.row_hi = p.split_row;
+        VS_TRY(launch(q));
+        q.out[0] = p.out[1];
+        q.row_lo = p.split_row;
+        q.row_hi = h->c_out;
+        // rows are addressed relative to split_row in the second destination
+        q.out[0].y -= (long long)p.split_row * p.Tout;
+        if (q.out[0].res) q.out[0].res -= (long long)p.split_row * p.Tout;
+        if (q.out[0].acc) q.out[0].acc -= (long long)p.split_row * p.Tout;
+        return launch(q);
+    }
+    return launch(p);
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Internal helpers shared by the HIP translation units of libvisinger_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/visinger_hip.h"
+
+namespace vs {
+
+void set_error(const char *fmt, ...);
+
+#define VS_CHECK_HIP(expr)                                                                             \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            vs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));       \
+            return VS_EHIP;                                                                            \
+        }                                                                                              \
+    } while (0)
+
+#define VS_REQUIRE(cond, ...)             \
+    do {                                  \
+        if (!(cond)) {                    \
+            vs::set_error(__VA_ARGS__);   \
+            return VS_EINVAL;             \
+        }                                 \
+    } while (0)
+
+#define VS_TRY(expr)                 \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != VS_OK) return rc_; \
+    } while (0)
+
+// Device buffer owned by a handle (grown, never shrunk; hipMalloc happens off the steady-state path).
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n) {
+        if (n <= bytes) return VS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            return VS_ENOMEM;
+        }
+        bytes = n;
+        return VS_OK;
+    }
+    template <typename T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace vs

@@ -1,0 +1,102 @@
+"""Thin Python objects over the C-ABI operator handles (include/visinger_hip.h).  Plumbing only: tensors in,
+device pointers and the current HIP stream out.  Used by visinger_amd.modules.* and by the GPU parity tests."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _off(t, elems):
+    """pointer `elems` floats into tensor t"""
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
+
+
+class ConvOp:
+    """vs_conv_t: one nn.Conv1d / nn.ConvTranspose1d site, weights folded + packed on the device."""
+
+    def __init__(self, kind, c_in, c_out, k, dilation_or_stride=1, padding=0, flags=0):
+        self.lib = L.require_gpu()
+        self.kind, self.c_in, self.c_out, self.k = kind, c_in, c_out, k
+        self.dil, self.pad, self.flags = dilation_or_stride, padding, flags
+        h = ctypes.c_void_p()
+        L.check(self.lib.vs_conv_create(ctypes.byref(h), kind, c_in, c_out, k, dilation_or_stride, padding, flags))
+        self.h = h
+        self._wkey = None
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.vs_conv_destroy(h)
+            except Exception:
+                pass
+
+    def out_len(self, T):
+        return int(self.lib.vs_conv_out_len(self.h, T))
+
+    @property
+    def rows_out(self):
+        return self.c_out // 2 if self.kind == L.CONV1D_PAIRED else self.c_out
+
+    def set_weights(self, w, g=None, bias=None):
+        """w: weight or weight_v; g: weight_g or None; bias or None (contiguous fp32 CUDA tensors).
+        Re-packs only when a tensor changed (data_ptr / in-place version)."""
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in (w, g, bias))
+        if key == self._wkey:
+            return
+        w = w.detach()
+        g = None if g is None else g.detach()
+        bias = None if bias is None else bias.detach()
+        L.check(self.lib.vs_conv_set_weights(self.h, L.ptr(w.contiguous()), L.ptr(None if g is None else g.contiguous()),
+                                             L.ptr(None if bias is None else bias.contiguous()), L.stream_ptr()))
+        self._wkey = key
+
+    def forward(self, x, *, B=None, T=None, x_bs=0, in_act=L.IN_NONE, mask=None, bias_b=None, bias_b_bs=0,
+                y=None, y_bs=0, res=None, res_bs=0, acc=None, acc_bs=0, scale=1.0, out_act=L.OUT_NONE, out_mask=False,
+                mode=L.MODE_LINEAR, split_row=0, out1=None, pair_mode=L.PAIR_GATE, logdet=None,
+                x_ptr=None, y_ptr=None, res_ptr=None, acc_ptr=None):
+        """Launch.  x: [B, c_in, T] (or pass x_ptr/x_bs/B/T for a channel window of a larger tensor).
+        Returns y (allocated [B, rows_out, T_out] when not given)."""
+        if B is None:
+            B, _, T = x.shape
+        Tout = self.out_len(T)
+        if y is None and y_ptr is None:
+            rows = split_row if split_row else self.rows_out
+            y = torch.empty((B, rows, Tout), device=x.device, dtype=torch.float32)
+        io = L.ConvIO()
+        io.x = x_ptr if x_ptr is not None else L.ptr(x)
+        io.x_bs, io.B, io.T = x_bs, B, T
+        io.in_act = in_act
+        io.mask = L.ptr(mask)
+        io.bias_b = L.ptr(bias_b)
+        io.bias_b_bs = bias_b_bs
+        io.split_row = split_row
+        o = io.out[0]
+        o.y = y_ptr if y_ptr is not None else L.ptr(y)
+        o.res = res_ptr if res_ptr is not None else L.ptr(res)
+        o.acc = acc_ptr if acc_ptr is not None else L.ptr(acc)
+        o.y_bs, o.res_bs, o.acc_bs = y_bs, res_bs, acc_bs
+        o.scale, o.out_act, o.out_mask, o.mode = scale, out_act, int(bool(out_mask)), mode
+        if out1 is not None:
+            o1 = io.out[1]
+            o1.y = L.ptr(out1["y"])
+            o1.res = L.ptr(out1.get("res"))
+            o1.acc = L.ptr(out1.get("acc"))
+            o1.y_bs, o1.res_bs, o1.acc_bs = out1.get("y_bs", 0), out1.get("res_bs", 0), out1.get("acc_bs", 0)
+            o1.scale, o1.out_act = out1.get("scale", 1.0), out1.get("out_act", L.OUT_NONE)
+            o1.out_mask, o1.mode = int(bool(out1.get("out_mask", False))), out1.get("mode", L.MODE_LINEAR)
+        io.pair_mode = pair_mode
+        io.logdet = L.ptr(logdet)
+        L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
+        return y
+
+
+def weightnorm_fold(v, g):
+    """w = g * v / ||v|| over all dims but 0 (a12)."""
+    lib = L.require_gpu()
+    v = v.contiguous()
+    w = torch.empty_like(v)
+    rows = v.shape[0]
+    L.check(lib.vs_weightnorm_fold(L.ptr(v), L.ptr(g.contiguous()), L.ptr(w), rows, v.numel() // rows, L.stream_ptr()))
+    return w
