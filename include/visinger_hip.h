@@ -54,7 +54,12 @@ enum vs_conv_kind {
     VS_CONV1D_PAIRED = 2     /* Conv1d whose c_out = 2*H rows are consumed as (row c, row H+c) pairs by a fused
                                 epilogue: WaveNet gate (encoder.py:206-213) or affine coupling (flow.py:71-85) */
 };
-enum vs_in_act { VS_IN_NONE = 0, VS_IN_LRELU = 1 /* leaky_relu(x, 0.1) */, VS_IN_MASK = 2 /* x * mask[b,t] */ };
+enum vs_in_act {
+    VS_IN_NONE = 0,
+    VS_IN_LRELU = 1,      /* leaky_relu(x, 0.1)                 */
+    VS_IN_MASK = 2,       /* x * mask[b,t]                      */
+    VS_IN_LRELU_MASK = 3  /* leaky_relu(x, 0.1) * mask[b,t]     (decoder.py:93-95) */
+};
 enum vs_out_act { VS_OUT_NONE = 0, VS_OUT_TANH = 1, VS_OUT_RELU = 2 };
 enum vs_pair_mode { VS_PAIR_GATE = 0, VS_PAIR_COUPLING_FWD = 1, VS_PAIR_COUPLING_INV = 2 };
 enum vs_out_mode {
@@ -105,6 +110,26 @@ typedef struct vs_conv_io {
 VS_API int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream);
 /* length of the time axis produced for an input of length T */
 VS_API int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a6  windowed relative-position self-attention core: MultiHeadAttention.attention
+ *     (modules/rel_transformer.py:148-179 with the relative helpers 181-243).
+ *     q, k, v: [B, n_heads*k_channels, T] (the outputs of conv_q/k/v; they may live in one [B, 3C, T] buffer, hence
+ *     the shared batch stride).  rel_k / rel_v: [n_heads_rel, 2*window+1, k_channels] (emb_rel_k / emb_rel_v);
+ *     window_size < 0 disables the relative terms.  mask: [B, T] frame mask m, attention mask = m[i]*m[j]; masked
+ *     scores are SET to -1e4 (fully masked rows come out uniform, never NaN).  out: [B, n_heads*k_channels, T].
+ *     Streaming softmax: no [T, T] tensor is materialised (the reference's `self.attn` is not produced).        */
+VS_API int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                          const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B,
+                          int n_heads, int k_channels, int64_t T, int window_size, int n_heads_rel, void *stream);
+
+/* a7  channel LayerNorm with its neighbours fused (rel_transformer.py:24-42; call sites 297-299, 305-307, 314-316):
+ *     y = ((LayerNorm_C(a + r) * gamma + beta) + g) * mask      r, g, mask optional.
+ *     g is the conditioning added at the top of the NEXT encoder layer: [B, C, T] (g_time_stride = 1,
+ *     g_batch_stride = C*T) or [B, C, 1] broadcast over time (g_time_stride = 0, g_batch_stride = C).            */
+VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma, const float *beta, const float *g,
+                              int64_t g_batch_stride, int g_time_stride, const float *mask, float *y, int64_t B,
+                              int64_t C, int64_t T, float eps, void *stream);
 
 #ifdef __cplusplus
 }

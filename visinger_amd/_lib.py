@@ -13,7 +13,7 @@ VS_OK = 0
 # enum vs_conv_kind
 CONV1D, CONV_TRANSPOSE1D, CONV1D_PAIRED = 0, 1, 2
 # enum vs_in_act / vs_out_act / vs_pair_mode / vs_out_mode
-IN_NONE, IN_LRELU, IN_MASK = 0, 1, 2
+IN_NONE, IN_LRELU, IN_MASK, IN_LRELU_MASK = 0, 1, 2, 3
 OUT_NONE, OUT_TANH, OUT_RELU = 0, 1, 2
 PAIR_GATE, PAIR_COUPLING_FWD, PAIR_COUPLING_INV = 0, 1, 2
 MODE_LINEAR, MODE_COUPLING_MEAN_FWD, MODE_COUPLING_MEAN_INV = 0, 1, 2
@@ -65,6 +65,10 @@ def lib():
     L.vs_conv_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(ConvIO), ctypes.c_void_p]
     L.vs_conv_out_len.argtypes = [ctypes.c_void_p, ctypes.c_int64]
     L.vs_conv_out_len.restype = ctypes.c_int64
+    i64, ci, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+    L.vs_relattn_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, i64, ci, ci, i64, ci, ci, vp]
+    L.vs_layernorm_c_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, i64, ci, _f32p, _f32p, i64, i64, i64,
+                                     ctypes.c_float, vp]
     _lib = L
     return L
 

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         for (int i = 0; i < CIT; ++i) {
             const int n = n0 + p.lo + lane + 64 * i;
             const int nc = min(max(n, 0), p.Tin - 1);
-            if (in_act == VS_IN_MASK) mk[i] = maskb[nc];
+            if (in_act >= VS_IN_MASK) mk[i] = maskb[nc];
 #pragma unroll
             for (int j = 0; j < RPW; ++j) {
                 const int ci = min(chunk * CK + wave + NW * j, p.Cin - 1);
@@ -168,8 +168,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
             for (int j = 0; j < RPW; ++j) {
                 const bool ok = okn && (chunk * CK + wave + NW * j < p.Cin);
                 float v = ok ? st[j][i] : 0.f;
-                v = (in_act == VS_IN_LRELU) ? lrelu(v) : v;
-                v = (in_act == VS_IN_MASK) ? v * mk[i] : v;
+                v = (in_act == VS_IN_LRELU || in_act == VS_IN_LRELU_MASK) ? lrelu(v) : v;
+                v = (in_act >= VS_IN_MASK) ? v * mk[i] : v;
                 if (col < W) buf[(wave + NW * j) * W + col] = v;
             }
         }
@@ -636,7 +636,8 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     p.upK = h->k; p.uppad = h->pad; p.dmin = h->dmin;
     const int rows_out = (h->kind == VS_CONV1D_PAIRED) ? h->Hh : h->c_out;
     p.split_row = (io->split_row > 0 && io->split_row < rows_out && h->kind != VS_CONV1D_PAIRED) ? io->split_row : 0;
-    bool need_mask = (io->in_act == VS_IN_MASK);
+    bool need_mask = (io->in_act >= VS_IN_MASK);
+    VS_REQUIRE(io->in_act >= VS_IN_NONE && io->in_act <= VS_IN_LRELU_MASK, "vs_conv_forward: bad in_act");
     for (int s = 0; s < 2; ++s) {
         const vs_conv_out_t &o = io->out[s];
         OutSpec &d = p.out[s];

@@ -1,0 +1,345 @@
+// transformer_ops.hip -- the non-conv kernels of the windowed relative-position transformer on gfx950:
+//   vs_relattn_fwd       MultiHeadAttention.attention      (reference modules/rel_transformer.py:148-179 + 181-243)
+//   vs_layernorm_c_fwd   LayerNorm over channels (+ fused residual add / conditioning add / mask)
+//                                                         (rel_transformer.py:24-42, 305-307, 314-316, 297-299)
+//
+// Attention is a streaming-softmax ("flash") kernel on the exact-fp32 matrix instruction: the [T, T] score
+// tensor, its three padded/skewed copies (rel_transformer.py:214-243) and the stored `self.attn` never exist.
+// The relative-key bias and the relative-value term are non-zero only for |i - j| <= window, so they are computed
+// by index arithmetic: QR[i][r] = q_i . rel_k[r] (9 dots per query) is added on the diagonal tiles, and the 9
+// in-window scores of each query are kept aside so that sum_r p[i, i+r] * rel_v[r] is added once at the end.
+//
+// Orientation: the kernel computes S^T = K^T Q (keys on the MFMA rows, queries on the lanes), so a query's row
+// statistics are in-register reductions plus one cross-half exchange, and the probability tile is -- register for
+// register -- the B operand of the P.V product (k-index order chosen to match the accumulator layout): no LDS
+// round trip, no shuffles between the two GEMMs.
+#include "vs_internal.h"
+
+namespace vs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ATT_MAXREL = 16;   // 2*window+1 <= 16
+constexpr int ATT_QRS = 17;      // LDS stride of the per-query relative rows
+
+struct AttnParams {
+    const float *q, *k, *v;
+    long long bs;                 // batch stride of q/k/v (floats)
+    const float *rel_k, *rel_v;   // [nh_rel, 2ws+1, dk] or null
+    const float *mask;            // [B, T] or null
+    float *out;
+    long long out_bs;
+    int B, nh, dk, T, ws, nh_rel;
+    float scale;
+};
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// DT = number of 32-wide tiles of the head dimension (dk <= 32*DT)
+template <int DT>
+__global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int dk = p.dk, T = p.T;
+    const int dkp = (dk + 1) & ~1;
+    const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
+
+    float *Qs = smem;                              // [4][dkp][32]
+    float *QRs = Qs + 4 * dkp * 32;                // [4][32][ATT_QRS]   rel-key logits, later unused
+    float *Sws = QRs + 4 * 32 * ATT_QRS;           // [4][32][ATT_QRS]   in-window raw scores
+    float *Ks = Sws + 4 * 32 * ATT_QRS;            // [dkp][32]
+    float *Vs = Ks + dkp * 32;                     // [DT*32][33]
+    float *Ms = Vs + DT * 32 * 33;                 // [32] key mask of the tile
+    float *RVs = Ms + 32;                          // [ATT_MAXREL][dk] relative value embeddings
+
+    const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
+    const float *kb = p.k + (long long)b * p.bs + (long long)h * dk * T;
+    const float *vb = p.v + (long long)b * p.bs + (long long)h * dk * T;
+    const float *maskb = p.mask ? p.mask + (long long)b * T : nullptr;
+    const float *relk = nrel ? p.rel_k + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+    const float *relv = nrel ? p.rel_v + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+
+    // ---- stage this wave's query tile (pre-scaled by 1/sqrt(dk)) and the relative value table ----
+    float *Qw = Qs + wave * dkp * 32;
+    for (int e = lane; e < dkp * 32; e += 64) {
+        const int d = e >> 5, i = e & 31;
+        float v = 0.f;
+        if (d < dk && i0 + i < T) v = qb[(long long)d * T + i0 + i] * p.scale;
+        Qw[e] = v;
+    }
+    for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
+    float *QRw = QRs + wave * 32 * ATT_QRS;
+    float *Sww = Sws + wave * 32 * ATT_QRS;
+    for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
+    __syncthreads();
+    if (nrel) {
+        // QR[i][r] = (q_i * scale) . rel_k[r];  half 0 -> r in [0,8), half 1 -> r in [8,16)
+        float qr[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) qr[r] = 0.f;
+        for (int d = 0; d < dk; ++d) {
+            const float qv = Qw[d * 32 + l31];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = half * 8 + r;
+                const float kvv = (rr < nrel) ? relk[rr * dk + d] : 0.f;
+                qr[r] += qv * kvv;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) QRw[l31 * ATT_QRS + half * 8 + r] = qr[r];
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_half = 0.f;
+    const int qi = i0 + l31;                      // this lane's query
+    const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
+
+    const int ntiles = (T + 31) / 32;
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int j0 = jt * 32;
+        __syncthreads();                          // previous tile fully consumed
+        for (int e = tid; e < dkp * 32; e += 256) {
+            const int d = e >> 5, jj = e & 31;
+            const bool ok = (d < dk) && (j0 + jj < T);
+            Ks[e] = ok ? kb[(long long)d * T + j0 + jj] : 0.f;
+        }
+        for (int e = tid; e < DT * 32 * 32; e += 256) {
+            const int d = e >> 5, jj = e & 31;
+            const bool ok = (d < dk) && (j0 + jj < T);
+            Vs[d * 33 + jj] = ok ? vb[(long long)d * T + j0 + jj] : 0.f;
+        }
+        if (tid < 32) Ms[tid] = (maskb && j0 + tid < T) ? maskb[j0 + tid] : 1.f;
+        __syncthreads();
+
+        // ---- S^T tile: rows = keys, cols (lanes) = queries ----
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int kk = 0; kk < dkp / 2; ++kk) {
+            const float a = Ks[(2 * kk + half) * 32 + l31];
+            const float bq = Qw[(2 * kk + half) * 32 + l31];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, s, 0, 0, 0);
+        }
+        const bool near_diag = nrel && (j0 + 31 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = acc_row(r, half);
+            const int j = j0 + jj;
+            float sv = s[r];
+            if (near_diag) {
+                const int rel = j - qi;
+                if (rel >= -p.ws && rel <= p.ws) sv += QRw[l31 * ATT_QRS + rel + p.ws];
+            }
+            if (mi * Ms[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
+            if (j >= T) sv = -INFINITY;                  // beyond the sequence: not part of the softmax
+            if (near_diag) {
+                const int rel = j - qi;
+                if (rel >= -p.ws && rel <= p.ws && j < T) Sww[l31 * ATT_QRS + rel + p.ws] = sv;
+            }
+            s[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = expf(s[r] - m_new);     // exp(-inf) = 0 for excluded keys
+            s[r] = pv;
+            psum += pv;
+        }
+        l_half = l_half * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+        // ---- O^T += V P^T : k-step ks sums over key acc_row(ks, half), i.e. exactly the key held in s[ks] ----
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int jj = acc_row(ks, half);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const float a = Vs[(t * 32 + l31) * 33 + jj];
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[ks], o[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- finish: normalise, add the relative-value term, store ----
+    const float l_tot = l_half + __shfl_xor(l_half, 32);
+    const float inv = 1.0f / l_tot;
+    float pw[ATT_MAXREL];
+    __syncthreads();   // Sww written by both halves of this wave (same wave: program order suffices, keep simple)
+#pragma unroll
+    for (int r = 0; r < ATT_MAXREL; ++r) pw[r] = (r < nrel) ? expf(Sww[l31 * ATT_QRS + r] - m_run) * inv : 0.f;
+    float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = t * 32 + acc_row(r, half);
+            float val = o[t][r] * inv;
+            if (d < dk) {
+#pragma unroll
+                for (int rr = 0; rr < ATT_MAXREL; ++rr)
+                    if (rr < nrel) val += pw[rr] * RVs[rr * dk + d];
+                if (qi < T) ob[(long long)d * T + qi] = val;
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// y[b,c,t] = ((LN_c(a + r) * gamma + beta) + g[b,c,t*g_ts]) * mask[b,t]
+// block = G channel groups x 64 frames; each thread keeps its C/G channel values in registers
+struct LnParams {
+    const float *a, *r;       // r may be null
+    const float *gamma, *beta;
+    const float *g;           // optional post-add (conditioning of the NEXT layer), time stride g_ts (0 or 1)
+    long long g_bs;
+    int g_ts;
+    const float *mask;        // optional [B, T]
+    float *y;
+    int B, C, T;
+    float eps;
+};
+
+template <int G, int PT>
+__global__ void __launch_bounds__(64 * G) layernorm_c_kernel(const LnParams p) {
+    __shared__ float red[G][64];
+    const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + tl;
+    const int tc = min(t, p.T - 1);
+    const float *ab = p.a + (long long)b * p.C * p.T + tc;
+    const float *rb = p.r ? p.r + (long long)b * p.C * p.T + tc : nullptr;
+    float v[PT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int c = grp + G * i;
+        const int cc = min(c, p.C - 1);
+        float x = ab[(long long)cc * p.T];
+        if (rb) x += rb[(long long)cc * p.T];
+        v[i] = (c < p.C) ? x : 0.f;
+        sum += v[i];
+    }
+    red[grp][tl] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) tot += red[gI][tl];
+    const float mean = tot / (float)p.C;
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int c = grp + G * i;
+        const float d = (c < p.C) ? v[i] - mean : 0.f;
+        sq += d * d;
+    }
+    red[grp][tl] = sq;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) var += red[gI][tl];
+    var /= (float)p.C;
+    const float rs = rsqrtf(var + p.eps);
+    const float mval = p.mask ? p.mask[(long long)b * p.T + tc] : 1.f;
+    if (t < p.T) {
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            const int c = grp + G * i;
+            if (c < p.C) {
+                float o = (v[i] - mean) * rs * p.gamma[c] + p.beta[c];
+                if (p.g) o += p.g[(long long)b * p.g_bs + (long long)c * (p.g_ts ? p.T : 1) + (p.g_ts ? t : 0)];
+                p.y[((long long)b * p.C + c) * p.T + t] = o * mval;
+            }
+        }
+    }
+}
+
+}  // namespace vs
+
+using namespace vs;
+
+template <int DT>
+static int launch_attn(const AttnParams &p, hipStream_t s) {
+    const int dkp = (p.dk + 1) & ~1;
+    const size_t lds = sizeof(float) * ((size_t)4 * dkp * 32 + 2 * 4 * 32 * ATT_QRS + (size_t)dkp * 32 + (size_t)DT * 32 * 33 +
+                                        32 + (size_t)ATT_MAXREL * p.dk);
+    auto kern = relattn_kernel<DT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) { set_error("vs_relattn_fwd: head dim %d needs %zu B of LDS", p.dk, lds); return VS_EUNSUPPORTED; }
+    dim3 grid((unsigned)ceil_div(p.T, 128), (unsigned)p.nh, (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+extern "C" {
+
+int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                   const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                   int k_channels, int64_t T, int window_size, int n_heads_rel, void *stream) {
+    VS_REQUIRE(q && k && v && out, "vs_relattn_fwd: NULL tensor");
+    VS_REQUIRE(B > 0 && B <= 65535 && n_heads > 0 && k_channels > 0 && T > 0, "vs_relattn_fwd: bad dims");
+    VS_REQUIRE(window_size < 0 || (rel_k && rel_v), "vs_relattn_fwd: window given but relative embeddings are NULL");
+    VS_REQUIRE(window_size < 0 || 2 * window_size + 1 <= ATT_MAXREL, "vs_relattn_fwd: window_size %d too large", window_size);
+    VS_REQUIRE(n_heads_rel == 1 || n_heads_rel == n_heads, "vs_relattn_fwd: bad n_heads_rel");
+    AttnParams p;
+    p.q = q; p.k = k; p.v = v;
+    p.bs = qkv_batch_stride ? qkv_batch_stride : (long long)n_heads * k_channels * T;
+    p.rel_k = window_size >= 0 ? rel_k : nullptr;
+    p.rel_v = window_size >= 0 ? rel_v : nullptr;
+    p.mask = mask; p.out = out;
+    p.out_bs = out_batch_stride ? out_batch_stride : (long long)n_heads * k_channels * T;
+    p.B = (int)B; p.nh = n_heads; p.dk = k_channels; p.T = (int)T; p.ws = window_size; p.nh_rel = n_heads_rel;
+    p.scale = 1.0f / sqrtf((float)k_channels);
+    hipStream_t s = as_stream(stream);
+    const int DT = (int)ceil_div(k_channels, 32);
+    switch (DT) {
+        case 1: return launch_attn<1>(p, s);
+        case 2: return launch_attn<2>(p, s);
+        case 3: return launch_attn<3>(p, s);
+        case 4: return launch_attn<4>(p, s);
+        default: set_error("vs_relattn_fwd: k_channels %d > 128 not supported yet", k_channels); return VS_EUNSUPPORTED;
+    }
+}
+
+int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma, const float *beta, const float *g,
+                       int64_t g_batch_stride, int g_time_stride, const float *mask, float *y, int64_t B, int64_t C,
+                       int64_t T, float eps, void *stream) {
+    VS_REQUIRE(a && gamma && beta && y && B > 0 && B <= 65535 && C > 0 && T > 0, "vs_layernorm_c_fwd: bad arguments");
+    LnParams p;
+    p.a = a; p.r = r; p.gamma = gamma; p.beta = beta; p.g = g; p.g_bs = g_batch_stride; p.g_ts = g_time_stride;
+    p.mask = mask; p.y = y; p.B = (int)B; p.C = (int)C; p.T = (int)T; p.eps = eps;
+    hipStream_t s = as_stream(stream);
+    dim3 grid((unsigned)ceil_div(T, 64), (unsigned)B);
+    if (C <= 4 * 16) hipLaunchKernelGGL((layernorm_c_kernel<4, 16>), grid, dim3(256), 0, s, p);
+    else if (C <= 4 * 64) hipLaunchKernelGGL((layernorm_c_kernel<4, 64>), grid, dim3(256), 0, s, p);
+    else if (C <= 8 * 64) hipLaunchKernelGGL((layernorm_c_kernel<8, 64>), grid, dim3(512), 0, s, p);
+    else if (C <= 16 * 64) hipLaunchKernelGGL((layernorm_c_kernel<16, 64>), grid, dim3(1024), 0, s, p);
+    else { set_error("vs_layernorm_c_fwd: C=%lld > 1024 unsupported", (long long)C); return VS_EUNSUPPORTED; }
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+}  // extern "C"

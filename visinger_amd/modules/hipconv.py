@@ -1,0 +1,77 @@
+"""nn.Conv1d / nn.ConvTranspose1d whose forward runs on the HIP conv engine (C ABI vs_conv_*).
+
+They ARE torch.nn.Conv1d / ConvTranspose1d subclasses, so construction, default initialisation,
+``torch.nn.utils.weight_norm`` (old-style ``weight_g`` / ``weight_v`` parameters), ``remove_weight_norm`` and the
+``state_dict`` keys are exactly the reference's; only the arithmetic moves to gfx950.  Parent modules call
+``run(...)`` to fuse their elementwise neighbours (activation, mask, residual, gate, coupling) into the conv.
+
+Forward-only this round: the HIP kernels have no backward yet, so calling them in training mode with autograd
+enabled raises instead of silently returning tensors that cannot back-propagate.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..ops import ConvOp
+
+
+def _forward_only_guard(module):
+    if torch.is_grad_enabled() and module.training:
+        raise NotImplementedError(
+            "visinger_amd HIP modules are forward-only in this release (no backward kernels yet): call .eval() "
+            "or wrap the call in torch.no_grad().")
+
+
+class _HipConvMixin:
+    _kind = L.CONV1D
+
+    def _weights(self):
+        if hasattr(self, "weight_g"):           # torch.nn.utils.weight_norm applied
+            return self.weight_v, self.weight_g
+        return self.weight, None
+
+    def _op(self, kind=None, flags=0):
+        """ConvOp for (kind, flags); created lazily so that modules can be built/loaded without a GPU."""
+        kind = self._kind if kind is None else kind
+        ops = self.__dict__.setdefault("_hip_ops", {})
+        key = (kind, flags)
+        if key not in ops:
+            if self._kind == L.CONV_TRANSPOSE1D:
+                ops[key] = ConvOp(L.CONV_TRANSPOSE1D, self.in_channels, self.out_channels, self.kernel_size[0],
+                                  self.stride[0], self.padding[0], flags)
+            else:
+                assert self.stride[0] == 1 and self.groups == 1, "HIP conv engine: stride-1 ungrouped convs only"
+                ops[key] = ConvOp(kind, self.in_channels, self.out_channels, self.kernel_size[0],
+                                  self.dilation[0], self.padding[0], flags)
+        op = ops[key]
+        w, g = self._weights()
+        op.set_weights(w, g, self.bias)
+        return op
+
+    def run(self, x, *, kind=None, flags=0, **kw):
+        """Launch the conv with fused options (see visinger_amd.ops.ConvOp.forward)."""
+        _forward_only_guard(self)
+        return self._op(kind, flags).forward(x, **kw)
+
+    def forward(self, x):
+        return self.run(x.contiguous().float())
+
+    def __getstate__(self):                      # handles are process-local
+        st = self.__dict__.copy()
+        st.pop("_hip_ops", None)
+        return st
+
+
+class HipConv1d(_HipConvMixin, nn.Conv1d):
+    _kind = L.CONV1D
+
+
+class HipConvTranspose1d(_HipConvMixin, nn.ConvTranspose1d):
+    _kind = L.CONV_TRANSPOSE1D
+
+
+def mask2d(x_mask, B, T):
+    """[B,1,T] (or [B,T]) nonpadding mask -> contiguous fp32 [B,T]"""
+    if x_mask is None:
+        return None
+    return x_mask.reshape(B, T).to(torch.float32).contiguous()

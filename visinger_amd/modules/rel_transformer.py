@@ -1,0 +1,230 @@
+"""MI355X-native mirror of the reference's modules/rel_transformer.py:24-345 -- LayerNorm,
+SinusoidalPositionalEmbedding, MultiHeadAttention, RelativeEncoder, FFN (same names, signatures, parameters).
+(ConvReluNorm / RelativeTransformerEncoder/Decoder at rel_transformer.py:348-453 are not used by VISinger.)
+
+Per encoder layer: q/k/v 1x1 convs write one [B, 3C, T] buffer (mask applied while staging x) -> streaming-softmax
+attention with the banded relative terms (vs_relattn_fwd) -> conv_o -> LayerNorm kernel with the residual add
+fused -> FFN conv k (mask in, ReLU out) -> 1x1 conv (mask in) -> LayerNorm kernel with the residual add and the
+NEXT layer's `(x + g) * mask` fused.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from ..ops import layernorm_c, rel_attention, _off
+from .hipconv import HipConv1d, mask2d, _forward_only_guard
+
+
+def convert_pad_shape(pad_shape):
+    l = pad_shape[::-1]
+    return [item for sublist in l for item in sublist]
+
+
+def sequence_mask(length, max_length=None):
+    if max_length is None:
+        max_length = length.max()
+    x = torch.arange(max_length, dtype=length.dtype, device=length.device)
+    return x.unsqueeze(0) < length.unsqueeze(1)
+
+
+class LayerNorm(nn.Module):
+    """rel_transformer.py:24-42: normalises dim 1 of [B, C, T]; biased variance, eps inside rsqrt."""
+
+    def __init__(self, channels, eps=1e-4):
+        super().__init__()
+        self.channels = channels
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x):
+        _forward_only_guard(self)
+        shp = x.shape
+        x3 = x.contiguous().float().reshape(shp[0], shp[1], -1)
+        return layernorm_c(x3, self.gamma, self.beta, eps=self.eps).reshape(shp)
+
+
+class SinusoidalPositionalEmbedding(nn.Module):
+    """rel_transformer.py:45-100.  Positions are integer bookkeeping (cumsum of `!= padding_idx`), bit-exact; the
+    table is built on the CPU with the reference's formula and moved to the input's device."""
+
+    def __init__(self, embedding_dim, padding_idx, init_size=1024):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.padding_idx = padding_idx
+        self.weights = SinusoidalPositionalEmbedding.get_embedding(init_size, embedding_dim, padding_idx)
+        self.register_buffer('_float_tensor', torch.FloatTensor(1))
+
+    @staticmethod
+    def get_embedding(num_embeddings, embedding_dim, padding_idx=None):
+        half_dim = embedding_dim // 2
+        emb = math.log(10000) / (half_dim - 1)
+        emb = torch.exp(torch.arange(half_dim, dtype=torch.float) * -emb)
+        emb = torch.arange(num_embeddings, dtype=torch.float).unsqueeze(1) * emb.unsqueeze(0)
+        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1).view(num_embeddings, -1)
+        if embedding_dim % 2 == 1:
+            emb = torch.cat([emb, torch.zeros(num_embeddings, 1)], dim=1)
+        if padding_idx is not None:
+            emb[padding_idx, :] = 0
+        return emb
+
+    def make_positions(tensor, padding_idx):
+        mask = tensor.ne(padding_idx).int()
+        return (torch.cumsum(mask, dim=1).type_as(mask) * mask).long() + padding_idx
+
+    def forward(self, bsz, seq_len, input):
+        max_pos = self.padding_idx + 1 + seq_len
+        if self.weights is None or max_pos > self.weights.size(0):
+            self.weights = SinusoidalPositionalEmbedding.get_embedding(max_pos, self.embedding_dim, self.padding_idx)
+        self.weights = self.weights.to(self._float_tensor)
+        positions = SinusoidalPositionalEmbedding.make_positions(input, self.padding_idx)
+        return self.weights.index_select(0, positions.view(-1)).view(bsz, seq_len, -1).detach()
+
+
+class MultiHeadAttention(nn.Module):
+    """rel_transformer.py:103-254"""
+
+    def __init__(self, channels, out_channels, n_heads, window_size=None, heads_share=True, p_dropout=0.,
+                 block_length=None, proximal_bias=False, proximal_init=False):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.channels = channels
+        self.out_channels = out_channels
+        self.n_heads = n_heads
+        self.window_size = window_size
+        self.heads_share = heads_share
+        self.block_length = block_length
+        self.proximal_bias = proximal_bias
+        self.p_dropout = p_dropout
+        self.attn = None     # the [B, h, T, T] probabilities are never materialised by the streaming kernel
+
+        self.k_channels = channels // n_heads
+        self.conv_q = HipConv1d(channels, channels, 1)
+        self.conv_k = HipConv1d(channels, channels, 1)
+        self.conv_v = HipConv1d(channels, channels, 1)
+        if window_size is not None:
+            n_heads_rel = 1 if heads_share else n_heads
+            rel_stddev = self.k_channels ** -0.5
+            self.emb_rel_k = nn.Parameter(torch.randn(n_heads_rel, window_size * 2 + 1, self.k_channels) * rel_stddev)
+            self.emb_rel_v = nn.Parameter(torch.randn(n_heads_rel, window_size * 2 + 1, self.k_channels) * rel_stddev)
+        self.conv_o = HipConv1d(channels, out_channels, 1)
+        self.drop = nn.Dropout(p_dropout)
+
+        nn.init.xavier_uniform_(self.conv_q.weight)
+        nn.init.xavier_uniform_(self.conv_k.weight)
+        if proximal_init:
+            self.conv_k.weight.data.copy_(self.conv_q.weight.data)
+            self.conv_k.bias.data.copy_(self.conv_q.bias.data)
+        nn.init.xavier_uniform_(self.conv_v.weight)
+
+    def forward(self, x, c, attn_mask=None, frame_mask=None, in_mask=False):
+        """x, c: [B, C, T].  attn_mask: the reference's [B, 1, T, T] mask, which RelativeEncoder always builds as
+        m[:, :, :, None] * m[:, :, None, :] from the frame mask m; the streaming kernel takes m itself (`frame_mask`
+        [B, T]); a 4-D attn_mask is reduced back to m through its diagonal.  in_mask: multiply x by m while
+        staging (fuses RelativeEncoder's `x = x * x_mask`)."""
+        _forward_only_guard(self)
+        if self.proximal_bias or self.block_length is not None:
+            raise NotImplementedError("proximal_bias / block_length are not used by VISinger and not implemented")
+        if self.training and self.p_dropout > 0:
+            raise NotImplementedError("attention dropout is not implemented (eval only)")
+        assert x.shape == c.shape, "Relative attention is only available for self-attention."
+        B, C, T = x.shape
+        if frame_mask is None and attn_mask is not None:
+            frame_mask = torch.diagonal(attn_mask.reshape(B, T, T), dim1=1, dim2=2)
+        m2 = None if frame_mask is None else frame_mask.reshape(B, T).float().contiguous()
+        x = x.contiguous().float()
+        c = x if c is x else c.contiguous().float()
+        qkv = torch.empty((B, 3 * C, T), device=x.device, dtype=torch.float32)
+        ia = L.IN_MASK if in_mask else L.IN_NONE
+        for j, (conv, src) in enumerate(((self.conv_q, x), (self.conv_k, c), (self.conv_v, c))):
+            conv.run(src, in_act=ia, mask=m2, y_ptr=_off(qkv, j * C * T), y_bs=3 * C * T)
+        rel_k = self.emb_rel_k if self.window_size is not None else None
+        rel_v = self.emb_rel_v if self.window_size is not None else None
+        att = rel_attention(qkv, self.n_heads, rel_k, rel_v, m2, self.window_size)
+        return self.conv_o.run(att)
+
+
+class RelativeEncoder(nn.Module):
+    """rel_transformer.py:257-320"""
+
+    def __init__(self, hidden_channels, filter_channels, n_heads, n_layers, kernel_size=1, p_dropout=0.,
+                 window_size=4, block_length=None, pre_ln=False, gin_channels=None, **kwargs):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.filter_channels = filter_channels
+        self.n_heads = n_heads
+        self.n_layers = n_layers
+        self.kernel_size = kernel_size
+        self.p_dropout = p_dropout
+        self.window_size = window_size
+        self.block_length = block_length
+        self.pre_ln = pre_ln
+
+        self.drop = nn.Dropout(p_dropout)
+        self.attn_layers = nn.ModuleList()
+        self.norm_layers_1 = nn.ModuleList()
+        self.ffn_layers = nn.ModuleList()
+        self.norm_layers_2 = nn.ModuleList()
+        for i in range(self.n_layers):
+            self.attn_layers.append(
+                MultiHeadAttention(hidden_channels, hidden_channels, n_heads, window_size=window_size,
+                                   p_dropout=p_dropout, block_length=block_length))
+            self.norm_layers_1.append(LayerNorm(hidden_channels))
+            self.ffn_layers.append(
+                FFN(hidden_channels, hidden_channels, filter_channels, kernel_size, p_dropout=p_dropout))
+            self.norm_layers_2.append(LayerNorm(hidden_channels))
+        if pre_ln:
+            self.last_ln = LayerNorm(hidden_channels)
+        if gin_channels is not None:
+            self.pre_net = HipConv1d(gin_channels, hidden_channels, 1)
+
+    def forward(self, x, x_mask, g=None):
+        _forward_only_guard(self)
+        if self.pre_ln:
+            raise NotImplementedError("pre_ln=True is never used by VISinger (rel_transformer.py:281-282) and not implemented")
+        if self.training and self.p_dropout > 0:
+            raise NotImplementedError("dropout is not implemented in the fused encoder (eval only)")
+        B, C, T = x.shape
+        m2 = mask2d(x_mask, B, T)
+        x = x.contiguous().float()
+        if g is not None:
+            g = self.pre_net.run(g.contiguous().float())          # [B, C, T] or [B, C, 1]
+            x = x + g                                             # first layer's conditioning add (:297-298)
+        x = x * m2[:, None, :]                                    # (:299)
+        for i in range(self.n_layers):
+            # attention block, post-LN: x = LN1(x + attn(x))
+            y = self.attn_layers[i](x, x, frame_mask=m2)
+            ln1 = self.norm_layers_1[i]
+            x = layernorm_c(y, ln1.gamma, ln1.beta, r=x, eps=ln1.eps)
+            # FFN block, post-LN: x = LN2(x + ffn(x)); then the next layer's (x + g) * mask (or the final mask)
+            y = self.ffn_layers[i](x, m2)
+            ln2 = self.norm_layers_2[i]
+            last = (i == self.n_layers - 1)
+            x = layernorm_c(y, ln2.gamma, ln2.beta, r=x, g=None if last else g, mask=m2, eps=ln2.eps)
+        return x
+
+
+class FFN(nn.Module):
+    """rel_transformer.py:323-345"""
+
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0.0, activation=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.filter_channels = filter_channels
+        self.kernel_size = kernel_size
+        self.activation = activation
+        self.conv_1 = HipConv1d(in_channels, filter_channels, kernel_size, padding=kernel_size // 2)
+        self.conv_2 = HipConv1d(filter_channels, out_channels, 1)
+        self.dropout = nn.Dropout(p_dropout)
+
+    def forward(self, x, x_mask):
+        _forward_only_guard(self)
+        if self.activation == "gelu":
+            raise NotImplementedError("FFN(activation='gelu') is never built by VISinger (rel_transformer.py:281-282)")
+        B, _, T = x.shape
+        m2 = mask2d(x_mask, B, T)
+        h = self.conv_1.run(x.contiguous().float(), in_act=L.IN_MASK, mask=m2, out_act=L.OUT_RELU)
+        return self.conv_2.run(h, in_act=L.IN_MASK, mask=m2)

@@ -1,0 +1,153 @@
+"""MI355X-native mirror of the reference's modules/visinger/decoder.py:13-137 -- the HiFi-GAN generator with
+multi-receptive-field resblocks (Generator, ResBlock1, ResBlock2).  This is where 90-97 % of the synthesis FLOPs
+are.
+
+Fusion plan (no elementwise kernel touches HBM):
+  * every leaky_relu is applied while the consuming conv stages its input into LDS;
+  * `x = xt + x` is the residual input of the second conv of each pair;
+  * the MRF sum `xs += resblock(x)` and the final `/ num_kernels` ride on the epilogue of the LAST conv of each
+    resblock (accumulate input + scale);
+  * `conv_pre(x) + cond(g)` : cond(g) is a per-item bias of conv_pre;  leaky_relu + conv_post + tanh is one launch;
+  * ConvTranspose1d runs as a polyphase conv (no zero-stuffing, no multiplies by structural zeros).
+"""
+import torch
+import torch.nn as nn
+from torch.nn.utils import weight_norm, remove_weight_norm
+
+from ... import _lib as L
+from ..commons.utils import init_weights, get_padding
+from ..hipconv import HipConv1d, HipConvTranspose1d, mask2d, _forward_only_guard
+
+LRELU_SLOPE = 0.1
+
+
+class Generator(nn.Module):
+    """decoder.py:13-65"""
+
+    def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
+                 upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
+        super(Generator, self).__init__()
+        self.num_kernels = len(resblock_kernel_sizes)
+        self.num_upsamples = len(upsample_rates)
+        self.conv_pre = HipConv1d(initial_channel, upsample_initial_channel, 7, 1, padding=3)
+        resblock = ResBlock1 if resblock == '1' else ResBlock2
+
+        self.ups = nn.ModuleList()
+        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+            self.ups.append(weight_norm(
+                HipConvTranspose1d(upsample_initial_channel // (2 ** i), upsample_initial_channel // (2 ** (i + 1)),
+                                   k, u, padding=(k - u) // 2)))
+
+        self.resblocks = nn.ModuleList()
+        for i in range(len(self.ups)):
+            ch = upsample_initial_channel // (2 ** (i + 1))
+            for _, (k, d) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
+                self.resblocks.append(resblock(ch, k, d))
+
+        self.conv_post = HipConv1d(ch, 1, 7, 1, padding=3, bias=False)
+        self.ups.apply(init_weights)
+
+        if gin_channels != 0:
+            self.cond = HipConv1d(gin_channels, upsample_initial_channel, 1)
+
+    def forward(self, x, g=None):
+        _forward_only_guard(self)
+        x = x.contiguous().float()
+        cb = None
+        if g is not None:
+            cb = self.cond.run(g.contiguous().float())          # [B, C0, 1] -> per-item bias of conv_pre
+        x = self.conv_pre.run(x, bias_b=cb)
+        nk = self.num_kernels
+        for i in range(self.num_upsamples):
+            x = self.ups[i].run(x, in_act=L.IN_LRELU)
+            xs = torch.empty_like(x)
+            for j in range(nk):
+                self.resblocks[i * nk + j]._run_fused(x, xs, first=(j == 0), scale=(1.0 / nk if j == nk - 1 else 1.0))
+            x = xs
+        return self.conv_post.run(x, in_act=L.IN_LRELU, out_act=L.OUT_TANH)
+
+    def remove_weight_norm(self):
+        for l in self.ups:
+            remove_weight_norm(l)
+        for l in self.resblocks:
+            l.remove_weight_norm()
+
+
+class ResBlock1(torch.nn.Module):
+    """decoder.py:68-110"""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super(ResBlock1, self).__init__()
+        self.convs1 = nn.ModuleList([
+            weight_norm(HipConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)))
+            for d in dilation])
+        self.convs1.apply(init_weights)
+        self.convs2 = nn.ModuleList([
+            weight_norm(HipConv1d(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1)))
+            for _ in dilation])
+        self.convs2.apply(init_weights)
+
+    def _run_fused(self, x, out, first=True, scale=1.0, mask=None):
+        """out = ((out if not first else 0) + resblock(x)) * scale   [* mask];  x is left untouched."""
+        n = len(self.convs1)
+        act = L.IN_LRELU if mask is None else L.IN_LRELU_MASK
+        cur = x
+        tmp = torch.empty_like(x)
+        pp = [torch.empty_like(x) if n > 1 else None, torch.empty_like(x) if n > 2 else None]
+        for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            c1.run(cur, in_act=act, mask=mask, y=tmp)
+            if i < n - 1:
+                nxt = pp[i % 2]
+                c2.run(tmp, in_act=act, mask=mask, res=cur, y=nxt)
+                cur = nxt
+            else:
+                c2.run(tmp, in_act=act, mask=mask, res=cur, acc=None if first else out, y=out, scale=scale,
+                       out_mask=mask is not None)
+        return out
+
+    def forward(self, x, x_mask=None):
+        _forward_only_guard(self)
+        x = x.contiguous().float()
+        B, _, T = x.shape
+        return self._run_fused(x, torch.empty_like(x), mask=mask2d(x_mask, B, T))
+
+    def remove_weight_norm(self):
+        for l in self.convs1:
+            remove_weight_norm(l)
+        for l in self.convs2:
+            remove_weight_norm(l)
+
+
+class ResBlock2(nn.Module):
+    """decoder.py:113-137"""
+
+    def __init__(self, channels, kernel_size=3, dilation=(1, 3)):
+        super(ResBlock2, self).__init__()
+        self.convs = nn.ModuleList([
+            weight_norm(HipConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)))
+            for d in dilation])
+        self.convs.apply(init_weights)
+
+    def _run_fused(self, x, out, first=True, scale=1.0, mask=None):
+        n = len(self.convs)
+        act = L.IN_LRELU if mask is None else L.IN_LRELU_MASK
+        cur = x
+        for i, c in enumerate(self.convs):
+            if i < n - 1:
+                nxt = torch.empty_like(x)
+                c.run(cur, in_act=act, mask=mask, res=cur, y=nxt)
+                cur = nxt
+            else:
+                c.run(cur, in_act=act, mask=mask, res=cur, acc=None if first else out, y=out, scale=scale,
+                      out_mask=mask is not None)
+        return out
+
+    def forward(self, x, x_mask=None):
+        _forward_only_guard(self)
+        x = x.contiguous().float()
+        B, _, T = x.shape
+        return self._run_fused(x, torch.empty_like(x), mask=mask2d(x_mask, B, T))
+
+    def remove_weight_norm(self):
+        for l in self.convs:
+            remove_weight_norm(l)

@@ -100,3 +100,34 @@ def weightnorm_fold(v, g):
     rows = v.shape[0]
     L.check(lib.vs_weightnorm_fold(L.ptr(v), L.ptr(g.contiguous()), L.ptr(w), rows, v.numel() // rows, L.stream_ptr()))
     return w
+
+
+def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=None, out=None):
+    """a6: attention core on a fused [B, 3C, T] q|k|v buffer -> [B, C, T]."""
+    lib = L.require_gpu()
+    B, C3, T = qkv.shape
+    C = C3 // 3
+    if out is None:
+        out = torch.empty((B, C, T), device=qkv.device, dtype=torch.float32)
+    ws = -1 if window_size is None else int(window_size)
+    L.check(lib.vs_relattn_fwd(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
+                               L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
+                               L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
+                               C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
+                               L.stream_ptr()))
+    return out
+
+
+def layernorm_c(a, gamma, beta, r=None, g=None, mask=None, eps=1e-4, out=None):
+    """a7: y = ((LN_C(a + r) * gamma + beta) + g) * mask over [B, C, T]."""
+    lib = L.require_gpu()
+    B, C, T = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    g_bs, g_ts = 0, 0
+    if g is not None:
+        g_ts = 1 if g.shape[-1] == T else 0
+        g_bs = C * (T if g_ts else 1)
+    L.check(lib.vs_layernorm_c_fwd(L.ptr(a), L.ptr(r), L.ptr(gamma.detach().contiguous()), L.ptr(beta.detach().contiguous()),
+                                   L.ptr(g), g_bs, g_ts, L.ptr(mask), L.ptr(out), B, C, T, eps, L.stream_ptr()))
+    return out
