@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- VISinger synthesis throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the synthesis hot path (VISinger.forward(infer=True) body: text encoder -> pitch predictor
+-> frame-prior transformer -> reparameterised sample -> flow inverse -> HiFi-GAN generator) over one batch of
+B=32 synthetic utterances of T_mel=1024 frames, hop 256 (22.05 kHz): 8 388 608 audio samples per step per GPU.
+Inputs (tokens, mel2ph, noise) are resident in HBM before the timed region; weights are random-init of the
+reference architecture (no checkpoints offline).  Multi-GPU = one process per GPU, utterances sharded by the
+reference's strided rule (batch[rank::world], tasks/base.py:130-133), no data-path collective -> weak scaling.
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (the fp32-MFMA
+implicit-GEMM conv instance with the largest share of the step), from HIP events recorded around each of its
+launches inside the timed steps; `cpu_baseline` is the CPU oracle ("port") timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HOP = 256
+SR = 22050
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+
+
+def synthetic_batch(B, T, Tph, ph_dict, seed, device, ragged=False):
+    """SURVEY.md 8d synthetic inputs: mel2ph = repeat_interleave(arange(1, Tph+1), T/Tph); tokens uniform."""
+    g = torch.Generator().manual_seed(seed)
+    text = torch.randint(4, ph_dict, (B, Tph), generator=g)
+    pitch = torch.randint(1, 117, (B, Tph), generator=g)
+    dur = torch.randint(4, 131, (B, Tph), generator=g)
+    mel2ph = torch.repeat_interleave(torch.arange(1, Tph + 1), T // Tph)[None].repeat(B, 1)
+    if ragged:
+        lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+        mel2ph = mel2ph * (torch.arange(T)[None] < lens[:, None])
+    noise = torch.randn(B, 192, T, generator=g)
+    spk = torch.zeros(B, dtype=torch.long)
+    return [t.to(device) for t in (text, pitch, dur, mel2ph, spk, noise)]
+
+
+def build_model(seed=1234):
+    from visinger_amd.models.visinger import VISinger, hop256_hparams
+    torch.manual_seed(seed)
+    hp = hop256_hparams()
+    model = VISinger(64, 117, 131, hp)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():    # non-trivial flow (post convs are zero-initialised in the reference)
+        for f in range(4):
+            post = model.flow.flows[2 * f].post
+            post.weight.copy_(0.05 * torch.randn(post.weight.shape, generator=g))
+            post.bias.copy_(0.05 * torch.randn(post.bias.shape, generator=g))
+    return model.eval(), hp
+
+
+def cpu_baseline(model, hp, budget_s=15.0):
+    """The CPU oracle (fp32 'port' of the reference arithmetic, oracle/) timed on a bounded sample of the SAME
+    workload (same weights, same synthetic input recipe): B=1, T_mel sized from a T_mel=32 probe to ~budget_s."""
+    from oracle import visinger_oracle as orc
+    orc.build()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    hpo = dict(hp, use_pitch_embed=False)   # the runnable reference configuration
+    cores = os.cpu_count() or 1
+
+    def run(T):
+        text, pitch, dur, mel2ph, spk, noise = [t.numpy() for t in synthetic_batch(1, T, max(1, T // 8), 64, 1234, "cpu")]
+        t0 = time.perf_counter()
+        wav = orc.visinger_infer(sd, hpo, text, pitch, dur, mel2ph, spk, noise, dtype=np.float32)
+        return wav.size, time.perf_counter() - t0
+
+    T = 32
+    n, dt = run(T)
+    T2 = int(min(512, 32 * max(1, 2 ** int(np.log2(max(1.0, budget_s / max(dt, 1e-3)))))))
+    if T2 > T:
+        T = T2
+        n, dt = run(T)
+    return {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ fp32 C+numpy port (OpenMP, {cores} threads), B=1 T_mel={T} hop={HOP}: {n} samples in "
+                      f"{dt:.2f}s; text-encoder + frame-prior + flow-inverse + generator"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="T_mel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    from visinger_amd.ops import PROFILER
+    model, hp = build_model()
+    model = model.to(dev)
+    B, T = args.batch, args.frames
+    # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
+    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu")
+    text, pitch, dur, mel2ph, spk, noise = [t[rank::world].contiguous().to(dev) for t in gb]
+
+    def step():
+        with torch.no_grad():
+            return model(text, pitch, dur, mel2ph, spk_id=spk, infer=True, noise=noise)["wav_out"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wav = step()
+    barrier()
+    PROFILER.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    PROFILER.stop()
+    assert wav.shape == (B, T * HOP) and bool(torch.isfinite(wav).all())
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    samples = B * world * T * HOP * args.steps
+
+    if rank == 0:
+        prof = PROFILER.summary()
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["ms"] for v in prof.values())
+        out = {
+            "metric": "audio samples/sec (22.05 kHz) synthesis, B=32 T_mel=1024",
+            "value": samples / dt,
+            "unit": "audio samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"VISinger synthesis (text-enc + pitch-pred + frame-prior + flow-inverse + HiFi-GAN), "
+                                   f"B={B}/GPU T_mel={T} hop={HOP} fp32, random-init weights",
+                       "per_gpu_batch": B, "global_batch": B * world, "t_mel": T, "hop": HOP,
+                       "parallelism": f"dp{world} (utterance shard, no collective)",
+                       "realtime_factor": samples / dt / SR},
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": d["launches"] / args.steps,
+                         "avg_launch_ms": d["ms"] / d["launches"],
+                         "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                         "share_of_step": d["ms"] / (dt * 1e3),
+                         "all_conv_instances": {k: {"ms_per_step": v["ms"] / args.steps,
+                                                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+                                                for k, v in prof.items()},
+                         "conv_engine_share_of_step": conv_ms / (dt * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, hp)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

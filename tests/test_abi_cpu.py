@@ -1,0 +1,130 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares
+(no compute without a GPU), the product path fails loudly without a GPU, and the nn.Module mirrors expose exactly
+the reference's parameter names/shapes (manifest generated from the reference by tests/golden/make_golden.py)."""
+import ctypes
+import inspect
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def declared_symbols():
+    syms = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", fn)).read()
+            syms |= set(re.findall(r"VS_API\s+[\w\s\*]+?\b(vs_\w+)\s*\(", txt))
+    return syms
+
+
+def test_library_exports_every_declared_symbol():
+    from visinger_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    missing = [s for s in sorted(syms) if not hasattr(lib, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    assert _lib.lib().vs_abi_version() >= 1
+
+
+def test_arguments_are_validated_without_a_gpu():
+    from visinger_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.vs_conv_create(ctypes.byref(h), 0, 16, 16, 33, 5, 80, 0) == 3          # VS_EUNSUPPORTED (span)
+    assert b"span" in L.vs_last_error()
+    assert L.vs_conv_create(ctypes.byref(h), 7, 16, 16, 3, 1, 1, 0) == 1            # VS_EINVAL (kind)
+    assert L.vs_conv_create(ctypes.byref(h), 2, 16, 15, 3, 1, 1, 0) == 1            # PAIRED needs even c_out
+    assert L.vs_conv_create(ctypes.byref(h), 0, 16, 16, 3, 1, 1, 0) == 0
+    assert L.vs_conv_out_len(h, 100) == 100
+    L.vs_conv_destroy(h)
+    assert L.vs_conv_create(ctypes.byref(h), 1, 16, 8, 16, 8, 4, 0) == 0
+    assert L.vs_conv_out_len(h, 10) == 80
+    L.vs_conv_destroy(h)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from visinger_amd import _lib
+    from visinger_amd.modules.visinger.encoder import WaveNet
+    m = WaveNet(16, 5, 1, 2).eval()
+    with torch.no_grad(), pytest.raises(_lib.VisingerHipError):
+        m(torch.zeros(1, 16, 8), torch.ones(1, 1, 8))
+
+
+def test_state_dict_matches_reference_manifest():
+    """Same parameter names and shapes as the reference's VISinger -> its checkpoints load with strict=True."""
+    from visinger_amd.models.visinger import VISinger
+    man = json.load(open(os.path.join(GOLDEN, "visinger_state_dict_manifest.json")))
+    m = VISinger(man["ph_dict_size"], man["pitch_size"], man["dur_size"], man["hparams"])
+    ours = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert ours == man["state_dict"]
+    # and the reverse direction: a reference-shaped state dict loads strictly
+    m.load_state_dict({k: torch.zeros(s) for k, s in man["state_dict"].items()}, strict=True)
+
+
+def test_signatures_match_survey_8b():
+    """Constructor / forward argument names of the boundary classes."""
+    from visinger_amd.modules.visinger import encoder, flow, decoder, predictor
+    from visinger_amd.modules import rel_transformer as rt
+
+    def params(f):
+        return [p for p in inspect.signature(f).parameters if p != "self"]
+
+    assert params(encoder.WaveNet.__init__) == ["hidden_channels", "kernel_size", "dilation_rate", "n_layers", "gin_channels", "p_dropout"]
+    assert params(encoder.WaveNet.forward)[:3] == ["x", "x_mask", "g"]
+    assert params(encoder.PosteriorEncoder.__init__) == ["in_channels", "out_channels", "hidden_channels", "kernel_size", "dilation_rate", "n_layers", "gin_channels"]
+    assert params(encoder.PosteriorEncoder.forward)[:3] == ["x", "nonpadding", "g"]
+    assert params(flow.ResidualCouplingBlock.__init__) == ["channels", "hidden_channels", "kernel_size", "dilation_rate", "n_layers", "n_flows", "gin_channels"]
+    assert params(flow.ResidualCouplingBlock.forward) == ["x", "x_mask", "g", "reverse"]
+    assert params(flow.ResidualCouplingLayer.__init__) == ["channels", "hidden_channels", "kernel_size", "dilation_rate", "n_layers", "p_dropout", "gin_channels", "mean_only"]
+    assert params(decoder.Generator.__init__) == ["initial_channel", "resblock", "resblock_kernel_sizes", "resblock_dilation_sizes", "upsample_rates", "upsample_initial_channel", "upsample_kernel_sizes", "gin_channels"]
+    assert params(decoder.Generator.forward) == ["x", "g"]
+    assert params(rt.RelativeEncoder.__init__)[:10] == ["hidden_channels", "filter_channels", "n_heads", "n_layers", "kernel_size", "p_dropout", "window_size", "block_length", "pre_ln", "gin_channels"]
+    assert params(rt.RelativeEncoder.forward) == ["x", "x_mask", "g"]
+    assert params(rt.MultiHeadAttention.__init__) == ["channels", "out_channels", "n_heads", "window_size", "heads_share", "p_dropout", "block_length", "proximal_bias", "proximal_init"]
+    assert params(rt.MultiHeadAttention.forward)[:3] == ["x", "c", "attn_mask"]
+    assert params(encoder.FramePriorNetwork.__init__) == ["hidden_channels", "filter_channels", "n_heads", "n_layers", "kernel_size", "gin_channels", "p_dropout"]
+    assert params(encoder.TextEncoder.forward) == ["text_tokens", "pitch_tokens", "dur_tokens", "mel2ph"]
+    assert params(predictor.PitchPredictor.forward) == ["x", "x_mask", "spk_emb"]
+    assert params(predictor.PhonemePredictor.forward) == ["x", "x_mask"]
+    with pytest.raises(AssertionError):
+        flow.ResidualCouplingLayer(5, 8, 5, 1, 2)                 # channels % 2 (flow.py:50)
+    with pytest.raises(AssertionError):
+        encoder.WaveNet(8, 4, 1, 2)                               # even kernel (encoder.py:133)
+    with pytest.raises(AssertionError):
+        rt.MultiHeadAttention(10, 10, 3)                          # channels % n_heads (rel_transformer.py:107)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="needs the reference checkout (build container only)")
+def test_reference_glue_imports_our_modules_unchanged():
+    """Drop-in: the reference's own models/visinger.py, imported unchanged, builds its VISinger out of our classes."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+from unittest.mock import MagicMock
+sys.dont_write_bytecode = True
+for n in ("librosa", "librosa.filters", "pyloudnorm", "webrtcvad", "skimage", "skimage.transform", "parselmouth", "pyworld", "torchaudio"):
+    sys.modules.setdefault(n, MagicMock())
+sys.path.insert(0, %r)
+import visinger_amd
+visinger_amd.install_as_reference_modules()
+sys.path.append("/root/reference")
+import json
+from models.visinger import VISinger          # the reference's file
+import visinger_amd.modules.visinger.decoder as d
+man = json.load(open(%r))
+m = VISinger(man["ph_dict_size"], man["pitch_size"], man["dur_size"], man["hparams"])
+assert type(m.decoder) is d.Generator, type(m.decoder)
+assert {k: list(v.shape) for k, v in m.state_dict().items()} == man["state_dict"]
+print("ok")
+''' % (ROOT, os.path.join(GOLDEN, "visinger_state_dict_manifest.json"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

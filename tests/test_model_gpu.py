@@ -1,0 +1,139 @@
+"""Model-level GPU parity (the caller of the hot path, reference models/visinger.py:71-112) against the reference's
+golden outputs, plus full-size (hidden 192) parity against the fp64 oracle and size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def maxerr(got, ref):
+    return float(np.abs(got.detach().cpu().double().numpy() - np.asarray(ref, np.float64)).max())
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    from visinger_amd.models.visinger import VISinger
+    w, a = load_golden("visinger_tiny")
+    hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_hparams.json")))
+    m = VISinger(13, 9, 7, hp)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    return m.cuda().eval(), a, hp, w
+
+
+def test_visinger_infer_matches_reference_golden(tiny):
+    m, a, hp, _ = tiny
+    with torch.no_grad():
+        ret = m(cu(a["text"]), cu(a["pitch"]), cu(a["dur"]), cu(a["mel2ph"]), spk_id=cu(a["spk_id"]), infer=True,
+                noise=cu(a["noise"]))
+    assert ret["wav_out"].shape == a["wav_out"].shape
+    assert maxerr(ret["wav_out"], a["wav_out"]) <= 1e-4          # waveform: 1e-4 abs (north star)
+
+
+def test_visinger_training_forward_matches_reference_golden(tiny):
+    m, a, hp, _ = tiny
+    with torch.no_grad():
+        ret = m(cu(a["text"]), cu(a["pitch"]), cu(a["dur"]), cu(a["mel2ph"]), spk_id=cu(a["spk_id"]), mel=cu(a["lin"]),
+                infer=False, noise_q=cu(a["noise_q"]), u_slice=torch.from_numpy(a["u_slice"]))
+    assert np.array_equal(ret["ids_slice"].cpu().numpy(), a["t_ids_slice"])      # integer indexing: bit-exact
+    assert maxerr(ret["z_p"], a["t_z_p"]) <= 5e-5
+    assert abs(float(ret["kl"]) - float(a["t_kl"])) <= 1e-4 * max(1.0, abs(float(a["t_kl"])))
+    assert maxerr(ret["ph_pred"], a["t_ph_pred"]) <= 1e-4
+    assert maxerr(ret["wav_out"], a["t_wav_out"]) <= 1e-4
+
+
+def _rand_sd(module, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("weight_g"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                fan = max(1, int(np.prod(p.shape[1:])))
+                p.copy_(scale * torch.randn(p.shape, generator=g) / np.sqrt(fan))
+    return {k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def test_full_size_coupling_logdet_1e4_relative(oracle):
+    """hidden 192, gin 256, 4 WaveNet layers, mean_only=False: flow log-det within 1e-4 relative of the fp64 oracle."""
+    from visinger_amd.modules.visinger.flow import ResidualCouplingLayer
+    B, T = 2, 200
+    m = ResidualCouplingLayer(192, 192, 5, 1, 4, gin_channels=256, mean_only=False)
+    sd = _rand_sd(m, 5, scale=0.5)
+    m = m.cuda().eval()
+    r = np.random.default_rng(3)
+    x = r.standard_normal((B, 192, T)).astype(np.float32)
+    g = r.standard_normal((B, 256, 1)).astype(np.float32)
+    mask = np.ones((B, 1, T), np.float32)
+    mask[1, :, 150:] = 0
+    ref_y, ref_ld = oracle.coupling_layer(sd, x, mask, g, False, channels=192, hidden_channels=192, kernel_size=5,
+                                          dilation_rate=1, n_layers=4, mean_only=False)
+    with torch.no_grad():
+        y, ld = m(cu(x), cu(mask), g=cu(g), reverse=False)
+        xr = m(y, cu(mask), g=cu(g), reverse=True)
+    assert maxerr(y, ref_y) <= 5e-5
+    rel = np.abs(ld.cpu().double().numpy() - ref_ld) / np.abs(ref_ld)
+    assert rel.max() <= 1e-4, rel
+    assert maxerr(xr[:, 96:] , x[:, 96:] * mask) <= 5e-5            # decode(encode(x)) == x on valid frames
+
+
+def test_full_size_flow_inverse_and_generator_vs_oracle(oracle):
+    """BASELINE config-2 path (flow inverse + HiFi-GAN, hop 256) at hidden 192 on a short clip vs the fp64 oracle."""
+    from visinger_amd.modules.visinger.flow import ResidualCouplingBlock
+    from visinger_amd.modules.visinger.decoder import Generator
+    B, T = 1, 24
+    flow = ResidualCouplingBlock(192, 192, 5, 1, 4, gin_channels=256)
+    sdf = _rand_sd(flow, 6, scale=0.5)
+    gen = Generator(192, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 2, 2], 512, [16, 16, 4, 4], gin_channels=256)
+    sdg = _rand_sd(gen, 7)
+    flow, gen = flow.cuda().eval(), gen.cuda().eval()
+    r = np.random.default_rng(4)
+    z = r.standard_normal((B, 192, T)).astype(np.float32)
+    g = r.standard_normal((B, 256, 1)).astype(np.float32)
+    mask = np.ones((B, 1, T), np.float32)
+    mask[0, :, 20:] = 0
+    zq_ref = oracle.flow_block(sdf, z, mask, g, True, channels=192, hidden_channels=192, kernel_size=5, dilation_rate=1,
+                               n_layers=4)
+    wav_ref = oracle.generator(sdg, zq_ref * mask, g, resblock="1", resblock_kernel_sizes=[3, 7, 11],
+                               resblock_dilation_sizes=[[1, 3, 5]] * 3, upsample_rates=[8, 8, 2, 2],
+                               upsample_kernel_sizes=[16, 16, 4, 4])
+    with torch.no_grad():
+        zq = flow(cu(z), cu(mask), g=cu(g), reverse=True)
+        wav = gen(zq * cu(mask), g=cu(g))
+    assert maxerr(zq, zq_ref) <= 5e-5
+    assert wav.shape == (B, 1, T * 256)
+    assert maxerr(wav, wav_ref) <= 1e-4
+
+
+def test_north_star_shape_properties():
+    """B=32, T_mel=1024 (the BASELINE.json size): size-independent checks -- flow encode->decode round trip,
+    batch-item independence (what makes the utterance shard exact), masked frames stay zero, finite waveform."""
+    from visinger_amd.modules.visinger.flow import ResidualCouplingBlock
+    torch.manual_seed(0)
+    B, T = 32, 1024
+    flow = ResidualCouplingBlock(192, 192, 5, 1, 4, gin_channels=256)
+    _rand_sd(flow, 8, scale=0.5)
+    flow = flow.cuda().eval()
+    x = torch.randn(B, 192, T, device="cuda")
+    g = torch.randn(B, 256, 1, device="cuda")
+    lens = torch.randint(T // 2, T + 1, (B,), device="cuda")
+    mask = (torch.arange(T, device="cuda")[None] < lens[:, None]).float()[:, None]
+    with torch.no_grad():
+        y = flow(x, mask, g=g, reverse=False)
+        xr = flow(y, mask, g=g, reverse=True)
+        y7 = flow(x[7:9].contiguous(), mask[7:9].contiguous(), g=g[7:9].contiguous(), reverse=False)
+    assert torch.isfinite(y).all()
+    # x0 halves pass through unmasked, x1 halves are masked by every coupling (flow.py:78,83)
+    assert float(((xr - x) * mask).abs().max()) <= 2e-4
+    assert torch.equal(y[7:9], y7), "batch items must be independent (utterance sharding is exact)"

@@ -48,6 +48,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime this library binds to (shared device
+    # pointers and streams), so torch is always loaded first.  Loading the .so before torch pulls in a second
+    # runtime from /opt/rocm and every hipMalloc then fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise VisingerHipError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -m visinger_amd.csrc.build, or "

@@ -12,6 +12,35 @@ def _off(t, elems):
     return ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
 
 
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing of the conv engine (used by bench.py for the roofline line).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (kernel instance name, algorithmic flops, start event, end event)
+
+    def start(self):
+        self.records = []
+        self.enabled = True
+
+    def stop(self):
+        self.enabled = False
+
+    def summary(self):
+        """-> {instance: dict(launches, flops, ms)} ; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, fl, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILER = LaunchProfiler()
+
+
 class ConvOp:
     """vs_conv_t: one nn.Conv1d / nn.ConvTranspose1d site, weights folded + packed on the device."""
 
@@ -34,6 +63,22 @@ class ConvOp:
 
     def out_len(self, T):
         return int(self.lib.vs_conv_out_len(self.h, T))
+
+    def kernel_instance(self):
+        """Name of the conv_mfma_kernel<MT_W,NT_W,WAVES_M,WAVES_N> instance vs_conv_forward dispatches to
+        (mirrors the selection in csrc/conv_engine.hip)."""
+        if self.kind == L.CONV1D_PAIRED:
+            mt = 2 * -(-(self.c_out // 2) // 32)
+            return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
+        rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
+        mt = -(-rows // 32)
+        return "conv_mfma_kernel<1,8,4,1>" if mt >= 3 else ("conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>")
+
+    def algorithmic_flops(self, B, T):
+        """2*MAC of the convolution itself (what torch.utils.flop_counter reports for the reference's op)."""
+        if self.kind == L.CONV_TRANSPOSE1D:
+            return 2.0 * B * self.c_in * self.c_out * self.k * T
+        return 2.0 * B * self.c_in * self.c_out * self.k * self.out_len(T)
 
     @property
     def rows_out(self):
@@ -88,7 +133,14 @@ class ConvOp:
             o1.out_mask, o1.mode = int(bool(out1.get("out_mask", False))), out1.get("mode", L.MODE_LINEAR)
         io.pair_mode = pair_mode
         io.logdet = L.ptr(logdet)
-        L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
+        if PROFILER.enabled:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
+            e1.record()
+            PROFILER.records.append((self.kernel_instance(), self.algorithmic_flops(B, T), e0, e1))
+        else:
+            L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
         return y
 
 
