@@ -114,12 +114,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     from visinger_amd.ops import PROFILER
+    from visinger_amd.dp import shard_batch, max_over_ranks
     model, hp = build_model()
     model = model.to(dev)
     B, T = args.batch, args.frames
     # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
     gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu")
-    text, pitch, dur, mel2ph, spk, noise = [t[rank::world].contiguous().to(dev) for t in gb]
+    text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
 
     def step():
         with torch.no_grad():
@@ -142,10 +143,7 @@ def main():
     dt = time.perf_counter() - t0
     PROFILER.stop()
     assert wav.shape == (B, T * HOP) and bool(torch.isfinite(wav).all())
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, device=dev)
     samples = B * world * T * HOP * args.steps
 
     if rank == 0:
