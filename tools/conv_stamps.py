@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Debug: per-workgroup phase timeline of one conv launch (uses the vs_debug_set_stamp_buffer hook)."""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visinger_amd import _lib as L
+from visinger_amd.ops import ConvOp
+
+C, k, d, T, B = int(os.environ.get("C", 128)), int(os.environ.get("K", 3)), 1, int(os.environ.get("T", 65536)), int(os.environ.get("B", 32))
+op = ConvOp(L.CONV1D, C, C, k, d, (k * d - d) // 2)
+op.set_weights(torch.randn(C, C, k, device="cuda") * 0.05, None, torch.randn(C, device="cuda"))
+x = torch.randn(B, C, T, device="cuda"); y = torch.empty_like(x); res = torch.randn_like(x)
+use_res = os.environ.get("RES", "1") == "1"
+for _ in range(2):
+    op.forward(x, y=y, res=res if use_res else None, in_act=L.IN_LRELU)
+nblk = 65536
+buf = torch.zeros(nblk * 64, dtype=torch.int64, device="cuda")
+lib = L.lib()
+lib.vs_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+lib.vs_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+torch.cuda.synchronize()
+op.forward(x, y=y, res=res if use_res else None, in_act=L.IN_LRELU)
+torch.cuda.synchronize()
+lib.vs_debug_set_stamp_buffer(None)
+full = buf.cpu().numpy().reshape(-1, 64)
+full = full[full[:, 0] != 0]
+s = full[:, :8]
+t0 = s[:, 0].min()
+st = (s[:, :4] - t0) / 100.0     # us
+print("workgroups", len(s), "launch span %.1f us" % st[:, 3].max())
+pro, main, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
+for name, v in (("prologue", pro), ("main", main), ("epilogue", epi), ("total", st[:, 3] - st[:, 0])):
+    print(f"{name:9s} mean {v.mean():8.2f}  p10 {np.percentile(v,10):8.2f}  p50 {np.percentile(v,50):8.2f}  p90 {np.percentile(v,90):8.2f}  max {v.max():8.2f} us")
+cyc = (s[:, 5] - s[:, 4]).astype(np.float64)
+print("main-loop shader cycles: mean %.0f ; implied clock %.3f GHz" % (cyc.mean(), (cyc / (main * 1e3)).mean()))
+hw = s[:, 7] & 0xffffffff
+xcc = s[:, 7] >> 32
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x3   # HW_ID layout guess: cu_id[11:8], sh_id[12], se_id[15:13]
+print("xcc ids seen:", np.unique(xcc))
+# first 16 workgroups: start time, placement
+order = np.argsort(s[:, 0])
+for i in order[:12]:
+    print(f"wg {i:5d} start {st[i,0]:8.2f} pro {pro[i]:6.2f} main {main[i]:7.2f} epi {epi[i]:6.2f}  xcc {xcc[i]} hw {hw[i]:08x}")
+# concurrency: how many workgroups are in their epilogue at each time
+ts = np.linspace(0, st[:, 3].max(), 400)
+in_epi = [(np.logical_and(st[:, 2] <= t, st[:, 3] > t)).sum() for t in ts]
+in_main = [(np.logical_and(st[:, 1] <= t, st[:, 2] > t)).sum() for t in ts]
+print("in-epilogue count: mean %.1f max %d ; in-main mean %.1f" % (np.mean(in_epi), np.max(in_epi), np.mean(in_main)))
+# starts per round
+starts = np.sort(st[:, 0])
+print("start-time quantiles:", np.percentile(starts, [0, 5, 6.3, 12.5, 25, 50, 75, 100]).round(1))
+
+steps = full[:, 8:]
+nst = int((steps[0] != 0).sum())
+d = np.diff(steps[:, :nst].astype(np.float64), axis=1)
+print("per-step shader cycles (median over workgroups):", np.median(d, axis=0).round(0).astype(int).tolist())
+print("last step -> main end:", np.median(full[:, 5] - steps[:, nst - 1]))
+
+# which workgroups share a CU in the first dispatch round?
+first = np.where(st[:, 0] < 5.0)[0]
+cu_of = {}
+for i in first:
+    key = (int(xcc[i]), int((hw[i] >> 13) & 7), int((hw[i] >> 12) & 1), int((hw[i] >> 8) & 0xf))
+    cu_of.setdefault(key, []).append(int(i))
+print("first round: %d workgroups on %d CUs" % (len(first), len(cu_of)))
+diffs = {}
+for k, v in cu_of.items():
+    if len(v) == 2:
+        diffs[abs(v[0] - v[1])] = diffs.get(abs(v[0] - v[1]), 0) + 1
+print("id distance of CU-mates:", sorted(diffs.items(), key=lambda kv: -kv[1])[:6])
+print("examples:", list(cu_of.items())[:4])

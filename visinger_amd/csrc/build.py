@@ -42,6 +42,7 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.utime(LIB, None)
     return LIB
 
 

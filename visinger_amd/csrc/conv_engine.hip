@@ -23,7 +23,10 @@
 #include "vs_internal.h"
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdlib>
 #include <new>
+#include <type_traits>
 
 namespace vs {
 
@@ -48,6 +51,7 @@ struct OutSpec {
     long long y_bs, res_bs, acc_bs;
     float scale;
     int out_act, out_mask, mode;
+    int rows;    // rows addressable through res/acc (bounds of the buffer descriptors)
 };
 
 struct ConvParams {
@@ -73,6 +77,9 @@ struct ConvParams {
     int off0, tstep, lo, W;
     int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
     int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
+    int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
+    unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
+    int stagger;                // desynchronise the two co-resident workgroups of a CU (first dispatch round only)
 };
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
@@ -83,6 +90,17 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ float tanh_fast(float v) {
     const float t = expf(-2.0f * fabsf(v));
     return copysignf((1.0f - t) / (1.0f + t), v);
+}
+
+
+__device__ __forceinline__ void stamp(const ConvParams &p, int slot) {
+    if (p.stamps && threadIdx.x == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        p.stamps[(size_t)lin * 64 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 1 || slot == 2) p.stamps[(size_t)lin * 64 + 3 + slot] = __builtin_amdgcn_s_memtime();   // [4], [5]: shader clock
+        if (slot == 0) p.stamps[(size_t)lin * 64 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+    }
 }
 
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N>
@@ -131,6 +149,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         tap_e = min(p.KT, hi_t);
     }
 
+    // Co-resident workgroups do identical work, so they run their memory-bound prologue/epilogue and their MFMA main
+    // loop in lockstep.  Delaying every second workgroup of the first dispatch round by ~half a main loop puts one
+    // workgroup's epilogue under the other's MFMAs for the rest of the launch (speed only: nothing depends on it).
+    if (p.stagger) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (p.stagger > 0 && lin < 512u && ((lin >> 8) & 1u)) {
+            const long long delay = (long long)p.nchunks * (tap_e - tap_b) * (CK / 2) * (MT_W * NT_W) * 64 * p.stagger / 4;
+            const long long t0 = __builtin_amdgcn_s_memtime();
+            while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+
     f32x16 acc[MT_W][NT_W];
 #pragma unroll
     for (int i = 0; i < MT_W; ++i)
@@ -143,22 +173,31 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     float mk[CIT];
     const int in_act = p.in_act;
 
-    // Staging loads are UNCONDITIONAL (clamped addresses) and the zero-fill is applied when the registers are
-    // written to LDS: a predicated load makes hipcc branch around every load and drain vmcnt(0) per element.
-    auto stage_load = [&](int chunk) {
+    // Staging loads are UNCONDITIONAL buffer loads (one 32-bit offset VGPR per LDS row, the column iterations are
+    // immediate offsets; out-of-range bytes of the item's [Cin, Tin] slab read as 0 by the descriptor's bounds check)
+    // and the zero-fill of the halo is applied when the registers are written to LDS: a predicated load makes hipcc
+    // branch around every load and drain vmcnt(0) per element, and 64-bit per-load addresses cost 2 VGPRs each.
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.Cin * p.Tin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t msrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(maskb ? maskb : xb), 0, p.Tin * 4, 0x00020000);
+    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
+        const int nbase = n0 + p.lo + lane;
+        if (in_act >= VS_IN_MASK) {
 #pragma unroll
-        for (int i = 0; i < CIT; ++i) {
-            const int n = n0 + p.lo + lane + 64 * i;
-            const int nc = min(max(n, 0), p.Tin - 1);
-            if (in_act >= VS_IN_MASK) mk[i] = maskb[nc];
+            for (int i = 0; i < CIT; ++i)
+                mk[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msrc, nbase * 4 + i * 256, 0, 0));
+        }
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                const int ci = min(chunk * CK + wave + NW * j, p.Cin - 1);
-                st[j][i] = xb[(long long)ci * p.Tin + nc];
-            }
+        for (int j = 0; j < RPW; ++j) {
+            const int ci = min(chunk * CK + wave + NW * j, p.Cin - 1);
+            const int voff = (ci * p.Tin + nbase) * 4;
+#pragma unroll
+            for (int i = 0; i < CIT; ++i)
+                st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
         }
     };
-    auto stage_store = [&](float *buf, int chunk) {
+    auto stage_store = [&](float *buf, int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CIT; ++i) {
             const int col = lane + 64 * i;
@@ -178,65 +217,99 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     const int lhalf = lane >> 5;
     const int l31 = lane & 31;
 
+    // ---------------------------------------------------------------------------------------------- main loop
+    // The K loop is flattened into steps s = (chunk, tap); a step is 8 groups (one per input-channel pair) of
+    // MT_W*NT_W MFMAs.  Software pipeline (hipcc builds none by itself):
+    //   * A fragments (packed weights, L2-resident): 3-deep register ring rotated by NAME (the step loop is unrolled
+    //     by 3; a rotating copy would read the slot being prefetched); the slot of step s+2 is requested at step s;
+    //   * activations of chunk c+1 (HBM latency): requested at the first tap of chunk c, right AFTER that step's A
+    //     prefetch (vmcnt retires in issue order: whatever is issued behind them completes behind them), written to
+    //     the other LDS buffer after the last tap;
+    //   * B fragments of group g+1 are read from LDS under the MFMAs of group g, pinned above them by sched_barrier
+    //     (left alone hipcc sinks each ds_read next to its consumer: ds_read2 -> lgkmcnt(0) -> 2 MFMA).
+    // Tried and measured worse (tools/conv_stamps.py, per-step shader cycles): inline-asm ring loads with hand-counted
+    // vmcnt (same), staging pieces spread over the gaps between groups (+8 %: a lone wave hides only ~64 cycles of
+    // non-MFMA issue per gap).
+    const int ntaps = tap_e - tap_b;
+    const int nsteps = p.nchunks * ntaps;
+    const float *wbase[MT_W];
+#pragma unroll
+    for (int i = 0; i < MT_W; ++i) wbase[i] = p.wp + (long long)(mt0 + i) * p.KT * p.CP * 64 + lane;
+    float a0[MT_W][CK / 2], a1[MT_W][CK / 2], a2[MT_W][CK / 2];
+    auto load_a = [&](float (&dst)[MT_W][CK / 2], int chunk, int tap) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+            for (int cp = 0; cp < CK / 2; ++cp)
+                dst[i][cp] = wbase[i][((long long)tap * p.CP + chunk * (CK / 2) + cp) * 64];
+    };
+    // (chunk, tap) of the step two ahead of the current one
+    int pc = 0, pt = tap_b;
+    auto advance = [&]() __attribute__((always_inline)) { if (++pt == tap_e) { pt = tap_b; ++pc; } };
+    if (nsteps > 0) { load_a(a0, pc, pt); advance(); }
+    if (nsteps > 1) { load_a(a1, pc, pt); advance(); }
+
+    stamp(p, 0);
     stage_load(0);
     stage_store(buf0, 0);
     __syncthreads();
+    stamp(p, 1);
 
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    int chunk = 0, tap = tap_b, s = 0;
+    auto step = [&](float (&acur)[MT_W][CK / 2], float (&apre)[MT_W][CK / 2]) __attribute__((always_inline)) {
         const float *cur = (chunk & 1) ? buf1 : buf0;
         const bool more = (chunk + 1 < p.nchunks);
-        if (more) stage_load(chunk + 1);
+        if (s + 2 < nsteps) { load_a(apre, pc, pt); advance(); }
+        if (tap == tap_b && more) stage_load(chunk + 1);
 
-        // Software pipeline (hipcc does not build one by itself): the 8 A fragments of tap t+1 are requested from
-        // L2 while tap t computes, and the B fragments of k-step s+1 are read from LDS under the MFMAs of step s.
-        const float *const xs0 = cur + lhalf * W + wn * (NT_W * 32) + l31 - p.lo;
-        const float *wbase[MT_W];
+        const float *xs = cur + lhalf * W + wn * (NT_W * 32) + l31 - p.lo + (p.off0 + tap * p.tstep);
+        float bf[NT_W], bn[NT_W];
 #pragma unroll
-        for (int i = 0; i < MT_W; ++i)
-            wbase[i] = p.wp + ((long long)(mt0 + i) * p.KT * p.CP + chunk * (CK / 2)) * 64 + lane;
-        float a_cur[MT_W][CK / 2], a_nxt[MT_W][CK / 2];
-        if (tap_b < tap_e) {
+        for (int j = 0; j < NT_W; ++j) bf[j] = xs[j * 32];
+#pragma unroll
+        for (int cp = 0; cp < CK / 2; ++cp) {
+            if (cp + 1 < CK / 2) {
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) bn[j] = xs[(cp + 1) * 2 * W + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT_W; ++i)
 #pragma unroll
-                for (int cp = 0; cp < CK / 2; ++cp) a_cur[i][cp] = wbase[i][((long long)tap_b * p.CP + cp) * 64];
+                for (int j = 0; j < NT_W; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[i][cp], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j) bf[j] = bn[j];
         }
-        for (int tap = tap_b; tap < tap_e; ++tap) {
-            if (tap + 1 < tap_e) {
-#pragma unroll
-                for (int i = 0; i < MT_W; ++i)
-#pragma unroll
-                    for (int cp = 0; cp < CK / 2; ++cp)
-                        a_nxt[i][cp] = wbase[i][((long long)(tap + 1) * p.CP + cp) * 64];
-            }
-            const float *xs = xs0 + (p.off0 + tap * p.tstep);
-            float bf[NT_W], bn[NT_W];
-#pragma unroll
-            for (int j = 0; j < NT_W; ++j) bf[j] = xs[j * 32];
-#pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
-                if (cp + 1 < CK / 2) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j) bn[j] = xs[(cp + 1) * 2 * W + j * 32];
-                }
-#pragma unroll
-                for (int i = 0; i < MT_W; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][cp], bf[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < NT_W; ++j) bf[j] = bn[j];
-            }
-#pragma unroll
-            for (int i = 0; i < MT_W; ++i)
-#pragma unroll
-                for (int cp = 0; cp < CK / 2; ++cp) a_cur[i][cp] = a_nxt[i][cp];
+        if (++tap == tap_e) {
+            if (more) stage_store((chunk & 1) ? buf0 : buf1, chunk + 1);
+            __syncthreads();
+            tap = tap_b;
+            ++chunk;
         }
-
-        if (more) stage_store((chunk & 1) ? buf0 : buf1, chunk + 1);
-        __syncthreads();
+        ++s;
+    };
+    while (s < nsteps) {
+        step(a0, a2);
+        if (s < nsteps) step(a1, a0);
+        if (s < nsteps) step(a2, a1);
     }
 
+    stamp(p, 2);
+    if (p.stagger == -1) { stamp(p, 3); return; }   // debug: skip the epilogue
+    if (p.stagger == -2) {                            // debug: touch the accumulators only
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT_W; ++i)
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 123.456f) p.out[0].y[0] = sacc;
+        stamp(p, 3);
+        return;
+    }
     // ------------------------------------------------------------------ epilogue
     // All loops have constant trip counts and no early exits (acc[][][] must stay in registers); every global
     // LOAD is unconditional on a clamped address and issued NT_W at a time ahead of its uses, only the STORES are
@@ -246,8 +319,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
 #pragma unroll
     for (int j = 0; j < NT_W; ++j) ncol[j] = n0 + (wn * NT_W + j) * 32 + l31;
 
-    if (p.kind == VS_CONV1D_PAIRED) {
-        if constexpr (MT_W == 2) {
+    // (the host dispatches PAIRED convs to the MT_W == 2 instances only, and every other kind to MT_W == 1)
+    if constexpr (MT_W == 2) {
+        {
             // tiles (2i, 2i+1) of this wave hold rows c (first half) and Hh + c (second half)
             const OutSpec o = p.out[0];
             const int pair = mt0 >> 1;
@@ -299,8 +373,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         return;
     }
 
+    if constexpr (MT_W == 1) {
     // Every 32-row tile goes to exactly one output spec (the host guarantees split_row % 32 == 0 or launches the
     // two specs separately with a row window), so the spec, its null-checks and its mode are wave-uniform.
+    //
+    // Residual / accumulate reads are issued RB rows (RB * NT_W loads per lane) at a time before the first use: each
+    // batch exposes one HBM round trip (2-4 us with the whole chip in its epilogue), so a one-row batch (16 round
+    // trips per tile) cost ~0.9 ms of a 2.3 ms launch at C=128, k=3.  RB*NT_W = 32 loads in flight per lane when only
+    // `res` is read, 2 x 16 when `acc` is read as well (more spills: 128 accumulators + per-row metadata).
     const bool transposed = (p.kind == VS_CONV_TRANSPOSE1D);
 #pragma unroll
     for (int i = 0; i < MT_W; ++i) {
@@ -310,63 +390,143 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         const int row_sub = s1 ? p.split_row : 0;
         const bool has_res = o.res != nullptr, has_acc = o.acc != nullptr;
         const bool use_mask = (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
+        float *const yb = o.y + (long long)b * o.y_bs;
+        const int spec_bytes = (int)((long long)o.rows * p.Tout * 4);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(has_res ? o.res + (long long)b * o.res_bs : yb), 0, spec_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(has_acc ? o.acc + (long long)b * o.acc_bs : yb), 0, spec_bytes, 0x00020000);
+        // ---- fast path: interior tile of a plain conv.  The accumulator tile (row = register, column = lane) is
+        // transposed through the now-idle staging LDS, 8 rows at a time, so that every global access of the epilogue
+        // is one 16-B-per-lane instruction over a contiguous run of a row (1 KiB per wave-instruction at NT_W = 8)
+        // instead of 4-B stores split over two rows, and the per-element predicate / address arithmetic disappears.
+        // (Measured on the element-wise path: 44 us of a 138 us workgroup at C=128, k=3 WITHOUT any store or
+        // residual load -- instruction-issue-bound, not memory-bound.)
+        if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M)) {
+            constexpr int CW = 32 * NT_W;          // columns of this wave's tile
+            constexpr int LPR = CW / 4;            // lanes per row (float4 each)
+            constexpr int RPI = 64 / LPR;          // rows per wave-instruction
+            constexpr int NIT = 8 / RPI;           // instructions per 8-row pass
+            float *const Lw = smem + wave * 8 * CW;
+            const int lrow = lane / LPR;
+            const int c4 = (lane % LPR) * 4;
+            const int colg = n0 + wn * CW + c4;
+            float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (use_mask) m4 = *reinterpret_cast<const float4 *>(maskb + colg);
+            float badd[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            const int mc = min(m, p.M - 1);
-            int row = mc, phase = 0;
-            if (transposed) { phase = mc / p.c_out; row = mc - phase * p.c_out; }
-            const bool okm = (m < p.M) && (row >= p.row_lo) && (row < p.row_hi);
-            float badd = p.biasp[mc];
-            if (bbias) badd += bbias[row];
-            const long long roff = (long long)(row - row_sub) * p.Tout;
-            float *const y = o.y + (long long)b * o.y_bs + roff;
-            int col[NT_W], cc[NT_W];
-            float rv[NT_W], av[NT_W], mv[NT_W];
-#pragma unroll
-            for (int j = 0; j < NT_W; ++j) {
-                col[j] = transposed ? ncol[j] * p.up + phase : ncol[j];
-                cc[j] = min(col[j], p.Tout - 1);
-                rv[j] = 0.f; av[j] = 0.f; mv[j] = 1.f;
+            for (int r = 0; r < 16; ++r) {
+                const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                badd[r] = p.biasp[row];
+                if (bbias) badd[r] += bbias[row];
             }
-            if (has_res) {
-                const float *res = o.res + (long long)b * o.res_bs + roff;
+            const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
+            const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
 #pragma unroll
-                for (int j = 0; j < NT_W; ++j) rv[j] = res[cc[j]];
-            }
-            if (has_acc) {
-                const float *ac = o.acc + (long long)b * o.acc_bs + roff;
+            for (int ps = 0; ps < 4; ++ps) {
+                float4 r4[NIT], a4[NIT];
+                long long goff[NIT];
 #pragma unroll
-                for (int j = 0; j < NT_W; ++j) av[j] = ac[cc[j]];
-            }
-            if (use_mask) {
-#pragma unroll
-                for (int j = 0; j < NT_W; ++j) mv[j] = maskb[cc[j]];
-            }
-            float outv[NT_W];
-            if (o.mode == VS_OUT_LINEAR) {
-#pragma unroll
-                for (int j = 0; j < NT_W; ++j) outv[j] = (acc[i][j][r] + badd + rv[j] + av[j]) * o.scale;
-                if (o.out_act == VS_OUT_TANH) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j) outv[j] = tanh_fast(outv[j]);
-                } else if (o.out_act == VS_OUT_RELU) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j) outv[j] = fmaxf(outv[j], 0.f);
+                for (int it = 0; it < NIT; ++it) {
+                    goff[it] = (long long)(tile_row0 - row_sub + 8 * ps + it * RPI + lrow) * p.Tout + colg;
+                    if (has_res) r4[it] = *reinterpret_cast<const float4 *>(resp + goff[it]);
+                    if (has_acc) a4[it] = *reinterpret_cast<const float4 *>(accp + goff[it]);
                 }
 #pragma unroll
-                for (int j = 0; j < NT_W; ++j) outv[j] *= mv[j];
-            } else if (o.mode == VS_OUT_COUPLING_MEAN_FWD) {
+                for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int j = 0; j < NT_W; ++j) outv[j] = (acc[i][j][r] + badd) * mv[j] + rv[j] * mv[j];
-            } else {
+                    for (int j = 0; j < NT_W; ++j)
+                        Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = acc[i][j][4 * ps + q] + badd[4 * ps + q];
+                }
 #pragma unroll
-                for (int j = 0; j < NT_W; ++j) outv[j] = (rv[j] - (acc[i][j][r] + badd) * mv[j]) * mv[j];
+                for (int it = 0; it < NIT; ++it) {
+                    float4 v = *reinterpret_cast<const float4 *>(Lw + (it * RPI + lrow) * CW + c4);
+                    if (has_res) { v.x += r4[it].x; v.y += r4[it].y; v.z += r4[it].z; v.w += r4[it].w; }
+                    if (has_acc) { v.x += a4[it].x; v.y += a4[it].y; v.z += a4[it].z; v.w += a4[it].w; }
+                    v.x *= o.scale; v.y *= o.scale; v.z *= o.scale; v.w *= o.scale;
+                    if (o.out_act == VS_OUT_TANH) {
+                        v.x = tanh_fast(v.x); v.y = tanh_fast(v.y); v.z = tanh_fast(v.z); v.w = tanh_fast(v.w);
+                    } else if (o.out_act == VS_OUT_RELU) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
+                    *reinterpret_cast<float4 *>(yb + goff[it]) = v;
+                }
             }
+        } else {
+
+        float mv[NT_W];
 #pragma unroll
-            for (int j = 0; j < NT_W; ++j)
-                if (okm && ncol[j] < p.N && col[j] < p.Tout) y[col[j]] = outv[j];
+        for (int j = 0; j < NT_W; ++j) mv[j] = 1.f;
+        if (use_mask) {
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j) mv[j] = maskb[min(ncol[j], p.Tout - 1)];   // (never with a transposed conv)
         }
+
+        auto run = [&](auto rb_tag, auto acc_tag) __attribute__((always_inline)) {
+            constexpr int RB = decltype(rb_tag)::value;
+            constexpr bool WITH_ACC = decltype(acc_tag)::value;
+#pragma unroll
+            for (int nb = 0; nb < 16 / RB; ++nb) {
+                float rv[RB][NT_W], av[WITH_ACC ? RB : 1][NT_W], badd[RB];
+                int roff[RB], phase_[RB];
+                bool okm[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = nb * RB + q;
+                    const int m = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    const int mc = min(m, p.M - 1);
+                    int row = mc, phase = 0;
+                    if (transposed) { phase = mc / p.c_out; row = mc - phase * p.c_out; }
+                    okm[q] = (m < p.M) && (row >= p.row_lo) && (row < p.row_hi);
+                    phase_[q] = phase;
+                    float bd = p.biasp[mc];
+                    if (bbias) bd += bbias[row];
+                    badd[q] = bd;
+                    roff[q] = (row - row_sub) * p.Tout;       // < 2^31: one item's rows * T_out
+                    // (res / acc are never combined with a transposed conv: host-checked)
+                    const int voff = (roff[q] + ncol[0]) * 4;
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j) {
+                        rv[q][j] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + j * 128, 0, 0)) : 0.f;
+                        if constexpr (WITH_ACC)
+                            av[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(asrc, voff + j * 128, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = nb * RB + q;
+                    float *const y = yb + roff[q];
+#pragma unroll
+                    for (int j = 0; j < NT_W; ++j) {
+                        const int col = transposed ? ncol[j] * p.up + phase_[q] : ncol[j];
+                        const float v = acc[i][j][r] + badd[q];
+                        float outv;
+                        if (o.mode == VS_OUT_LINEAR) {
+                            outv = v + rv[q][j];
+                            if constexpr (WITH_ACC) outv += av[q][j];
+                            outv *= o.scale;
+                            if (o.out_act == VS_OUT_TANH) outv = tanh_fast(outv);
+                            else if (o.out_act == VS_OUT_RELU) outv = fmaxf(outv, 0.f);
+                            outv *= mv[j];
+                        } else if (o.mode == VS_OUT_COUPLING_MEAN_FWD) {
+                            outv = v * mv[j] + rv[q][j] * mv[j];
+                        } else {
+                            outv = (rv[q][j] - v * mv[j]) * mv[j];
+                        }
+                        if (okm[q] && ncol[j] < p.N && col < p.Tout) y[col] = outv;
+                    }
+                }
+            }
+        };
+        if (has_acc) run(std::integral_constant<int, (NT_W >= 8 ? 2 : 4)>{}, std::true_type{});
+        else run(std::integral_constant<int, (NT_W >= 8 ? 4 : 8)>{}, std::false_type{});
+        }   // element-wise path
+    }
+    }   // MT_W == 1
+    if (p.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);   // all stores acknowledged
+        stamp(p, 3);
     }
 }
 
@@ -470,6 +630,8 @@ static inline int ceil_div_i(int a, int b) { return -floor_div(-a, b); }
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 
+static unsigned long long *g_stamp_buf = nullptr;   // debug hook, see vs_debug_set_stamp_buffer
+
 struct vs_conv {
     int kind, c_in, c_out, k, dil, pad;   // dil = stride for transposed
     unsigned flags;
@@ -514,6 +676,11 @@ int vs_device_info(char *buf, size_t n) {
     }
     return cnt;
 }
+
+// Debug only (not part of the public header): per-workgroup phase stamps of the next conv launches are written
+// to buf[64 * n_workgroups] (s_memrealtime, 100 MHz): [0] start, [1] first chunk staged, [2] main loop done, [3] epilogue
+// issued, [7] HW ids.  NULL disables.
+__attribute__((visibility("default"))) void vs_debug_set_stamp_buffer(void *buf) { g_stamp_buf = (unsigned long long *)buf; }
 
 int vs_weightnorm_fold(const float *v, const float *g, float *w, int64_t rows, int64_t cols, void *stream) {
     VS_REQUIRE(v && g && w && rows > 0 && cols > 0, "vs_weightnorm_fold: bad arguments");
@@ -632,6 +799,9 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     p.N = (h->kind == VS_CONV_TRANSPOSE1D) ? (int)ceil_div(Tout, h->dil) : (int)Tout;
     p.KT = h->KT; p.CP = h->CP; p.nchunks = h->nchunks;
     p.off0 = h->off0; p.tstep = h->tstep; p.lo = h->lo;
+    static const int stagger_env = getenv("VS_STAGGER") ? atoi(getenv("VS_STAGGER")) : 0;
+    p.stagger = stagger_env;
+    p.stamps = g_stamp_buf;
     p.up = (h->kind == VS_CONV_TRANSPOSE1D) ? h->dil : 1;
     p.upK = h->k; p.uppad = h->pad; p.dmin = h->dmin;
     const int rows_out = (h->kind == VS_CONV1D_PAIRED) ? h->Hh : h->c_out;
@@ -647,12 +817,17 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         d.y_bs = o.y_bs ? o.y_bs : dflt; d.res_bs = o.res_bs ? o.res_bs : dflt; d.acc_bs = o.acc_bs ? o.acc_bs : dflt;
         d.scale = (o.scale == 0.f) ? 1.f : o.scale;   // 0 = unset
         d.out_act = o.out_act; d.out_mask = o.out_mask; d.mode = o.mode;
+        d.rows = rows;
         if (s == 0 || p.split_row) {
             need_mask |= (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
             VS_REQUIRE(o.mode == VS_OUT_LINEAR || o.res, "vs_conv_forward: coupling mode needs res (x1)");
         }
     }
     VS_REQUIRE(!p.split_row || io->out[1].y, "vs_conv_forward: split_row set but out[1].y is NULL");
+    VS_REQUIRE(h->kind != VS_CONV_TRANSPOSE1D || (!io->out[0].res && !io->out[0].acc && !p.split_row),
+               "vs_conv_forward: res / acc / split_row are not supported with a transposed conv");
+    VS_REQUIRE((long long)h->c_in * io->T * 4 < (1ll << 31) && (long long)rows_out * Tout * 4 < (1ll << 31),
+               "vs_conv_forward: one item's tensor exceeds the 2 GiB buffer-descriptor range");
     if (h->kind == VS_CONV1D_PAIRED) {
         VS_REQUIRE(io->pair_mode >= VS_PAIR_GATE && io->pair_mode <= VS_PAIR_COUPLING_INV, "bad pair_mode");
         if (io->pair_mode != VS_PAIR_GATE) {
@@ -671,6 +846,17 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         p.W = 256 + h->span;
         return launch_cfg<2, 2, 1, 4>(p, s);
     }
+    {
+        auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+        bool ok = (h->kind == VS_CONV1D) && (Tout % 4 == 0) && !getenv("VS_NO_FAST_EPI");
+        for (int s2 = 0; s2 < (p.split_row ? 2 : 1) && ok; ++s2) {
+            const OutSpec &d = p.out[s2];
+            ok = ok && d.mode == VS_OUT_LINEAR && al16(d.y) && (d.y_bs % 4 == 0) && (!d.res || (al16(d.res) && d.res_bs % 4 == 0)) &&
+                 (!d.acc || (al16(d.acc) && d.acc_bs % 4 == 0));
+        }
+        ok = ok && (!p.mask || al16(p.mask)) && (!p.split_row || p.split_row % 32 == 0);
+        p.fast_epi = ok ? 1 : 0;
+    }
     auto launch = [&](const ConvParams &q) -> int {
         if (h->MT >= 3) return launch_cfg<1, 8, 4, 1>(q, s);
         if (h->MT == 2) return launch_cfg<1, 8, 2, 2>(q, s);
@@ -683,6 +869,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         // a 32-row tile would straddle the two destinations: store them in two passes (odd sizes only; the
         // production split is hidden_channels = 192 = 6 tiles)
         ConvParams q = p;
+        q.fast_epi = 0;
         q.split_row = 0;
         q.row_hi = p.split_row;
         VS_TRY(launch(q));
@@ -690,6 +877,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         q.row_lo = p.split_row;
         q.row_hi = h->c_out;
         // rows are addressed relative to split_row in the second destination
+        q.out[0].rows = h->c_out;
         q.out[0].y -= (long long)p.split_row * p.Tout;
         if (q.out[0].res) q.out[0].res -= (long long)p.split_row * p.Tout;
         if (q.out[0].acc) q.out[0].acc -= (long long)p.split_row * p.Tout;
