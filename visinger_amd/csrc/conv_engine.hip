@@ -79,7 +79,6 @@ struct ConvParams {
     int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
     int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
     unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
-    int stagger;                // desynchronise the two co-resident workgroups of a CU (first dispatch round only)
 };
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
@@ -147,18 +146,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         }
         tap_b = max(0, lo_t);
         tap_e = min(p.KT, hi_t);
-    }
-
-    // Co-resident workgroups do identical work, so they run their memory-bound prologue/epilogue and their MFMA main
-    // loop in lockstep.  Delaying every second workgroup of the first dispatch round by ~half a main loop puts one
-    // workgroup's epilogue under the other's MFMAs for the rest of the launch (speed only: nothing depends on it).
-    if (p.stagger) {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (p.stagger > 0 && lin < 512u && ((lin >> 8) & 1u)) {
-            const long long delay = (long long)p.nchunks * (tap_e - tap_b) * (CK / 2) * (MT_W * NT_W) * 64 * p.stagger / 4;
-            const long long t0 = __builtin_amdgcn_s_memtime();
-            while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(64);
-        }
     }
 
     f32x16 acc[MT_W][NT_W];
@@ -297,19 +284,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     }
 
     stamp(p, 2);
-    if (p.stagger == -1) { stamp(p, 3); return; }   // debug: skip the epilogue
-    if (p.stagger == -2) {                            // debug: touch the accumulators only
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < MT_W; ++i)
-#pragma unroll
-            for (int j = 0; j < NT_W; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 123.456f) p.out[0].y[0] = sacc;
-        stamp(p, 3);
-        return;
-    }
     // ------------------------------------------------------------------ epilogue
     // All loops have constant trip counts and no early exits (acc[][][] must stay in registers); every global
     // LOAD is unconditional on a clamped address and issued NT_W at a time ahead of its uses, only the STORES are
@@ -622,6 +596,132 @@ __global__ void pack_conv_kernel(const PackParams q) {
     q.wp[e] = val;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Convs with <= 4 output channels (HiFi-GAN conv_post 32->1 k7 + tanh, decoder.py:34,55-57; PitchPredictor.linear
+// 192->2, predictor.py:14): a 32-row MFMA tile would be 97 % padding (measured 1.7 ms for conv_post at 2 TFLOP/s),
+// and the op is a pure HBM stream of its input (1.07 GB for conv_post), so it runs on the VALU: one thread per
+// 4 consecutive output frames, weights through the scalar cache, x re-read across taps through L1.
+struct SmallParams {
+    const float *x;
+    long long x_bs;
+    const float *w;      // effective weights [c_out][c_in][k]
+    const float *bias;   // [c_out] or null
+    const float *bias_b;
+    long long bias_b_bs;
+    const float *mask;   // [B, T]
+    float *y;
+    long long y_bs;
+    int B, Cin, Cout, Tin, Tout, K, dil, pad, in_act, out_act, out_mask;
+    float scale;
+};
+
+// KT > 0: compile-time taps KT and padding PAD (PAD <= 4, KT-1-PAD <= 4), dilation 1, T % 4 == 0, 16-B aligned rows: each thread
+// produces 4 consecutive frames from three aligned float4 loads per input channel (its own 16 bytes, coalesced, plus
+// its two neighbours' through L1), activates every value once and keeps the window in registers for all taps.
+// KT == 0: generic runtime taps / dilation / alignment, one scalar load per (tap, frame).
+template <int COUT, int KT, int PAD>
+__global__ void __launch_bounds__(256) conv_small_kernel(const SmallParams p) {
+    constexpr int NQ = 4;
+    const int b = blockIdx.y;
+    const int n0 = (blockIdx.x * 256 + threadIdx.x) * NQ;
+    if (n0 >= p.Tout) return;
+    const float *xb = p.x + (long long)b * p.x_bs;
+    const float *mb = p.mask ? p.mask + (long long)b * p.Tin : nullptr;
+    const bool act_lrelu = (p.in_act == VS_IN_LRELU || p.in_act == VS_IN_LRELU_MASK);
+    const bool act_mask = (p.in_act >= VS_IN_MASK);
+    float acc[COUT][NQ];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[c][q] = 0.f;
+    if constexpr (KT > 0) {
+        // window = frames n0-4 .. n0+7 ; frame n0 + q + k - pad is window[q + k - pad + 4]
+        const bool okl = (n0 >= 4), okr = (n0 + 8 <= p.Tin);
+        const int nl = okl ? n0 - 4 : n0, nr = okr ? n0 + 4 : n0;
+        float mw[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) mw[i] = 1.f;
+        if (act_mask) {
+            const float4 a = *reinterpret_cast<const float4 *>(mb + nl), c4 = *reinterpret_cast<const float4 *>(mb + n0),
+                         d = *reinterpret_cast<const float4 *>(mb + nr);
+            mw[0] = a.x; mw[1] = a.y; mw[2] = a.z; mw[3] = a.w; mw[4] = c4.x; mw[5] = c4.y; mw[6] = c4.z; mw[7] = c4.w;
+            mw[8] = d.x; mw[9] = d.y; mw[10] = d.z; mw[11] = d.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mw[i] = okl ? mw[i] : 0.f; mw[8 + i] = okr ? mw[8 + i] : 0.f; }
+        for (int ci = 0; ci < p.Cin; ++ci) {
+            const float *xr = xb + (long long)ci * p.Tin;
+            const float4 a = *reinterpret_cast<const float4 *>(xr + nl), c4 = *reinterpret_cast<const float4 *>(xr + n0),
+                         d = *reinterpret_cast<const float4 *>(xr + nr);
+            float xw[12] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                float v = xw[i];
+                if (act_lrelu) v = lrelu(v);
+                xw[i] = v * mw[i];
+            }
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const float wv = (c < p.Cout) ? p.w[((long long)c * p.Cin + ci) * KT + k] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[c][q] += wv * xw[q + k - PAD + 4];
+                }
+            }
+        }
+    } else {
+        for (int ci = 0; ci < p.Cin; ++ci) {
+            const float *xr = xb + (long long)ci * p.Tin;
+            for (int k = 0; k < p.K; ++k) {
+                const int off = k * p.dil - p.pad;
+                float xv[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int n = n0 + q + off;
+                    const bool ok = (n >= 0 && n < p.Tin);
+                    float v = ok ? xr[n] : 0.f;
+                    if (act_lrelu) v = lrelu(v);
+                    if (act_mask) v *= ok ? mb[n] : 0.f;
+                    xv[q] = v;
+                }
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) {
+                    const float wv = (c < p.Cout) ? p.w[((long long)c * p.Cin + ci) * p.K + k] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[c][q] += wv * xv[q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        if (c < p.Cout) {
+            float bv = p.bias ? p.bias[c] : 0.f;
+            if (p.bias_b) bv += p.bias_b[(long long)b * p.bias_b_bs + c];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int n = n0 + q;
+                if (n < p.Tout) {
+                    float v = (acc[c][q] + bv) * p.scale;
+                    if (p.out_act == VS_OUT_TANH) v = tanhf(v);
+                    else if (p.out_act == VS_OUT_RELU) v = fmaxf(v, 0.f);
+                    if (p.out_mask) v *= mb[n];
+                    p.y[(long long)b * p.y_bs + (long long)c * p.Tout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// effective (weight-norm folded) weights in the reference layout, for the VALU path
+__global__ void fold_weights_kernel(const float *__restrict__ w, const float *__restrict__ scale, float *__restrict__ out,
+                                    long long rows, long long cols) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) out[i] = scale ? w[i] * scale[i / cols] : w[i];
+}
+
 static inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 static inline int ceil_div_i(int a, int b) { return -floor_div(-a, b); }
 
@@ -637,7 +737,8 @@ struct vs_conv {
     unsigned flags;
     int M, MT, MT_alloc, KT, CP, nchunks, off0, tstep, lo, span, dmin, Hh;
     bool weights_set = false;
-    vs::DevBuf wp, biasp, scale;
+    vs::DevBuf wp, biasp, scale, weff, beff;   // weff/beff: unpacked effective weights (c_out <= 4 VALU path)
+    bool has_bias = false;
 };
 
 using namespace vs;
@@ -767,6 +868,17 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags;
     const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
+    if (h->kind == VS_CONV1D && h->c_out <= 4) {
+        const long long cols = (long long)h->c_in * h->k;
+        VS_TRY(h->weff.reserve((size_t)h->c_out * cols * sizeof(float)));
+        hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)ceil_div(h->c_out * cols, 256)), dim3(256), 0, s, w, scale,
+                           h->weff.as<float>(), (long long)h->c_out, cols);
+        h->has_bias = bias != nullptr;
+        if (bias) {
+            VS_TRY(h->beff.reserve((size_t)h->c_out * sizeof(float)));
+            VS_CHECK_HIP(hipMemcpyAsync(h->beff.p, bias, (size_t)h->c_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
     VS_CHECK_HIP(hipGetLastError());
     h->weights_set = true;
     return VS_OK;
@@ -799,8 +911,6 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     p.N = (h->kind == VS_CONV_TRANSPOSE1D) ? (int)ceil_div(Tout, h->dil) : (int)Tout;
     p.KT = h->KT; p.CP = h->CP; p.nchunks = h->nchunks;
     p.off0 = h->off0; p.tstep = h->tstep; p.lo = h->lo;
-    static const int stagger_env = getenv("VS_STAGGER") ? atoi(getenv("VS_STAGGER")) : 0;
-    p.stagger = stagger_env;
     p.stamps = g_stamp_buf;
     p.up = (h->kind == VS_CONV_TRANSPOSE1D) ? h->dil : 1;
     p.upK = h->k; p.uppad = h->pad; p.dmin = h->dmin;
@@ -838,6 +948,32 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     VS_REQUIRE(!need_mask || io->mask, "vs_conv_forward: mask required but NULL");
     VS_REQUIRE(Tout == io->T || !need_mask || h->kind != VS_CONV_TRANSPOSE1D, "mask with transposed conv unsupported");
     hipStream_t s = as_stream(stream);
+
+    if (h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT)) && !p.split_row &&
+        !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {
+        SmallParams q;
+        q.x = p.x; q.x_bs = p.x_bs; q.w = h->weff.as<float>(); q.bias = h->has_bias ? h->beff.as<float>() : nullptr;
+        q.bias_b = p.bias_b; q.bias_b_bs = p.bias_b_bs; q.mask = p.mask; q.y = p.out[0].y; q.y_bs = p.out[0].y_bs;
+        q.B = p.B; q.Cin = h->c_in; q.Cout = h->c_out; q.Tin = p.Tin; q.Tout = p.Tout; q.K = h->k; q.dil = h->dil;
+        q.pad = h->pad; q.in_act = p.in_act; q.out_act = p.out[0].out_act; q.out_mask = p.out[0].out_mask;
+        q.scale = p.out[0].scale;
+        dim3 grid((unsigned)ceil_div(p.Tout, 256 * 4), (unsigned)p.B);
+        auto al16 = [](const void *q2) { return (reinterpret_cast<uintptr_t>(q2) & 15u) == 0; };
+        const bool vec_ok = (p.Tin % 4 == 0) && (Tout == io->T) && al16(q.x) && (q.x_bs % 4 == 0) && (!q.mask || al16(q.mask));
+        const bool k7 = vec_ok && (h->k == 7 && h->dil == 1 && h->pad == 3), k1 = vec_ok && (h->k == 1 && h->pad == 0);
+#define VS_SMALL(CO)                                                                                       \
+        do {                                                                                               \
+            if (k7) hipLaunchKernelGGL((conv_small_kernel<CO, 7, 3>), grid, dim3(256), 0, s, q);           \
+            else if (k1) hipLaunchKernelGGL((conv_small_kernel<CO, 1, 0>), grid, dim3(256), 0, s, q);      \
+            else hipLaunchKernelGGL((conv_small_kernel<CO, 0, 0>), grid, dim3(256), 0, s, q);              \
+        } while (0)
+        if (h->c_out == 1) VS_SMALL(1);
+        else if (h->c_out == 2) VS_SMALL(2);
+        else VS_SMALL(4);
+#undef VS_SMALL
+        VS_CHECK_HIP(hipGetLastError());
+        return VS_OK;
+    }
 
     if (h->kind == VS_CONV1D_PAIRED) {
         p.row_lo = 0;

@@ -70,6 +70,8 @@ class ConvOp:
         if self.kind == L.CONV1D_PAIRED:
             mt = 2 * -(-(self.c_out // 2) // 32)
             return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
+        if self.kind == L.CONV1D and self.c_out <= 4:
+            return "conv_small_kernel"
         rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
         mt = -(-rows // 32)
         return "conv_mfma_kernel<1,8,4,1>" if mt >= 3 else ("conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>")
