@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvisinger_hip.so")
+LIB_PATH = os.environ.get("VS_LIB") or os.path.join(_HERE, "csrc", "libvisinger_hip.so")   # VS_LIB: A/B builds
 
 VS_OK = 0
 # enum vs_conv_kind

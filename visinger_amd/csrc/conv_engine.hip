@@ -209,9 +209,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     // MT_W*NT_W MFMAs.  Software pipeline (hipcc builds none by itself):
     //   * A fragments (packed weights, L2-resident): 3-deep register ring rotated by NAME (the step loop is unrolled
     //     by 3; a rotating copy would read the slot being prefetched); the slot of step s+2 is requested at step s;
-    //   * activations of chunk c+1 (HBM latency): requested at the first tap of chunk c, right AFTER that step's A
-    //     prefetch (vmcnt retires in issue order: whatever is issued behind them completes behind them), written to
-    //     the other LDS buffer after the last tap;
+    //   * activations: chunk c+2 is requested at the first tap of chunk c, right AFTER that step's A prefetch (vmcnt
+    //     retires in issue order: whatever is issued behind them completes behind them) and stays in registers for a
+    //     whole chunk; chunk c+1 is written to the other LDS buffer at the same point;
     //   * B fragments of group g+1 are read from LDS under the MFMAs of group g, pinned above them by sched_barrier
     //     (left alone hipcc sinks each ds_read next to its consumer: ds_read2 -> lgkmcnt(0) -> 2 MFMA).
     // Tried and measured worse (tools/conv_stamps.py, per-step shader cycles): inline-asm ring loads with hand-counted
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     stamp(p, 0);
     stage_load(0);
     stage_store(buf0, 0);
+    if (p.nchunks > 1) stage_load(1);      // lives in registers during chunk 0
     __syncthreads();
     stamp(p, 1);
 
@@ -247,7 +248,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         const float *cur = (chunk & 1) ? buf1 : buf0;
         const bool more = (chunk + 1 < p.nchunks);
         if (s + 2 < nsteps) { load_a(apre, pc, pt); advance(); }
-        if (tap == tap_b && more) stage_load(chunk + 1);
+        if (tap == tap_b) {
+            // chunk c+1 (requested one whole chunk ago) goes to the other LDS buffer, which every wave finished reading
+            // at the barrier that ended chunk c-1; then chunk c+2 is requested: a full chunk of MFMAs hides its latency
+            // whatever the tap count (with the request at the first tap and the store at the last one, a 1-tap conv
+            // waited for HBM in every step)
+            if (more) stage_store((chunk & 1) ? buf0 : buf1, chunk + 1);
+            if (chunk + 2 < p.nchunks) stage_load(chunk + 2);
+        }
 
         const float *xs = cur + lhalf * W + wn * (NT_W * 32) + l31 - p.lo + (p.off0 + tap * p.tstep);
         float bf[NT_W], bn[NT_W];
@@ -270,7 +278,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
             for (int j = 0; j < NT_W; ++j) bf[j] = bn[j];
         }
         if (++tap == tap_e) {
-            if (more) stage_store((chunk & 1) ? buf0 : buf1, chunk + 1);
             __syncthreads();
             tap = tap_b;
             ++chunk;
@@ -993,12 +1000,22 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         ok = ok && (!p.mask || al16(p.mask)) && (!p.split_row || p.split_row % 32 == 0);
         p.fast_epi = ok ? 1 : 0;
     }
+    // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,
+    // coupling `pre` and last res/skip convs) AND the launch is short (T_mel-sized): there 64 x 256 blocks waste no MFMA
+    // rows and give 1.5x the workgroups (a 256-workgroup launch fills only one slot per CU)
+    int cfg;   // 0: <1,8,4,1> 128x256   1: <1,8,2,2> 64x512   2: <1,4,1,4> 32x512   3: <1,4,2,2> 64x256
+    if (h->MT >= 3) cfg = ((h->MT % 4) == 2 && (long long)p.N * p.B <= 65536) ? 3 : 0;
+    else cfg = (h->MT == 2) ? 1 : 2;
+    if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : 0) : cfg;
     auto launch = [&](const ConvParams &q) -> int {
-        if (h->MT >= 3) return launch_cfg<1, 8, 4, 1>(q, s);
-        if (h->MT == 2) return launch_cfg<1, 8, 2, 2>(q, s);
-        return launch_cfg<1, 4, 1, 4>(q, s);
+        switch (cfg) {
+            case 0: return launch_cfg<1, 8, 4, 1>(q, s);
+            case 1: return launch_cfg<1, 8, 2, 2>(q, s);
+            case 3: return launch_cfg<1, 4, 2, 2>(q, s);
+            default: return launch_cfg<1, 4, 1, 4>(q, s);
+        }
     };
-    p.W = ((h->MT >= 3) ? 256 : 512) + h->span;
+    p.W = ((cfg == 0 || cfg == 3) ? 256 : 512) + h->span;
     p.row_lo = 0;
     p.row_hi = h->c_out;
     if (p.split_row && (p.split_row % 32) != 0) {

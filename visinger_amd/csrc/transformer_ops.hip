@@ -35,9 +35,15 @@ struct AttnParams {
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// DT = number of 32-wide tiles of the head dimension (dk <= 32*DT)
+// DT = number of 32-wide tiles of the head dimension (dk <= 32*DT).
+// One workgroup = 4 waves = 4 query tiles of 32 rows of one (batch, head); the K/V tiles of 32 keys are shared through
+// LDS, double-buffered: the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other
+// buffer after them (one barrier per tile).  The pre-scaled query tile lives in registers (it is the B operand of every
+// S^T MFMA), which keeps the LDS footprint at 74 KB for dk = 96 -> two workgroups per CU.
 template <int DT>
-__global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
+    constexpr int DKR = DT * 32;                   // padded head dim (rows of the K / V tiles in LDS)
+    constexpr int KPT = DKR * 32 / 256;            // K (and V) tile elements staged per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,16 +51,14 @@ __global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int i0 = (blockIdx.x * 4 + wave) * 32;
     const int dk = p.dk, T = p.T;
-    const int dkp = (dk + 1) & ~1;
     const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
 
-    float *Qs = smem;                              // [4][dkp][32]
-    float *QRs = Qs + 4 * dkp * 32;                // [4][32][ATT_QRS]   rel-key logits, later unused
+    float *Ks = smem;                              // [2][DKR][32]
+    float *Vs = Ks + 2 * DKR * 32;                 // [2][DKR][33]
+    float *Ms = Vs + 2 * DKR * 33;                 // [2][32]   key mask of the tile
+    float *QRs = Ms + 64;                          // [4][32][ATT_QRS]   rel-key logits
     float *Sws = QRs + 4 * 32 * ATT_QRS;           // [4][32][ATT_QRS]   in-window raw scores
-    float *Ks = Sws + 4 * 32 * ATT_QRS;            // [dkp][32]
-    float *Vs = Ks + dkp * 32;                     // [DT*32][33]
-    float *Ms = Vs + DT * 32 * 33;                 // [32] key mask of the tile
-    float *RVs = Ms + 32;                          // [ATT_MAXREL][dk] relative value embeddings
+    float *RVs = Sws + 4 * 32 * ATT_QRS;           // [ATT_MAXREL][dk] relative value embeddings
 
     const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
     const float *kb = p.k + (long long)b * p.bs + (long long)h * dk * T;
@@ -63,36 +67,66 @@ __global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
     const float *relk = nrel ? p.rel_k + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
     const float *relv = nrel ? p.rel_v + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
 
-    // ---- stage this wave's query tile (pre-scaled by 1/sqrt(dk)) and the relative value table ----
-    float *Qw = Qs + wave * dkp * 32;
-    for (int e = lane; e < dkp * 32; e += 64) {
-        const int d = e >> 5, i = e & 31;
-        float v = 0.f;
-        if (d < dk && i0 + i < T) v = qb[(long long)d * T + i0 + i] * p.scale;
-        Qw[e] = v;
+    // ---- this lane's slice of the query tile, pre-scaled: B operand of S^T = K^T Q is Q[d = 2kk+half][i = l31] ----
+    const int qi = i0 + l31;                       // this lane's query
+    const int qic = min(qi, T - 1);
+    float qreg[DT * 16];
+#pragma unroll
+    for (int kk = 0; kk < DT * 16; ++kk) {
+        const int d = 2 * kk + half;
+        const float v = qb[(long long)min(d, dk - 1) * T + qic];
+        qreg[kk] = (d < dk && qi < T) ? v * p.scale : 0.f;
     }
     for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
     for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
-    __syncthreads();
     if (nrel) {
-        // QR[i][r] = (q_i * scale) . rel_k[r];  half 0 -> r in [0,8), half 1 -> r in [8,16)
-        float qr[8];
+        // QR[i][r] = (q_i * scale) . rel_k[r]: each lane holds half of the d's -> partial dots, summed across halves
+        float qr[ATT_MAXREL];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) qr[r] = 0.f;
-        for (int d = 0; d < dk; ++d) {
-            const float qv = Qw[d * 32 + l31];
+        for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int rr = half * 8 + r;
-                const float kvv = (rr < nrel) ? relk[rr * dk + d] : 0.f;
-                qr[r] += qv * kvv;
-            }
+        for (int kk = 0; kk < DT * 16; ++kk) {
+            const int d = min(2 * kk + half, dk - 1);      // qreg is 0 beyond dk
+#pragma unroll
+            for (int r = 0; r < ATT_MAXREL; ++r)
+                if (r < nrel) qr[r] += qreg[kk] * relk[r * dk + d];
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) QRw[l31 * ATT_QRS + half * 8 + r] = qr[r];
+        for (int r = 0; r < ATT_MAXREL; ++r) {
+            const float tot = qr[r] + __shfl_xor(qr[r], 32);
+            if (half == 0) QRw[l31 * ATT_QRS + r] = tot;
+        }
     }
+
+    // ---- K/V tile staging (registers -> LDS), thread t owns elements e = t + 256*i of the [DKR][32] tile ----
+    float kst[KPT], vst[KPT], mst = 1.f;
+    auto tile_load = [&](int jt) __attribute__((always_inline)) {
+        const int j0 = jt * 32;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int e = tid + 256 * i;
+            const int d = e >> 5, jj = e & 31;
+            const long long off = (long long)min(d, dk - 1) * T + min(j0 + jj, T - 1);
+            kst[i] = kb[off];
+            vst[i] = vb[off];
+        }
+        if (tid < 32) mst = maskb ? maskb[min(j0 + tid, T - 1)] : 1.f;
+    };
+    auto tile_store = [&](int jt, int buf) __attribute__((always_inline)) {
+        const int j0 = jt * 32;
+        float *Kb = Ks + buf * DKR * 32, *Vb = Vs + buf * DKR * 33;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int e = tid + 256 * i;
+            const int d = e >> 5, jj = e & 31;
+            const bool ok = (d < dk) && (j0 + jj < T);
+            Kb[e] = ok ? kst[i] : 0.f;
+            Vb[d * 33 + jj] = ok ? vst[i] : 0.f;
+        }
+        if (tid < 32) Ms[buf * 32 + tid] = (j0 + tid < T) ? mst : 1.f;
+    };
 
     f32x16 o[DT];
 #pragma unroll
@@ -100,34 +134,26 @@ __global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_half = 0.f;
-    const int qi = i0 + l31;                      // this lane's query
     const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
 
     const int ntiles = (T + 31) / 32;
+    tile_load(0);
+    tile_store(0, 0);
+    __syncthreads();
     for (int jt = 0; jt < ntiles; ++jt) {
         const int j0 = jt * 32;
-        __syncthreads();                          // previous tile fully consumed
-        for (int e = tid; e < dkp * 32; e += 256) {
-            const int d = e >> 5, jj = e & 31;
-            const bool ok = (d < dk) && (j0 + jj < T);
-            Ks[e] = ok ? kb[(long long)d * T + j0 + jj] : 0.f;
-        }
-        for (int e = tid; e < DT * 32 * 32; e += 256) {
-            const int d = e >> 5, jj = e & 31;
-            const bool ok = (d < dk) && (j0 + jj < T);
-            Vs[d * 33 + jj] = ok ? vb[(long long)d * T + j0 + jj] : 0.f;
-        }
-        if (tid < 32) Ms[tid] = (maskb && j0 + tid < T) ? maskb[j0 + tid] : 1.f;
-        __syncthreads();
+        const int buf = jt & 1;
+        const float *Kb = Ks + buf * DKR * 32, *Vb = Vs + buf * DKR * 33, *Mb = Ms + buf * 32;
+        if (jt + 1 < ntiles) tile_load(jt + 1);
 
         // ---- S^T tile: rows = keys, cols (lanes) = queries ----
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        for (int kk = 0; kk < dkp / 2; ++kk) {
-            const float a = Ks[(2 * kk + half) * 32 + l31];
-            const float bq = Qw[(2 * kk + half) * 32 + l31];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, s, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < DT * 16; ++kk) {
+            const float a = Kb[(2 * kk + half) * 32 + l31];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[kk], s, 0, 0, 0);
         }
         const bool near_diag = nrel && (j0 + 31 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
         float tmax = -INFINITY;
@@ -140,7 +166,7 @@ __global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
                 const int rel = j - qi;
                 if (rel >= -p.ws && rel <= p.ws) sv += QRw[l31 * ATT_QRS + rel + p.ws];
             }
-            if (mi * Ms[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
+            if (mi * Mb[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
             if (j >= T) sv = -INFINITY;                  // beyond the sequence: not part of the softmax
             if (near_diag) {
                 const int rel = j - qi;
@@ -172,17 +198,18 @@ __global__ void __launch_bounds__(256) relattn_kernel(const AttnParams p) {
             const int jj = acc_row(ks, half);
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
-                const float a = Vs[(t * 32 + l31) * 33 + jj];
+                const float a = Vb[(t * 32 + l31) * 33 + jj];
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[ks], o[t], 0, 0, 0);
             }
         }
+        if (jt + 1 < ntiles) tile_store(jt + 1, buf ^ 1);
+        __syncthreads();
     }
 
     // ---- finish: normalise, add the relative-value term, store ----
     const float l_tot = l_half + __shfl_xor(l_half, 32);
     const float inv = 1.0f / l_tot;
     float pw[ATT_MAXREL];
-    __syncthreads();   // Sww written by both halves of this wave (same wave: program order suffices, keep simple)
 #pragma unroll
     for (int r = 0; r < ATT_MAXREL; ++r) pw[r] = (r < nrel) ? expf(Sww[l31 * ATT_QRS + r] - m_run) * inv : 0.f;
     float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
@@ -278,9 +305,8 @@ using namespace vs;
 
 template <int DT>
 static int launch_attn(const AttnParams &p, hipStream_t s) {
-    const int dkp = (p.dk + 1) & ~1;
-    const size_t lds = sizeof(float) * ((size_t)4 * dkp * 32 + 2 * 4 * 32 * ATT_QRS + (size_t)dkp * 32 + (size_t)DT * 32 * 33 +
-                                        32 + (size_t)ATT_MAXREL * p.dk);
+    const size_t lds = sizeof(float) * ((size_t)2 * DT * 32 * 32 + (size_t)2 * DT * 32 * 33 + 64 + 2 * 4 * 32 * ATT_QRS +
+                                        (size_t)ATT_MAXREL * p.dk);
     auto kern = relattn_kernel<DT>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -74,7 +74,9 @@ class ConvOp:
             return "conv_small_kernel"
         rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
         mt = -(-rows // 32)
-        return "conv_mfma_kernel<1,8,4,1>" if mt >= 3 else ("conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>")
+        if mt >= 3:
+            return "conv_mfma_kernel<1,8,4,1>"      # (or <1,4,2,2> for short 6-tile launches; same family)
+        return "conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>"
 
     def algorithmic_flops(self, B, T):
         """2*MAC of the convolution itself (what torch.utils.flop_counter reports for the reference's op)."""
