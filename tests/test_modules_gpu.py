@@ -230,3 +230,26 @@ def test_forward_only_guard_is_loud():
     m = WaveNet(16, 5, 1, 2).cuda().train()
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 16, 8, device="cuda"), torch.ones(1, 1, 8, device="cuda"))
+
+
+def test_index_ops_random_large(oracle):
+    """vs_expand_states / vs_make_positions / vs_slice_segments at the north-star size vs the numpy oracle: bit-exact."""
+    from visinger_amd.ops import expand_states, make_positions, slice_segments
+    r = np.random.default_rng(5)
+    B, Tp, T, H = 32, 128, 1024, 192
+    h = r.standard_normal((B, Tp, H)).astype(np.float32)
+    m2p = r.integers(0, Tp + 1, (B, T)).astype(np.int64)
+    m2p[3, 700:] = 0
+    m2p[0, :] = 0                                                     # an all-padding item
+    ref = oracle.expand_states(h, m2p)
+    assert np.array_equal(expand_states(cu(h), cu(m2p)).cpu().numpy(), ref)
+    got_cf = expand_states(cu(np.ascontiguousarray(h.transpose(0, 2, 1))), cu(m2p), h_channels_first=True, out_channels_first=True)
+    assert np.array_equal(got_cf.cpu().numpy(), ref.transpose(0, 2, 1))
+    x = r.standard_normal((B, T)).astype(np.float32)
+    x[r.random((B, T)) < 0.3] = 0.0
+    x[1, :] = 0.0
+    assert np.array_equal(make_positions(cu(x), 0).cpu().numpy(), oracle.make_positions(x, 0))
+    z = r.standard_normal((B, 192, T)).astype(np.float32)
+    ids = r.integers(0, T - 32 + 1, (B,)).astype(np.int64)
+    ids[0], ids[1] = 0, T - 32
+    assert np.array_equal(slice_segments(cu(z), cu(ids), 32).cpu().numpy(), oracle.slice_segments(z, ids, 32))

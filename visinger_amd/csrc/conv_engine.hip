@@ -1006,7 +1006,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     int cfg;   // 0: <1,8,4,1> 128x256   1: <1,8,2,2> 64x512   2: <1,4,1,4> 32x512   3: <1,4,2,2> 64x256
     if (h->MT >= 3) cfg = ((h->MT % 4) == 2 && (long long)p.N * p.B <= 65536) ? 3 : 0;
     else cfg = (h->MT == 2) ? 1 : 2;
-    if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : 0) : cfg;
+    if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : 0) : cfg;   // A/B switch
     auto launch = [&](const ConvParams &q) -> int {
         switch (cfg) {
             case 0: return launch_cfg<1, 8, 4, 1>(q, s);

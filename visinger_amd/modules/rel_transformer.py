@@ -71,8 +71,8 @@ class SinusoidalPositionalEmbedding(nn.Module):
         return emb
 
     def make_positions(tensor, padding_idx):
-        mask = tensor.ne(padding_idx).int()
-        return (torch.cumsum(mask, dim=1).type_as(mask) * mask).long() + padding_idx
+        from ..ops import make_positions as _make_positions_hip
+        return _make_positions_hip(tensor, padding_idx)
 
     def forward(self, bsz, seq_len, input):
         max_pos = self.padding_idx + 1 + seq_len

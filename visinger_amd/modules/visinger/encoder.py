@@ -8,7 +8,8 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
-from ...models.commons.align_ops import expand_states
+from ...models.commons.align_ops import expand_states  # noqa: F401  (re-exported like the reference module)
+from ...ops import expand_states as _expand_states_hip
 from ..commons.utils import Embedding
 from ..hipconv import HipConv1d, mask2d, _forward_only_guard
 from ..rel_transformer import RelativeEncoder, SinusoidalPositionalEmbedding
@@ -168,9 +169,9 @@ class TextEncoder(nn.Module):
     def forward(self, text_tokens, pitch_tokens, dur_tokens, mel2ph):
         tgt_nonpadding = (text_tokens > 0).float().unsqueeze(1)
         token_emb = self.forward_text_embedding(text_tokens, pitch_tokens, dur_tokens, tgt_nonpadding.transpose(1, 2))
-        enc_out = self.text_encoder(token_emb.transpose(1, 2), tgt_nonpadding)
-        enc_out = expand_states(enc_out.transpose(1, 2), mel2ph)
-        return enc_out.transpose(1, 2)
+        enc_out = self.text_encoder(token_emb.transpose(1, 2), tgt_nonpadding)       # [B, H, T_ph]
+        # expand_states(enc_out.transpose(1, 2), mel2ph).transpose(1, 2) without the two transposes (encoder.py:39-40)
+        return _expand_states_hip(enc_out, mel2ph, h_channels_first=True, out_channels_first=True)
 
     def forward_text_embedding(self, text_tokens, pitch_tokens, dur_tokens, nonpadding):
         # T_ph-sized glue (embedding lookups + one Linear): plain PyTorch-ROCm ops, negligible next to the encoder

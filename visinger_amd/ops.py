@@ -187,3 +187,43 @@ def layernorm_c(a, gamma, beta, r=None, g=None, mask=None, eps=1e-4, out=None):
     L.check(lib.vs_layernorm_c_fwd(L.ptr(a), L.ptr(r), L.ptr(gamma.detach().contiguous()), L.ptr(beta.detach().contiguous()),
                                    L.ptr(g), g_bs, g_ts, L.ptr(mask), L.ptr(out), B, C, T, eps, L.stream_ptr()))
     return out
+
+
+def _i64ptr(t):
+    if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+        raise L.VisingerHipError("expected a contiguous int64 tensor on the GPU")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def expand_states(h, mel2token, h_channels_first=False, out_channels_first=False):
+    """a9: frame expansion by the 1-based mel2token index (0 = padding -> zeros)."""
+    lib = L.require_gpu()
+    h = h.contiguous().float()
+    B = h.shape[0]
+    Tp, C = (h.shape[2], h.shape[1]) if h_channels_first else (h.shape[1], h.shape[2])
+    T = mel2token.shape[1]
+    out = torch.empty((B, C, T) if out_channels_first else (B, T, C), device=h.device, dtype=torch.float32)
+    L.check(lib.vs_expand_states(L.ptr(h), _i64ptr(mel2token.contiguous()), L.ptr(out), B, Tp, T, C, int(h_channels_first),
+                                 int(out_channels_first), L.stream_ptr()))
+    return out
+
+
+def make_positions(x, padding_idx):
+    """a9: cumsum(x != pad) * (x != pad) + pad as int64, x: [B, T] fp32."""
+    lib = L.require_gpu()
+    x = x.contiguous().float()
+    B, T = x.shape
+    pos = torch.empty((B, T), device=x.device, dtype=torch.int64)
+    L.check(lib.vs_make_positions(L.ptr(x), ctypes.c_void_p(pos.data_ptr()), B, T, int(padding_idx), L.stream_ptr()))
+    return pos
+
+
+def slice_segments(x, ids_str, segment_size):
+    """a9: out[b, :, s] = x[b, :, ids_str[b] + s]."""
+    lib = L.require_gpu()
+    x = x.contiguous().float()
+    B, C, T = x.shape
+    ids = ids_str.to(device=x.device, dtype=torch.int64).contiguous()
+    out = torch.empty((B, C, segment_size), device=x.device, dtype=torch.float32)
+    L.check(lib.vs_slice_segments(L.ptr(x), _i64ptr(ids), L.ptr(out), B, C, T, segment_size, L.stream_ptr()))
+    return out
