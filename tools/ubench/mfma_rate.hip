@@ -77,19 +77,27 @@ __global__ void __launch_bounds__(256, 2) k2(const float* in, float* out, long l
     const float* xs0 = lds + (lane >> 5) * 512 + (lane & 31);
     int s = 0;
     const int nsteps = iters;
+    float bf[8];
     auto step = [&](float (&ac)[8], float (&ap)[8]) __attribute__((always_inline)) {
-        int younger = (s + 1 < nsteps) ? 8 : 0;
-        if (s + 2 < nsteps) { la(ap, s + 2); younger += 8; }
-        if (younger >= 16) wv<16>(ac); else if (younger >= 8) wv<8>(ac); else wv<0>(ac);
+        if (VARIANT & 1) {
+            int younger = (s + 1 < nsteps) ? 8 : 0;
+            if (s + 2 < nsteps) { la(ap, s + 2); younger += 8; }
+            if (younger >= 16) wv<16>(ac); else if (younger >= 8) wv<8>(ac); else wv<0>(ac);
+        }
         const float* xs = xs0 + (s & 1) * 32;
-        float bf[8], bn[8];
+        float bn[8];
+        if (!(VARIANT & 4) || s == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bf[j] = xs[j * 32];
+            for (int j = 0; j < 8; ++j) bf[j] = xs[j * 32];
+        }
 #pragma unroll
         for (int cp = 0; cp < 8; ++cp) {
             if (cp + 1 < 8) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bn[j] = xs[(cp + 1) * 1024 + j * 32];
+            } else if (VARIANT & 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bn[j] = xs0[((s + 1) & 1) * 32 + j * 32];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -98,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) k2(const float* in, float* out, long l
 #pragma unroll
             for (int j = 0; j < 8; ++j) bf[j] = bn[j];
         }
-        if (VARIANT >= 3 && (s % 3) == 2) __syncthreads();
+        if ((VARIANT & 2) && (s % 3) == 2) __syncthreads();
         ++s;
     };
     long long t0 = __builtin_amdgcn_s_memtime();
@@ -150,8 +158,11 @@ int main() {
     run<0>("regs only, 2 wg/CU", 512, in, out, cyc);
     run<1>("lds prefetch, 1 wg/CU", 256, in, out, cyc);
     run<1>("lds prefetch, 2 wg/CU", 512, in, out, cyc);
-    run2<2>("step ring asm, 1 wg/CU", 256, in, out, cyc);
-    run2<3>("step ring asm+barrier, 1 wg", 256, in, out, cyc);
-    run2<2>("step ring asm, 2 wg/CU", 512, in, out, cyc);
+    run2<0>("steps only (fixed A), 1 wg", 256, in, out, cyc);
+    run2<4>("steps, carried bf, 1 wg", 256, in, out, cyc);
+    run2<1>("steps + asm ring, 1 wg", 256, in, out, cyc);
+    run2<5>("steps + asm ring + carried bf", 256, in, out, cyc);
+    run2<7>("  ... + barrier/3 steps", 256, in, out, cyc);
+    run2<5>("steps + asm ring + carried, 2wg", 512, in, out, cyc);
     return 0;
 }
