@@ -137,3 +137,32 @@ def test_north_star_shape_properties():
     # x0 halves pass through unmasked, x1 halves are masked by every coupling (flow.py:78,83)
     assert float(((xr - x) * mask).abs().max()) <= 2e-4
     assert torch.equal(y[7:9], y7), "batch items must be independent (utterance sharding is exact)"
+
+
+def test_batched_synthesis_driver_matches_single_items(tiny):
+    """Length-bucketed batching is exact: an utterance synthesised inside a padded batch equals the same utterance
+    synthesised alone (batch items are independent, padding is masked) -- what makes the utterance shard exact."""
+    from visinger_amd import synth
+    m, a, hp, _ = tiny
+    hop = int(np.prod(hp["upsample_rates"]))
+    items = []
+    for b in range(2):
+        n = int((a["mel2ph"][b] > 0).sum())
+        nph = int((a["text"][b] > 0).sum())
+        items.append(dict(text_tokens=a["text"][b][:nph], pitch_tokens=a["pitch"][b][:nph], dur_tokens=a["dur"][b][:nph],
+                          mel2ph=a["mel2ph"][b][:n]))
+    assert synth.bucket_by_length([5, 9, 2, 9], 18) == [[1, 3], [0, 2]]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    both = synth.synthesize(m, items, hop, generator=g)
+    assert [len(w) for w in both] == [int((a["mel2ph"][b] > 0).sum()) * hop for b in range(2)]
+    # same noise for the longer item when run alone (it is first in its bucket, so it consumed the first draws)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    T0 = len(items[0]["mel2ph"])
+    noise = torch.randn((2, m.hidden_size, T0), device="cuda", generator=g)[:1]
+    batch = synth.collate(items[:1], "cuda")
+    with torch.no_grad():
+        alone = m(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"], spk_id=batch["spk_id"],
+                  infer=True, noise=noise)["wav_out"][0].cpu().numpy()
+    assert np.abs(alone - both[0]).max() <= 1e-6
+    pcm = synth.to_int16(both[0])
+    assert pcm.dtype == np.int16 and np.abs(pcm).max() == 32767

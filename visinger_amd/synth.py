@@ -1,0 +1,64 @@
+"""Batched synthesis driver: what the reference does one utterance at a time in
+``tasks/visinger.py:244-263`` (``test_step``) and ``inference/visinger.py:91-100``, done in length-bucketed batches on
+the MI355X-native model, plus the reference's wav normalisation (``utils/audio/io.py:8-15``: peak-normalise, scale to
+int16).  Host-side plumbing only."""
+import numpy as np
+import torch
+
+
+def bucket_by_length(lengths, max_frames_per_batch, max_items_per_batch=256):
+    """Sort by length (descending) and cut batches under a padded-frame budget (the reference's batch_by_size idea,
+    utils/commons/dataset_utils.py:181-191, without its dataset plumbing).  Returns lists of item indices."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    batches, cur = [], []
+    for i in order:
+        longest = int(lengths[cur[0]]) if cur else int(lengths[i])
+        if cur and (longest * (len(cur) + 1) > max_frames_per_batch or len(cur) >= max_items_per_batch):
+            batches.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def collate(items, device):
+    """items: dicts with int64 1-D arrays text_tokens, pitch_tokens, dur_tokens (T_ph) and mel2ph (T_mel); 0-padded."""
+    Tph = max(len(it["text_tokens"]) for it in items)
+    T = max(len(it["mel2ph"]) for it in items)
+    out = {k: torch.zeros((len(items), Tph if k != "mel2ph" else T), dtype=torch.long)
+           for k in ("text_tokens", "pitch_tokens", "dur_tokens", "mel2ph")}
+    for b, it in enumerate(items):
+        for k in out:
+            v = torch.as_tensor(np.asarray(it[k]), dtype=torch.long)
+            out[k][b, :len(v)] = v
+    out["spk_id"] = torch.as_tensor([int(it.get("spk_id", 0)) for it in items], dtype=torch.long)
+    return {k: v.to(device) for k, v in out.items()}
+
+
+def to_int16(wav, norm=True):
+    """utils/audio/io.py:8-15: optional peak normalisation, then * 32767 -> int16."""
+    wav = np.asarray(wav, dtype=np.float32)
+    if norm and wav.size:
+        peak = np.abs(wav).max()
+        if peak > 0:
+            wav = wav / peak
+    return (wav * 32767.0).astype(np.int16)
+
+
+@torch.no_grad()
+def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None):
+    """Run VISinger.forward(infer=True) over length-bucketed batches.  Returns a list of float32 waveforms trimmed to
+    each item's own length (frames * hop_size), in the input order."""
+    device = next(model.parameters()).device
+    lengths = [int((np.asarray(it["mel2ph"]) > 0).sum()) for it in items]
+    out = [None] * len(items)
+    for idx in bucket_by_length(lengths, max_frames_per_batch):
+        batch = collate([items[i] for i in idx], device)
+        B, T = batch["mel2ph"].shape
+        noise = torch.randn((B, model.hidden_size, T), device=device, generator=generator) * noise_scale
+        wav = model(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"],
+                    spk_id=batch["spk_id"], infer=True, noise=noise)["wav_out"].float().cpu().numpy()
+        for b, i in enumerate(idx):
+            out[i] = wav[b, :lengths[i] * hop_size].copy()
+    return out
