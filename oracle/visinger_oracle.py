@@ -104,6 +104,20 @@ def conv_transpose1d(x, w, bias=None, stride=1, padding=0, dtype=np.float64):
     return y
 
 
+def conv1d_sg(x, w, bias=None, stride=1, padding=0, groups=1, dtype=np.float64):
+    """Strided / grouped nn.Conv1d (discriminator.py:55-63); also serves the (k,1)-kernel Conv2d of DiscriminatorP
+    (discriminator.py:20-26) applied column by column."""
+    x, w, bias = _c(x, dtype), _c(w, dtype), _c(bias, dtype)
+    B, Cin, T = x.shape
+    Cout, cig, K = w.shape
+    assert Cin == cig * groups
+    Tout = (T + 2 * padding - K) // stride + 1
+    y = np.empty((B, Cout, Tout), dtype=dtype)
+    _lib(dtype).orc_conv1d_sg(_p(x), _p(w), _p(bias), _p(y), _i64(B), _i64(Cin), _i64(Cout), _i64(T), _i64(K), _i64(stride),
+                              _i64(padding), _i64(groups))
+    return y
+
+
 def layer_norm_c(x, gamma, beta, eps=1e-4, dtype=np.float64):
     """rel_transformer.py:24-42 (channel LayerNorm, biased variance, eps=1e-4)."""
     x, gamma, beta = _c(x, dtype), _c(gamma, dtype), _c(beta, dtype)
@@ -455,3 +469,48 @@ def visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk_id, noise, dtype=np.flo
     if return_all:
         return dict(prior=prior, mu_p=mu_p, logs_p=logs_p, z_p=z_p, z_q=z_q, wav_out=wav)
     return wav
+
+
+# ------------------------------------------------------------------------------------------------------------
+# discriminators (a13; BASELINE config 3 only)
+
+
+def discriminator_s(sd, x, dtype=np.float64):
+    """DiscriminatorS.forward, modules/discriminator.py:64-75 -> (flat logits, fmap list)."""
+    cfg = [(15, 1, 7, 1), (41, 4, 20, 4), (41, 4, 20, 16), (41, 4, 20, 64), (41, 4, 20, 256), (5, 1, 2, 1)]
+    fmap = []
+    x = _c(x, dtype)
+    for i, (k, st, pad, g) in enumerate(cfg):
+        x = leaky_relu(conv1d_sg(x, _get_w(sd, f"convs.{i}", dtype), sd[f"convs.{i}.bias"], st, pad, g, dtype=dtype))
+        fmap.append(x)
+    x = conv1d_sg(x, _get_w(sd, "conv_post", dtype), sd["conv_post.bias"], 1, 1, 1, dtype=dtype)
+    fmap.append(x)
+    return x.reshape(x.shape[0], -1), fmap
+
+
+def discriminator_p(sd, x, period, kernel_size=5, stride=3, dtype=np.float64):
+    """DiscriminatorP.forward, modules/discriminator.py:28-47: reflect-pad to a multiple of the period, view as
+    [B, 1, T/p, p], (k,1) convs along the first axis -> per column j a strided conv1d over x[:, :, j::p]."""
+    x = _c(x, dtype)
+    b, c, t = x.shape
+    if t % period != 0:
+        n_pad = period - (t % period)
+        x = np.pad(x, ((0, 0), (0, 0), (0, n_pad)), mode="reflect")
+        t += n_pad
+    x = x.reshape(b, c, t // period, period)
+    pad = get_padding(kernel_size, 1)
+
+    def conv2d_k1(x4, w, bias, st, pd):
+        B_, C_, H_, W_ = x4.shape
+        cols = np.ascontiguousarray(x4.transpose(0, 3, 1, 2)).reshape(B_ * W_, C_, H_)     # each column is a sequence
+        y = conv1d_sg(cols, w[:, :, :, 0], bias, st, pd, 1, dtype=dtype)
+        return np.ascontiguousarray(y.reshape(B_, W_, y.shape[1], y.shape[2]).transpose(0, 2, 3, 1))
+
+    fmap = []
+    for i in range(5):
+        st = stride if i < 4 else 1
+        x = leaky_relu(conv2d_k1(x, _get_w(sd, f"convs.{i}", dtype), sd[f"convs.{i}.bias"], st, pad))
+        fmap.append(x)
+    x = conv2d_k1(x, _get_w(sd, "conv_post", dtype), sd["conv_post.bias"], 1, 1)
+    fmap.append(x)
+    return x.reshape(b, -1), fmap

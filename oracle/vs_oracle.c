@@ -172,3 +172,31 @@ API void orc_rel_attention(const real *q, const real *k, const real *v, const re
         }
     }
 }
+
+/* Strided / grouped conv1d for the discriminators (modules/discriminator.py:20-27,55-63):
+ * y[b, co, t] = bias[co] + sum_{ci in group(co), k} w[co, ci_local, k] * x[b, ci, t*stride + k - pad]
+ * x: [B, Cin, T]   w: [Cout, Cin/groups, K]   y: [B, Cout, Tout],  Tout = (T + 2*pad - K) / stride + 1 */
+API void orc_conv1d_sg(const real *x, const real *w, const real *bias, real *y, int64_t B, int64_t Cin, int64_t Cout,
+                       int64_t T, int64_t K, int64_t stride, int64_t pad, int64_t groups) {
+    const int64_t Tout = (T + 2 * pad - K) / stride + 1;
+    const int64_t cig = Cin / groups, cog = Cout / groups;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        for (int64_t co = 0; co < Cout; ++co) {
+            const int64_t g = co / cog;
+            real *yr = y + (b * Cout + co) * Tout;
+            for (int64_t t = 0; t < Tout; ++t) {
+                real acc = bias ? bias[co] : (real)0;
+                for (int64_t cl = 0; cl < cig; ++cl) {
+                    const real *xr = x + (b * Cin + g * cig + cl) * T;
+                    const real *wr = w + (co * cig + cl) * K;
+                    for (int64_t k = 0; k < K; ++k) {
+                        const int64_t n = t * stride + k - pad;
+                        if (n >= 0 && n < T) acc += wr[k] * xr[n];
+                    }
+                }
+                yr[t] = acc;
+            }
+        }
+    }
+}

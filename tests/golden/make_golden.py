@@ -300,6 +300,28 @@ def gen_integer():
          pads=np.array([get_padding(k, d) for k in (3, 5, 7, 11) for d in (1, 3, 5)]))
 
 
+def gen_discriminators():
+    """modules/discriminator.py:13-75 + MultiPeriodDiscriminator models/visinger.py:138-158 (a13).  The channel widths
+    are hard-coded in the reference, so the fixture stores input/outputs and a SEED: the weights are re-created with
+    `randomize` on the identical architecture by the test (they would be 40 MB)."""
+    from modules.discriminator import DiscriminatorP, DiscriminatorS
+    y = rnd(71, 2, 1, 250) * 0.3
+    ds = randomize(DiscriminatorS().eval(), 72)
+    out, fmap = ds(y)
+    arrs = dict(y=y, s_logits=out, s_fmap_last=fmap[-1], s_fmap0=fmap[0], s_fmap3_sum=fmap[3].sum(), s_fmap3_abs=fmap[3].abs().sum())
+    for p_ in (2, 3, 11):
+        dp = randomize(DiscriminatorP(p_).eval(), 73 + p_)
+        out, fmap = dp(y)
+        arrs[f"p{p_}_logits"] = out
+        arrs[f"p{p_}_fmap0"] = fmap[0]
+        arrs[f"p{p_}_fmap_last"] = fmap[-1]
+    from models.visinger import MultiPeriodDiscriminator
+    mpd = MultiPeriodDiscriminator()
+    with open(os.path.join(OUT, "mpd_state_dict_manifest.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in mpd.state_dict().items()}, f, indent=0, sort_keys=True)
+    save("discriminators", **arrs)
+
+
 def gen_model():
     """State-dict manifest of the full-size reference model + a tiny end-to-end infer forward
     (use_pitch_embed=False: the shipped default raises in FramePriorNetwork)."""
@@ -362,4 +384,5 @@ if __name__ == "__main__":
     gen_transformer()
     gen_wrappers()
     gen_integer()
+    gen_discriminators()
     gen_model()

@@ -253,3 +253,21 @@ def test_index_ops_random_large(oracle):
     ids = r.integers(0, T - 32 + 1, (B,)).astype(np.int64)
     ids[0], ids[1] = 0, T - 32
     assert np.array_equal(slice_segments(cu(z), cu(ids), 32).cpu().numpy(), oracle.slice_segments(z, ids, 32))
+
+
+def test_discriminators_gpu():
+    """a13 on the GPU (PyTorch-ROCm ops, reference state-dict layout) vs the reference's golden outputs."""
+    from test_oracle_golden import _disc_weights
+    from visinger_amd.modules.discriminator import DiscriminatorP, DiscriminatorS
+    _, a = load_golden("discriminators")
+    m, _ = _disc_weights(DiscriminatorS, 72)
+    with torch.no_grad():
+        lt, ft = m.cuda()(cu(a["y"]))
+    close(lt, a["s_logits"], atol=1e-4)
+    close(ft[0], a["s_fmap0"], atol=1e-4)
+    for p in (2, 3, 11):
+        m, _ = _disc_weights(DiscriminatorP, 73 + p, p)
+        with torch.no_grad():
+            lt, ft = m.cuda()(cu(a["y"]))
+        close(lt, a[f"p{p}_logits"], atol=1e-4)
+        close(ft[-1], a[f"p{p}_fmap_last"], atol=1e-4)

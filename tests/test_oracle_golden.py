@@ -187,3 +187,49 @@ def test_visinger_tiny_infer(oracle):
     hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_hparams.json")))
     wav = oracle.visinger_infer(w, hp, a["text"], a["pitch"], a["dur"], a["mel2ph"], a["spk_id"], a["noise"])
     close(wav, a["wav_out"], atol=5e-5, rtol=1e-4)
+
+
+def _disc_weights(cls, seed, *args):
+    """The discriminator fixtures store a seed, not 40 MB of weights: re-create them with the generator script's
+    `randomize` recipe on our (state-dict identical) module."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    m = cls(*args)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("weight_g"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                fan = max(1, int(np.prod(p.shape[1:])))
+                p.copy_(torch.randn(p.shape, generator=g) / np.sqrt(fan))
+    return m.eval(), {k: v.detach().numpy() for k, v in m.state_dict().items()}
+
+
+def test_discriminators(oracle):
+    """a13: oracle restatement and our PyTorch-op modules vs the reference's golden outputs (CPU)."""
+    import torch
+    from visinger_amd.modules.discriminator import DiscriminatorP, DiscriminatorS
+    from visinger_amd.models.visinger import MultiPeriodDiscriminator
+    _, a = load_golden("discriminators")
+    m, sd = _disc_weights(DiscriminatorS, 72)
+    logits, fmap = oracle.discriminator_s(sd, a["y"])
+    close(logits, a["s_logits"], atol=5e-5)
+    close(fmap[0], a["s_fmap0"])
+    close(fmap[-1], a["s_fmap_last"], atol=5e-5)
+    with torch.no_grad():
+        lt, ft = m(torch.from_numpy(a["y"]))
+    close(lt.numpy(), a["s_logits"], atol=5e-5)
+    for p in (2, 3, 11):
+        m, sd = _disc_weights(DiscriminatorP, 73 + p, p)
+        logits, fmap = oracle.discriminator_p(sd, a["y"], p)
+        close(logits, a[f"p{p}_logits"], atol=5e-5)
+        close(fmap[0], a[f"p{p}_fmap0"])
+        close(fmap[-1], a[f"p{p}_fmap_last"], atol=5e-5)
+        with torch.no_grad():
+            lt, ft = m(torch.from_numpy(a["y"]))
+        close(lt.numpy(), a[f"p{p}_logits"], atol=5e-5)
+        close(ft[0].numpy(), a[f"p{p}_fmap0"])
+    man = json.load(open(os.path.join(GOLDEN, "mpd_state_dict_manifest.json")))
+    assert {k: list(v.shape) for k, v in MultiPeriodDiscriminator().state_dict().items()} == man

@@ -19,6 +19,7 @@ _ALIASES = {
     "modules.visinger.predictor": "visinger_amd.modules.visinger.predictor",
     "modules.rel_transformer": "visinger_amd.modules.rel_transformer",
     "modules.commons.utils": "visinger_amd.modules.commons.utils",
+    "modules.discriminator": "visinger_amd.modules.discriminator",
     "models.commons.align_ops": "visinger_amd.models.commons.align_ops",
 }
 

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from ..modules.commons.utils import Embedding, rand_slice_segments, slice_segments
+from ..modules.discriminator import DiscriminatorP, DiscriminatorS
 from ..modules.rel_transformer import SinusoidalPositionalEmbedding
 from ..modules.visinger.decoder import Generator
 from ..modules.visinger.encoder import TextEncoder, PosteriorEncoder, FramePriorNetwork
@@ -122,6 +123,28 @@ class VISinger(nn.Module):
             v = (uv == 0)
         f0 = (f0 * v).unsqueeze(1) * tgt_nonpadding
         return f0
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    """models/visinger.py:138-158: one scale discriminator + period discriminators (2, 3, 5, 7, 11) applied to the real
+    and the generated waveform."""
+
+    def __init__(self, use_spectral_norm=False):
+        super().__init__()
+        discs = [DiscriminatorS(use_spectral_norm=use_spectral_norm)]
+        discs += [DiscriminatorP(p, use_spectral_norm=use_spectral_norm) for p in (2, 3, 5, 7, 11)]
+        self.discriminators = nn.ModuleList(discs)
+
+    def forward(self, y, y_hat):
+        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
+        for d in self.discriminators:
+            y_d_r, fmap_r = d(y)
+            y_d_g, fmap_g = d(y_hat)
+            y_d_rs.append(y_d_r)
+            y_d_gs.append(y_d_g)
+            fmap_rs.append(fmap_r)
+            fmap_gs.append(fmap_g)
+        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
 
 
 # Hyper-parameters of config/models/visinger.yaml:8-45 (+ datasets/svs/csd/preprocess.yaml), as a plain dict.
