@@ -1,0 +1,50 @@
+"""Reference-format checkpoint round trip (legacy pickle, {'state_dict': {'model': ...}}) and shape/consistency checks
+of the spectrogram restatement (parity of the latter is unpinned: torchaudio is absent, see visinger_amd/audio.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    from visinger_amd import ckpt
+    from visinger_amd.models.visinger import VISinger
+    hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_hparams.json")))
+    m = VISinger(13, 9, 7, hp)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.8, 0.99), eps=1e-9)
+    p = ckpt.save_checkpoint(tmp_path / "model_ckpt_steps_1200.ckpt", {"model": m}, [opt], epoch=3, global_step=1200)
+    ckpt.save_checkpoint(tmp_path / "model_ckpt_steps_800.ckpt", {"model": m}, [opt], epoch=2, global_step=800)
+    assert not os.path.exists(str(p) + ".part")
+    with open(p, "rb") as f:
+        assert f.read(2) != b"PK", "the reference writes the legacy (non-zip) serialisation"
+    assert [os.path.basename(q) for q in ckpt.all_checkpoints(str(tmp_path))] == ["model_ckpt_steps_1200.ckpt",
+                                                                                  "model_ckpt_steps_800.ckpt"]
+    raw, path = ckpt.read_checkpoint(str(tmp_path))
+    assert set(raw) == {"epoch", "global_step", "checkpoint_callback_best", "optimizer_states", "state_dict"}
+    assert raw["global_step"] == 1200 and path.endswith("1200.ckpt")
+    m2 = VISinger(13, 9, 7, hp)
+    step, _ = ckpt.load_model(m2, str(tmp_path), child="model", strict=True)
+    assert step == 1200
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_spectrogram_shapes_and_energy():
+    from visinger_amd import audio
+    torch.manual_seed(0)
+    hop, T = 300, 37
+    wav = torch.randn(2, T * hop) * 0.1
+    lin = audio.linear_spectrogram(wav, 2048, 1200, hop)
+    assert lin.shape == (2, T, 1025) and (lin >= 0).all()          # T frames: center padding gives T+1, last dropped
+    mel = audio.mel_spectrogram(wav, 24000, 2048, 1200, hop, 128, 20.0, 12000.0)
+    assert mel.shape == (2, T, 128) and torch.isfinite(mel).all()
+    fb = audio.mel_filterbank(1025, 20.0, 12000.0, 128, 24000)
+    assert fb.shape == (1025, 128) and (fb >= 0).all() and (fb.sum(0) > 0).all()
+    # a pure tone lands in the bin torch.stft puts it in and in the matching mel band
+    t = torch.arange(24000) / 24000.0
+    tone = torch.sin(2 * np.pi * 3000.0 * t)[None]
+    lin = audio.linear_spectrogram(tone, 2048, 1200, hop)
+    assert abs(int(lin[0, 20].argmax()) - round(3000.0 / (24000 / 2048))) <= 1
