@@ -375,6 +375,32 @@ def gen_model():
     with open(os.path.join(OUT, "visinger_tiny_hparams.json"), "w") as f:
         json.dump(hp_t, f, sort_keys=True)
 
+    # ---- gradients of a scalar functional of the training forward, from the reference's own autograd --------------
+    torch.set_grad_enabled(True)
+    m.train()                                   # p_dropout = 0 in the tiny config: train == eval numerically
+    m.zero_grad()
+    torch.manual_seed(999)
+    with CaptureRandn() as cap:
+        out = m(text, pitch, dur, mel2ph, spk_id=spk_id, mel=lin, infer=False)
+    c_w, c_p, c_z = rnd(64, *out["wav_out"].shape), rnd(65, *out["ph_pred"].shape), rnd(66, *out["z_p"].shape)
+    loss = out["kl"] + 0.1 * (out["wav_out"] * c_w).sum() + 0.01 * (out["ph_pred"] * c_p).sum() + 0.01 * (out["z_p"] * c_z).sum()
+    loss.backward()
+    pick = ["decoder.conv_pre.weight", "decoder.ups.0.weight_v", "decoder.ups.1.weight_g",
+            "decoder.resblocks.0.convs1.0.weight_g", "decoder.resblocks.3.convs2.2.weight_v", "decoder.conv_post.weight",
+            "decoder.cond.weight", "flow.flows.0.post.weight", "flow.flows.2.enc.in_layers.1.weight_v",
+            "flow.flows.6.pre.bias", "posterior_encoder.enc.res_skip_layers.0.bias", "posterior_encoder.pre.weight",
+            "posterior_encoder.enc.cond_layer.weight_g", "frame_prior.encoder.attn_layers.0.emb_rel_k",
+            "frame_prior.encoder.attn_layers.1.emb_rel_v", "frame_prior.encoder.norm_layers_1.0.gamma",
+            "frame_prior.proj.weight", "text_encoder.ph_emb.weight", "text_encoder.linear.weight",
+            "text_encoder.text_encoder.ffn_layers.0.conv_1.weight", "text_encoder.text_encoder.attn_layers.1.conv_q.weight",
+            "phoneme_predictor.ph_proj.bias", "phoneme_predictor.phoneme_predictor.attn_layers.0.conv_o.weight",
+            "spk_id_proj.weight"]
+    named = dict(m.named_parameters())
+    grads = {"g." + k: named[k].grad.detach().clone() for k in pick}
+    save("visinger_tiny_grads", loss=loss.detach(), c_w=c_w, c_p=c_p, c_z=c_z, noise_q=cap.draws[0], u_slice=cap.uniform[0],
+         **grads)
+    torch.set_grad_enabled(False)
+
 
 if __name__ == "__main__":
     gen_wavenet()

@@ -1,0 +1,236 @@
+"""Training-mode (autograd) execution of the hot-path modules -- SURVEY.md 8f-1, first stage.
+
+Forward: every convolution still runs on the HIP conv engine (``HipConvFn``: the folded weight is re-packed each step
+because it changes each step); the elementwise neighbours that the inference path fuses into the conv epilogues
+(gates, residuals, masks, coupling updates, LayerNorm) and the attention core run as PyTorch-ROCm ops so that
+autograd records them.  Backward: PyTorch-ROCm ops throughout -- the conv backward recomputes the op with
+``torch.nn.functional`` under ``enable_grad`` and differentiates that (training throughput is not the benchmark
+metric; backward HIP kernels are the next stage).  The arithmetic restated here follows the same reference lines as the
+inference modules; `tests/test_train_gpu.py` checks train-mode forward == eval-mode (fused HIP) forward and the
+gradients against the reference's own autograd (golden vectors).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+LRELU_SLOPE = 0.1
+
+
+class HipConvFn(torch.autograd.Function):
+    """y = conv(x, w, b) with the forward on the HIP engine and the backward through torch.nn.functional."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, module):
+        x = x.contiguous().float()
+        op = module._op(bind=False)
+        op.set_weights(w.detach().contiguous(), None, None if b is None else b.detach())
+        y = op.forward(x)
+        ctx.module = module
+        ctx.save_for_backward(x, w, b if b is not None else x.new_empty(0))
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, b = ctx.saved_tensors
+        m = ctx.module
+        need = ctx.needs_input_grad
+        with torch.enable_grad():
+            x_ = x.detach().requires_grad_(need[0])
+            w_ = w.detach().requires_grad_(need[1])
+            b_ = b.detach().requires_grad_(need[2]) if ctx.has_bias else None
+            if m._kind == L.CONV_TRANSPOSE1D:
+                y = F.conv_transpose1d(x_, w_, b_, stride=m.stride, padding=m.padding)
+            else:
+                y = F.conv1d(x_, w_, b_, stride=1, padding=m.padding, dilation=m.dilation)
+            wanted = [t for t, n in ((x_, need[0]), (w_, need[1]), (b_, need[2] and ctx.has_bias)) if n]
+            grads = list(torch.autograd.grad(y, wanted, gy.contiguous())) if wanted else []
+        out = []
+        for n in (need[0], need[1], need[2] and ctx.has_bias):
+            out.append(grads.pop(0) if n else None)
+        return out[0], out[1], out[2], None
+
+
+def effective_weight(m):
+    """weight, or g * v / ||v|| (torch.nn.utils.weight_norm, dim 0) as a differentiable torch expression"""
+    if hasattr(m, "weight_g"):
+        return torch._weight_norm(m.weight_v, m.weight_g, 0)
+    return m.weight
+
+
+def conv(m, x):
+    """differentiable conv through HipConv1d / HipConvTranspose1d `m`"""
+    return HipConvFn.apply(x, effective_weight(m), m.bias, m)
+
+
+def training_path(module):
+    return module.training and torch.is_grad_enabled()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# module forwards (same reference lines as the inference modules)
+
+
+def wavenet(m, x, x_mask, g=None):
+    """encoder.py:167-195"""
+    H = m.hidden_channels
+    output = torch.zeros_like(x)
+    if g is not None:
+        g = conv(m.cond_layer, g)
+    for i in range(m.n_layers):
+        x_in = conv(m.in_layers[i], x)
+        if g is not None:
+            x_in = x_in + g[:, i * 2 * H:(i + 1) * 2 * H, :]
+        acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+        acts = m.drop(acts)
+        rs = conv(m.res_skip_layers[i], acts)
+        if i < m.n_layers - 1:
+            x = (x + rs[:, :H]) * x_mask
+            output = output + rs[:, H:]
+        else:
+            output = output + rs
+    return output * x_mask
+
+
+def coupling_layer(m, x, x_mask, g=None, reverse=False):
+    """flow.py:66-85"""
+    half = m.half_channels
+    x0, x1 = torch.split(x, [half, half], 1)
+    h = conv(m.pre, x0) * x_mask
+    h = wavenet(m.enc, h, x_mask, g)
+    stats = conv(m.post, h) * x_mask
+    if not m.mean_only:
+        mean, logs = torch.split(stats, [half, half], 1)
+    else:
+        mean, logs = stats, torch.zeros_like(stats)
+    if not reverse:
+        x1 = mean + x1 * torch.exp(logs) * x_mask
+        return torch.cat([x0, x1], 1), torch.sum(logs, [1, 2])
+    x1 = (x1 - mean) * torch.exp(-logs) * x_mask
+    return torch.cat([x0, x1], 1)
+
+
+def flow_block(m, x, x_mask, g=None, reverse=False):
+    """flow.py:33-40"""
+    if not reverse:
+        for f in range(m.n_flows):
+            x, _ = coupling_layer(m.flows[2 * f], x, x_mask, g, False)
+            x = torch.flip(x, [1])
+    else:
+        for f in reversed(range(m.n_flows)):
+            x = torch.flip(x, [1])
+            x = coupling_layer(m.flows[2 * f], x, x_mask, g, True)
+    return x
+
+
+def resblock1(m, x, x_mask=None):
+    """decoder.py:91-104"""
+    for c1, c2 in zip(m.convs1, m.convs2):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        if x_mask is not None:
+            xt = xt * x_mask
+        xt = conv(c1, xt)
+        xt = F.leaky_relu(xt, LRELU_SLOPE)
+        if x_mask is not None:
+            xt = xt * x_mask
+        xt = conv(c2, xt)
+        x = xt + x
+    return x if x_mask is None else x * x_mask
+
+
+def resblock2(m, x, x_mask=None):
+    """decoder.py:124-133"""
+    for c in m.convs:
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        if x_mask is not None:
+            xt = xt * x_mask
+        x = conv(c, xt) + x
+    return x if x_mask is None else x * x_mask
+
+
+def generator(m, x, g=None):
+    """decoder.py:40-59"""
+    x = conv(m.conv_pre, x)
+    if g is not None:
+        x = x + conv(m.cond, g)
+    for i in range(m.num_upsamples):
+        x = F.leaky_relu(x, LRELU_SLOPE)
+        x = conv(m.ups[i], x)
+        xs = None
+        for j in range(m.num_kernels):
+            rb = m.resblocks[i * m.num_kernels + j]
+            r = resblock1(rb, x) if hasattr(rb, "convs1") else resblock2(rb, x)
+            xs = r if xs is None else xs + r
+        x = xs / m.num_kernels
+    x = F.leaky_relu(x, LRELU_SLOPE)
+    return torch.tanh(conv(m.conv_post, x))
+
+
+def layer_norm(m, x):
+    """rel_transformer.py:33-42"""
+    mean = torch.mean(x, 1, keepdim=True)
+    var = torch.mean((x - mean) ** 2, 1, keepdim=True)
+    x = (x - mean) * torch.rsqrt(var + m.eps)
+    return x * m.gamma.view(1, -1, 1) + m.beta.view(1, -1, 1)
+
+
+def attention(m, x, frame_mask):
+    """rel_transformer.py:138-179: q/k/v/o convs on the HIP engine, the [T, T] core as differentiable torch ops.  The
+    relative terms are gathered from the (2w+1)-wide tables with the index map j - i + w (what the reference's
+    pad/reshape skew implements) instead of materialising the skewed copies."""
+    B, C, T = x.shape
+    nh, dk, w = m.n_heads, m.k_channels, m.window_size
+    q = conv(m.conv_q, x).view(B, nh, dk, T).transpose(2, 3)
+    k = conv(m.conv_k, x).view(B, nh, dk, T).transpose(2, 3)
+    v = conv(m.conv_v, x).view(B, nh, dk, T).transpose(2, 3)
+    scale = 1.0 / math.sqrt(dk)
+    scores = torch.matmul(q, k.transpose(-2, -1)) * scale
+    if w is not None:
+        idx = torch.arange(T, device=x.device)
+        rel = idx[None, :] - idx[:, None]                                   # j - i
+        band = (rel.abs() <= w)
+        ridx = (rel + w).clamp(0, 2 * w)                                    # [T, T]
+        qr = torch.matmul(q, m.emb_rel_k.unsqueeze(0).transpose(-2, -1))     # [B, nh, T, 2w+1]
+        bias = torch.gather(qr, 3, ridx[None, None].expand(B, nh, T, T)) * band
+        scores = scores + bias * scale
+    if frame_mask is not None:
+        am = frame_mask.view(B, 1, T, 1) * frame_mask.view(B, 1, 1, T)
+        scores = scores.masked_fill(am == 0, -1e4)
+    p = m.drop(F.softmax(scores, dim=-1))
+    out = torch.matmul(p, v)
+    if w is not None:
+        # relative weights p[i, i + r] for r in [-w, w] (zero outside the sequence) @ emb_rel_v
+        cols = (idx[:, None] + torch.arange(-w, w + 1, device=x.device)[None, :])       # [T, 2w+1]
+        ok = (cols >= 0) & (cols < T)
+        pw = torch.gather(p, 3, cols.clamp(0, T - 1)[None, None].expand(B, nh, T, 2 * w + 1)) * ok
+        out = out + torch.matmul(pw, m.emb_rel_v.unsqueeze(0))
+    out = out.transpose(2, 3).contiguous().view(B, C, T)
+    return conv(m.conv_o, out)
+
+
+def ffn(m, x, x_mask):
+    """rel_transformer.py:336-345"""
+    h = conv(m.conv_1, x * x_mask)
+    h = torch.relu(h) if m.activation != "gelu" else h * torch.sigmoid(1.702 * h)
+    h = m.dropout(h)
+    return conv(m.conv_2, h * x_mask)
+
+
+def rel_encoder(m, x, x_mask, g=None):
+    """rel_transformer.py:290-320 (post-LN)"""
+    B, C, T = x.shape
+    fm = x_mask.reshape(B, T)
+    if g is not None:
+        g = conv(m.pre_net, g)
+    for i in range(m.n_layers):
+        if g is not None:
+            x = x + g
+        x = x * x_mask
+        y = m.drop(attention(m.attn_layers[i], x, fm))
+        x = layer_norm(m.norm_layers_1[i], x + y)
+        y = m.drop(ffn(m.ffn_layers[i], x, x_mask))
+        x = layer_norm(m.norm_layers_2[i], x + y)
+    return x * x_mask

@@ -22,6 +22,9 @@ def sequence_mask(length, max_length=None):
 
 def slice_segments(x, ids_str, segment_size=4):
     """modules/commons/utils.py:86-92 -- one launch (vs_slice_segments) instead of a Python loop over the batch."""
+    if torch.is_grad_enabled() and x.requires_grad:      # training: differentiable gather (PyTorch-ROCm), same indexing
+        idx = ids_str.to(device=x.device, dtype=torch.long)[:, None] + torch.arange(segment_size, device=x.device)[None, :]
+        return torch.gather(x, 2, idx[:, None, :].expand(-1, x.size(1), -1))
     from ...ops import slice_segments as _slice_segments_hip
     return _slice_segments_hip(x, ids_str, segment_size)
 

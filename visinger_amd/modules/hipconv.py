@@ -5,8 +5,7 @@ They ARE torch.nn.Conv1d / ConvTranspose1d subclasses, so construction, default 
 ``state_dict`` keys are exactly the reference's; only the arithmetic moves to gfx950.  Parent modules call
 ``run(...)`` to fuse their elementwise neighbours (activation, mask, residual, gate, coupling) into the conv.
 
-Forward-only this round: the HIP kernels have no backward yet, so calling them in training mode with autograd
-enabled raises instead of silently returning tensors that cannot back-propagate.
+Training mode (autograd enabled) is served by visinger_amd.autograd: HIP forward for the convs, PyTorch-ROCm backward.
 """
 import torch
 import torch.nn as nn
@@ -16,10 +15,12 @@ from ..ops import ConvOp
 
 
 def _forward_only_guard(module):
+    """The fused inference kernels have no backward: reaching them in training mode with autograd on is a bug in the
+    dispatch (every module routes that case to visinger_amd.autograd first)."""
     if torch.is_grad_enabled() and module.training:
         raise NotImplementedError(
-            "visinger_amd HIP modules are forward-only in this release (no backward kernels yet): call .eval() "
-            "or wrap the call in torch.no_grad().")
+            "fused HIP inference path reached in training mode with autograd enabled; use the module's forward() "
+            "(which dispatches to visinger_amd.autograd) or call .eval() / torch.no_grad().")
 
 
 class _HipConvMixin:
@@ -30,8 +31,10 @@ class _HipConvMixin:
             return self.weight_v, self.weight_g
         return self.weight, None
 
-    def _op(self, kind=None, flags=0):
-        """ConvOp for (kind, flags); created lazily so that modules can be built/loaded without a GPU."""
+    def _op(self, kind=None, flags=0, bind=True):
+        """ConvOp for (kind, flags); created lazily so that modules can be built/loaded without a GPU.
+        bind=False returns the handle without (re)packing the module's parameters (the autograd path packs the live
+        folded weight itself)."""
         kind = self._kind if kind is None else kind
         ops = self.__dict__.setdefault("_hip_ops", {})
         key = (kind, flags)
@@ -44,8 +47,9 @@ class _HipConvMixin:
                 ops[key] = ConvOp(kind, self.in_channels, self.out_channels, self.kernel_size[0],
                                   self.dilation[0], self.padding[0], flags)
         op = ops[key]
-        w, g = self._weights()
-        op.set_weights(w, g, self.bias)
+        if bind:
+            w, g = self._weights()
+            op.set_weights(w, g, self.bias)
         return op
 
     def run(self, x, *, kind=None, flags=0, **kw):
@@ -54,6 +58,9 @@ class _HipConvMixin:
         return self._op(kind, flags).forward(x, **kw)
 
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            from ..autograd import conv
+            return conv(self, x)
         return self.run(x.contiguous().float())
 
     def __getstate__(self):                      # handles are process-local

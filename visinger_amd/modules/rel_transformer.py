@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
+from .. import autograd
 from ..ops import layernorm_c, rel_attention, _off
 from .hipconv import HipConv1d, mask2d, _forward_only_guard
 
@@ -40,6 +41,8 @@ class LayerNorm(nn.Module):
         self.beta = nn.Parameter(torch.zeros(channels))
 
     def forward(self, x):
+        if autograd.training_path(self):
+            return autograd.layer_norm(self, x)
         _forward_only_guard(self)
         shp = x.shape
         x3 = x.contiguous().float().reshape(shp[0], shp[1], -1)
@@ -124,15 +127,17 @@ class MultiHeadAttention(nn.Module):
         m[:, :, :, None] * m[:, :, None, :] from the frame mask m; the streaming kernel takes m itself (`frame_mask`
         [B, T]); a 4-D attn_mask is reduced back to m through its diagonal.  in_mask: multiply x by m while
         staging (fuses RelativeEncoder's `x = x * x_mask`)."""
-        _forward_only_guard(self)
         if self.proximal_bias or self.block_length is not None:
             raise NotImplementedError("proximal_bias / block_length are not used by VISinger and not implemented")
-        if self.training and self.p_dropout > 0:
-            raise NotImplementedError("attention dropout is not implemented (eval only)")
         assert x.shape == c.shape, "Relative attention is only available for self-attention."
         B, C, T = x.shape
         if frame_mask is None and attn_mask is not None:
             frame_mask = torch.diagonal(attn_mask.reshape(B, T, T), dim1=1, dim2=2)
+        if autograd.training_path(self):
+            assert c is x, "the training path implements self-attention"
+            return autograd.attention(self, x * frame_mask.reshape(B, 1, T) if (in_mask and frame_mask is not None) else x,
+                                      None if frame_mask is None else frame_mask.reshape(B, T).float())
+        _forward_only_guard(self)
         m2 = None if frame_mask is None else frame_mask.reshape(B, T).float().contiguous()
         x = x.contiguous().float()
         c = x if c is x else c.contiguous().float()
@@ -181,11 +186,11 @@ class RelativeEncoder(nn.Module):
             self.pre_net = HipConv1d(gin_channels, hidden_channels, 1)
 
     def forward(self, x, x_mask, g=None):
-        _forward_only_guard(self)
         if self.pre_ln:
             raise NotImplementedError("pre_ln=True is never used by VISinger (rel_transformer.py:281-282) and not implemented")
-        if self.training and self.p_dropout > 0:
-            raise NotImplementedError("dropout is not implemented in the fused encoder (eval only)")
+        if autograd.training_path(self):
+            return autograd.rel_encoder(self, x, x_mask.reshape(x.shape[0], 1, x.shape[2]), g)
+        _forward_only_guard(self)
         B, C, T = x.shape
         m2 = mask2d(x_mask, B, T)
         x = x.contiguous().float()
@@ -221,6 +226,8 @@ class FFN(nn.Module):
         self.dropout = nn.Dropout(p_dropout)
 
     def forward(self, x, x_mask):
+        if autograd.training_path(self):
+            return autograd.ffn(self, x, x_mask.reshape(x.shape[0], 1, x.shape[2]))
         _forward_only_guard(self)
         if self.activation == "gelu":
             raise NotImplementedError("FFN(activation='gelu') is never built by VISinger (rel_transformer.py:281-282)")

@@ -15,6 +15,7 @@ import torch.nn as nn
 from torch.nn.utils import weight_norm, remove_weight_norm
 
 from ... import _lib as L
+from ... import autograd
 from ..commons.utils import init_weights, get_padding
 from ..hipconv import HipConv1d, HipConvTranspose1d, mask2d, _forward_only_guard
 
@@ -51,6 +52,8 @@ class Generator(nn.Module):
             self.cond = HipConv1d(gin_channels, upsample_initial_channel, 1)
 
     def forward(self, x, g=None):
+        if autograd.training_path(self):
+            return autograd.generator(self, x, g)
         _forward_only_guard(self)
         x = x.contiguous().float()
         cb = None
@@ -106,6 +109,8 @@ class ResBlock1(torch.nn.Module):
         return out
 
     def forward(self, x, x_mask=None):
+        if autograd.training_path(self):
+            return autograd.resblock1(self, x, x_mask)
         _forward_only_guard(self)
         x = x.contiguous().float()
         B, _, T = x.shape
@@ -143,6 +148,8 @@ class ResBlock2(nn.Module):
         return out
 
     def forward(self, x, x_mask=None):
+        if autograd.training_path(self):
+            return autograd.resblock2(self, x, x_mask)
         _forward_only_guard(self)
         x = x.contiguous().float()
         B, _, T = x.shape

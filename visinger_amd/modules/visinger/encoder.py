@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from ... import autograd
 from ...models.commons.align_ops import expand_states  # noqa: F401  (re-exported like the reference module)
 from ...ops import expand_states as _expand_states_hip
 from ..commons.utils import Embedding
@@ -53,9 +54,9 @@ class WaveNet(torch.nn.Module):
             self.res_skip_layers.append(res_skip_layer)
 
     def forward(self, x, x_mask, g=None, **kwargs):
+        if autograd.training_path(self):
+            return autograd.wavenet(self, x, x_mask.reshape(x.shape[0], 1, x.shape[2]), g)
         _forward_only_guard(self)
-        if self.training and self.p_dropout > 0:
-            raise NotImplementedError("dropout inside the fused WaveNet is not implemented (eval / p_dropout=0 only)")
         B, H, T = x.shape
         x = x.contiguous().float()
         m2 = mask2d(x_mask, B, T)
@@ -112,6 +113,13 @@ class PosteriorEncoder(nn.Module):
 
     def forward(self, x, nonpadding, g=None, noise=None):
         """`noise` (optional, [B, out_channels, T]) replaces torch.randn_like(mu_q) for reproducible parity."""
+        if autograd.training_path(self):
+            h = autograd.conv(self.pre, x) * nonpadding
+            h = self.enc(h, nonpadding, g=g)
+            stats = autograd.conv(self.proj, h) * nonpadding
+            mu_q, logs_q = torch.split(stats, self.out_channels, dim=1)
+            noise = torch.randn_like(mu_q) if noise is None else noise
+            return (mu_q + noise * torch.exp(logs_q)) * nonpadding, mu_q, logs_q
         B, _, T = x.shape
         m2 = mask2d(nonpadding, B, T)
         h = self.pre.run(x.contiguous().float(), mask=m2, out_mask=True)
@@ -142,7 +150,10 @@ class FramePriorNetwork(nn.Module):
             g = g.transpose(1, 2)           # as the reference does (encoder.py:68-69)
         prior_out = self.encoder(x, x_mask, g)
         B, _, T = prior_out.shape
-        prior_out = self.proj.run(prior_out, mask=mask2d(x_mask, B, T), out_mask=True)
+        if autograd.training_path(self):
+            prior_out = autograd.conv(self.proj, prior_out) * x_mask
+        else:
+            prior_out = self.proj.run(prior_out, mask=mask2d(x_mask, B, T), out_mask=True)
         mu_p, logs_p = torch.split(prior_out, self.hidden_channels, dim=1)
         return mu_p, logs_p
 
@@ -170,6 +181,9 @@ class TextEncoder(nn.Module):
         tgt_nonpadding = (text_tokens > 0).float().unsqueeze(1)
         token_emb = self.forward_text_embedding(text_tokens, pitch_tokens, dur_tokens, tgt_nonpadding.transpose(1, 2))
         enc_out = self.text_encoder(token_emb.transpose(1, 2), tgt_nonpadding)       # [B, H, T_ph]
+        if autograd.training_path(self):      # differentiable gather (PyTorch-ROCm), same indexing
+            hp = torch.nn.functional.pad(enc_out, [1, 0])
+            return torch.gather(hp, 2, mel2ph[:, None, :].expand(-1, hp.shape[1], -1))
         # expand_states(enc_out.transpose(1, 2), mel2ph).transpose(1, 2) without the two transposes (encoder.py:39-40)
         return _expand_states_hip(enc_out, mel2ph, h_channels_first=True, out_channels_first=True)
 

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from ... import autograd
 from ...ops import _off
 from ..hipconv import HipConv1d, mask2d, _forward_only_guard
 from .encoder import WaveNet
@@ -36,6 +37,8 @@ class ResidualCouplingBlock(nn.Module):
             self.flows.append(Flip())
 
     def forward(self, x, x_mask, g=None, reverse=False):
+        if autograd.training_path(self):
+            return autograd.flow_block(self, x, x_mask, g, reverse)
         _forward_only_guard(self)
         B, C, T = x.shape
         xp = x.contiguous().float().clone()        # physical latent, updated in place by the couplings
@@ -100,6 +103,8 @@ class ResidualCouplingLayer(nn.Module):
                           logdet=logdet)
 
     def forward(self, x, x_mask, g=None, reverse=False):
+        if autograd.training_path(self):
+            return autograd.coupling_layer(self, x, x_mask, g, reverse)
         _forward_only_guard(self)
         B, C, T = x.shape
         xp = x.contiguous().float().clone()

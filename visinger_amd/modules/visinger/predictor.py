@@ -17,7 +17,7 @@ class PitchPredictor(nn.Module):
 
     def forward(self, x, x_mask, spk_emb):
         x = self.pitch_predictor(x, x_mask, g=spk_emb)
-        x = self.linear.run(x).transpose(1, 2)  # [Batch, T_len, Out_dim]
+        x = self.linear(x).transpose(1, 2)  # [Batch, T_len, Out_dim]
         return x
 
 
@@ -32,5 +32,5 @@ class PhonemePredictor(nn.Module):
 
     def forward(self, x, x_mask):
         x = self.phoneme_predictor(x, x_mask)
-        ph_pred = self.ph_proj.run(x)  # [Batch, Dict_size, T_len]
+        ph_pred = self.ph_proj(x)  # [Batch, Dict_size, T_len]
         return F.log_softmax(ph_pred, dim=1)

@@ -1,0 +1,153 @@
+"""GAN training step of VISinger on the MI355X-native modules, restated from the reference's
+``tasks/visinger.py:53-170,201-227`` (losses, optimizers, schedulers), ``tasks/base.py:227-238`` (masked mel L1) and
+``utils/commons/trainer.py:306-384`` (two optimizer passes per batch with the other optimizer's parameters frozen,
+gradient clipping over ALL task parameters, one scheduler step per pass).
+
+Forward: HIP conv engine (visinger_amd.autograd); backward: PyTorch-ROCm autograd; data parallel: stock
+``DistributedDataParallel(find_unused_parameters=True)`` over RCCL, one process per GPU -- the gradient all-reduce (<= 430 MB
+fp32 per backward) is the only collective of the training path.
+
+Deviations from the reference, all forced by its latent bugs: `uv` is passed to the model (the reference
+forgets it), ``lambda_uv`` / ``lambda_f0`` default to ``lambda_pitch`` (they are defined in no YAML).  The mel loss uses the
+``torch.stft`` restatement of torchaudio's transforms (visinger_amd/audio.py: parity unpinned).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import audio
+from .models.visinger import MultiPeriodDiscriminator, VISinger
+from .modules.commons.utils import slice_segments
+
+TRAIN_HPARAMS = dict(lr=2e-4, optimizer_adam_beta1=0.8, optimizer_adam_beta2=0.99, eps=1e-9, weight_decay=0.001,
+                     discriminator_optimizer_params=dict(eps=1e-9, weight_decay=0.0), scheduler_gamma=0.999875,
+                     clip_grad_norm=1.0, lambda_kl=1.0, kl_min=0.0, kl_start_steps=1, lambda_mel=45.0, lambda_ctc=45.0,
+                     lambda_mel_adv=1.0, lambda_fm=2.0, lambda_pitch=10.0, disc_start_steps=0, disc_interval=1,
+                     sample_rate=24000, fft_size=2048, win_size=1200, hop_size=300, fmin=20.0, fmax=12000.0,
+                     num_mel_bins=128, use_spectral_norm=False)
+
+
+def masked_l1(pred, target):
+    """tasks/base.py:232-238: L1 weighted by the frames whose target is not all-zero"""
+    w = target.abs().sum(-1, keepdim=True).ne(0).float().expand_as(target)
+    return (F.l1_loss(pred, target, reduction="none") * w).sum() / w.sum()
+
+
+def discriminator_loss(tgt_outputs, gen_outputs):
+    """tasks/visinger.py:147-153 (LSGAN)"""
+    return sum(torch.mean((1 - t.float()) ** 2) + torch.mean(g.float() ** 2) for t, g in zip(tgt_outputs, gen_outputs))
+
+
+def generator_loss(gen_outputs):
+    """tasks/visinger.py:155-160"""
+    return sum(torch.mean((1 - g.float()) ** 2) for g in gen_outputs)
+
+
+def feature_matching_loss(fmap_tgt, fmap_gen):
+    """tasks/visinger.py:162-169"""
+    return sum(torch.mean(torch.abs(t.float().detach() - g.float())) for ft, fg in zip(fmap_tgt, fmap_gen) for t, g in zip(ft, fg))
+
+
+class VISingerTrainer(nn.Module):
+    """Owns the two networks (children named ``model`` and ``mel_disc`` like the reference task, so the checkpoint layout
+    matches), the two AdamW optimizers and their ExponentialLR schedulers."""
+
+    def __init__(self, ph_dict_size, pitch_size, dur_size, hparams, train_hparams=None):
+        super().__init__()
+        self.hp = dict(TRAIN_HPARAMS, **(train_hparams or {}))
+        self.hop = int(torch.tensor(hparams["upsample_rates"]).prod())
+        self.hp["hop_size"] = self.hop
+        self.segment_size = hparams["segment_size"]
+        self.model = VISinger(ph_dict_size, pitch_size, dur_size, hparams)
+        self.mel_disc = MultiPeriodDiscriminator(self.hp["use_spectral_norm"])
+        self.global_step = 0
+        self._cached = None
+
+    def configure(self):
+        h = self.hp
+        self.opt_gen = torch.optim.AdamW(self.model.parameters(), lr=h["lr"], betas=(h["optimizer_adam_beta1"], h["optimizer_adam_beta2"]),
+                                         weight_decay=h["weight_decay"], eps=h["eps"])
+        self.opt_disc = torch.optim.AdamW(self.mel_disc.parameters(), lr=h["lr"],
+                                          betas=(h["optimizer_adam_beta1"], h["optimizer_adam_beta2"]),
+                                          **h["discriminator_optimizer_params"])
+        self.sched = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=h["scheduler_gamma"]) for o in (self.opt_gen, self.opt_disc)]
+        return self
+
+    def mel(self, wav):
+        h = self.hp
+        return audio.mel_spectrogram(wav, h["sample_rate"], h["fft_size"], h["win_size"], h["hop_size"], h["num_mel_bins"],
+                                     h["fmin"], h["fmax"])            # [B, T, n_mels]
+
+    # -- the two passes of tasks/visinger.py:53-89 ----------------------------------------------------------------
+    def generator_pass(self, batch):
+        h = self.hp
+        out = self.model(batch["text_tokens"], batch["note_pitch"], batch["note_dur"], batch["mel2ph"], spk_id=batch.get("spk_ids"),
+                         f0=batch.get("f0"), uv=batch.get("uv"), mel=batch["mels"], infer=False)
+        losses = {"kl": min(self.global_step / h["kl_start_steps"], 1) * torch.clamp(out["kl"], min=h["kl_min"]) * h["lambda_kl"]}
+        tgt_mel = self.mel(batch["wavs"])                                                   # [B, T, M]
+        tgt_slice = slice_segments(tgt_mel.transpose(1, 2).contiguous(), out["ids_slice"], self.segment_size).transpose(1, 2)
+        losses["mel_l1"] = masked_l1(self.mel(out["wav_out"]), tgt_slice) * h["lambda_mel"]
+        if "f0_pred" in out and batch.get("f0") is not None:
+            nonpad = (batch["mel2ph"] != 0).float()
+            uv, p = batch["uv"], out["f0_pred"]
+            losses["uv"] = (F.binary_cross_entropy_with_logits(p[:, :, 1], uv, reduction="none") * nonpad).sum() / nonpad.sum() * h["lambda_pitch"]
+            voiced = nonpad * (uv == 0).float()
+            losses["f0"] = (F.l1_loss(p[:, :, 0], batch["f0"], reduction="none") * voiced).sum() / voiced.sum().clamp(min=1) * h["lambda_pitch"]
+        if "ph_pred" in out:
+            losses["ctc"] = F.ctc_loss(out["ph_pred"].float().permute(2, 0, 1), batch["text_tokens"], batch["mel_lengths"],
+                                       batch["text_lengths"], zero_infinity=True) * h["lambda_ctc"]
+        self._cached = {k: v.detach() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        if self.global_step >= h["disc_start_steps"] and h["lambda_mel_adv"] > 0:
+            real = slice_segments(batch["wavs"].unsqueeze(1), out["ids_slice"] * self.hop, self.segment_size * self.hop)
+            _, d_gen, fmap_tgt, fmap_gen = self.mel_disc(real, out["wav_out"].unsqueeze(1))
+            losses["generator"] = generator_loss(d_gen) * h["lambda_mel_adv"]
+            losses["feature_match"] = feature_matching_loss(fmap_tgt, fmap_gen) * h["lambda_fm"]
+        return sum(losses.values()), losses
+
+    def discriminator_pass(self, batch):
+        out = self._cached
+        real = slice_segments(batch["wavs"].unsqueeze(1), out["ids_slice"] * self.hop, self.segment_size * self.hop)
+        d_tgt, d_gen, _, _ = self.mel_disc(real, out["wav_out"].unsqueeze(1))
+        loss = discriminator_loss(d_tgt, d_gen)
+        return loss, {"discriminator": loss}
+
+    def forward(self, batch, optimizer_idx):
+        """DDP entry point (the reference routes DDP.forward to training_step, ddp_utils.py:75-80)"""
+        return self.generator_pass(batch) if optimizer_idx == 0 else self.discriminator_pass(batch)
+
+    def training_step(self, batch, runner=None):
+        """One iteration = generator pass + discriminator pass (trainer.py:306-384).  `runner` is the (optionally
+        DDP-wrapped) module to call; gradients are clipped over ALL parameters of the task, as the reference does."""
+        runner = runner or self
+        logs = {}
+        for opt_idx, (opt, own, other) in enumerate(((self.opt_gen, self.model, self.mel_disc), (self.opt_disc, self.mel_disc, self.model))):
+            for p in other.parameters():
+                p.requires_grad_(False)
+            for p in own.parameters():
+                p.requires_grad_(True)
+            loss, parts = runner(batch, opt_idx)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()                      # under DDP: the bucketed gradient all-reduce over RCCL happens here
+            if self.hp["clip_grad_norm"] > 0:
+                torch.nn.utils.clip_grad_norm_(self.parameters(), self.hp["clip_grad_norm"])
+            opt.step()
+            self.sched[opt_idx].step()
+            logs.update({k: float(v.detach()) for k, v in parts.items()})
+        for p in self.parameters():
+            p.requires_grad_(True)
+        self.global_step += 1
+        return logs
+
+
+def synthetic_train_batch(B, T, Tph, hop, ph_dict, n_bins, seed, device):
+    """BASELINE config-3 synthetic batch: tokens uniform, mel2ph = repeat_interleave, linear spectrogram
+    |N(0,1)|^2, waveform U(-0.5, 0.5), log-f0 / uv random."""
+    g = torch.Generator().manual_seed(seed)
+    b = dict(text_tokens=torch.randint(4, ph_dict, (B, Tph), generator=g), note_pitch=torch.randint(1, 117, (B, Tph), generator=g),
+             note_dur=torch.randint(4, 131, (B, Tph), generator=g),
+             mel2ph=torch.repeat_interleave(torch.arange(1, Tph + 1), T // Tph)[None].repeat(B, 1),
+             mels=torch.randn(B, T, n_bins, generator=g).abs() ** 2, wavs=torch.rand(B, T * hop, generator=g) - 0.5,
+             f0=torch.rand(B, T, generator=g) * 2 + 4, uv=(torch.rand(B, T, generator=g) < 0.2).float(),
+             spk_ids=torch.zeros(B, dtype=torch.long), mel_lengths=torch.full((B,), T, dtype=torch.long),
+             text_lengths=torch.full((B,), Tph, dtype=torch.long))
+    return {k: v.to(device) for k, v in b.items()}
