@@ -88,6 +88,39 @@ def cpu_baseline(model, hp, budget_s=15.0):
                       f"{dt:.2f}s; text-encoder + frame-prior + flow-inverse + generator"}
 
 
+def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
+    """The metric's second half: flow log-det relative error of the HIP coupling layer against the fp64 oracle (part of
+    the cpu_baseline leg: the only place bench.py may call oracle/).  The model's own flow is mean_only=True
+    (models/visinger.py:66 -> flow.py:26-27), whose log-det must be EXACTLY 0; the affine form (mean_only=False,
+    flow.py:76-80) is checked on a coupling layer of the same size (192 ch, 4 WaveNet layers, gin 256)."""
+    from oracle import visinger_oracle as orc
+    from visinger_amd.modules.visinger.flow import ResidualCouplingLayer
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 192, T, generator=g)
+    lens = torch.tensor([T, T - T // 3])[:B]
+    mask = (torch.arange(T)[None] < lens[:, None]).float().unsqueeze(1)
+    spk = torch.randn(B, 256, 1, generator=g)
+    res = {}
+    with torch.no_grad():
+        lay0 = model.flow.flows[0]
+        _, ld0 = lay0(x.to(dev), mask.to(dev), g=spk.to(dev))
+        res["mean_only_true_logdet_is_exact_zero"] = bool((ld0 == 0).all())
+        torch.manual_seed(seed)
+        lay = ResidualCouplingLayer(192, 192, 5, 1, 4, gin_channels=256, mean_only=False)
+        lay.post.weight.copy_(0.05 * torch.randn(lay.post.weight.shape, generator=g))
+        lay.post.bias.copy_(0.05 * torch.randn(lay.post.bias.shape, generator=g))
+        sd = {k: v.detach().numpy().copy() for k, v in lay.state_dict().items()}
+        lay = lay.to(dev).eval()
+        y, ld = lay(x.to(dev), mask.to(dev), g=spk.to(dev))
+    y_ref, ld_ref = orc.coupling_layer(sd, x.numpy(), mask.numpy(), spk.numpy(), channels=192, hidden_channels=192,
+                                       kernel_size=5, dilation_rate=1, n_layers=4, mean_only=False, dtype=np.float64)
+    res["rel_err"] = float(np.max(np.abs(ld.cpu().numpy() - ld_ref) / np.abs(ld_ref)))
+    res["x_max_abs_err"] = float(np.max(np.abs(y.cpu().numpy() - y_ref)))
+    res["tolerance"] = 1e-4
+    res["sample"] = f"ResidualCouplingLayer(192,192,5,1,4,gin=256,mean_only=False) forward, B={B} T={T} ragged mask, vs fp64 oracle"
+    return res
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected
     from inside the timed run: they need rocprofv3 and one pass per counter); None when not recorded."""
@@ -163,7 +196,7 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in prof.values())
         out = {
-            "metric": "audio samples/sec (22.05 kHz) synthesis, B=32 T_mel=1024",
+            "metric": "audio samples/sec (22.05 kHz) + flow log-det rel-err, B=32 T_mel=1024",
             "value": samples / dt,
             "unit": "audio samples/s",
             "n_gpus": world,
@@ -195,6 +228,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, hp)
+            out["flow_logdet"] = flow_logdet_check(model, dev)
+            out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -137,12 +137,16 @@ VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma
  *                        h: [B, T_tokens, C] (h_channels_first = 0) or [B, C, T_tokens] (1); out likewise with T_frames.
  *     vs_make_positions: modules/rel_transformer.py:78-88.  positions = cumsum(x != pad) * (x != pad) + pad  (int64),
  *                        x: [B, T] fp32 (the channel-0 slice the callers pass), pad = padding_idx.
- *     vs_slice_segments: modules/commons/utils.py:86-92.  out[b, :, s] = x[b, :, ids_str[b] + s],  x: [B, C, T].      */
+ *     vs_slice_segments: modules/commons/utils.py:86-92.  out[b, :, s] = x[b, :, ids_str[b] + s],  x: [B, C, T].
+ *     vs_mel2token_to_dur: utils/audio/align.py:105-129.  dur[b, i-1] = #{t : mel2token[b, t] == i}, i in 1..T_tokens
+ *                        (index 0 = padding, dropped); clamped to max_dur when max_dur >= 0.  int64 in, int64 out.        */
 VS_API int vs_expand_states(const float *h, const int64_t *mel2token, float *out, int64_t B, int64_t T_tokens,
                             int64_t T_frames, int64_t C, int h_channels_first, int out_channels_first, void *stream);
 VS_API int vs_make_positions(const float *x, int64_t *positions, int64_t B, int64_t T, int64_t padding_idx, void *stream);
 VS_API int vs_slice_segments(const float *x, const int64_t *ids_str, float *out, int64_t B, int64_t C, int64_t T,
                              int64_t segment_size, void *stream);
+VS_API int vs_mel2token_to_dur(const int64_t *mel2token, int64_t *dur, int64_t B, int64_t T_frames, int64_t T_tokens,
+                               int64_t max_dur, void *stream);
 
 #ifdef __cplusplus
 }

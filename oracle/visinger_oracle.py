@@ -417,6 +417,16 @@ def slice_segments(x, ids_str, segment_size=4):
     return np.stack([x[i, :, int(s):int(s) + segment_size] for i, s in enumerate(ids_str)], 0)
 
 
+def mel2token_to_dur(mel2token, T_txt, max_dur=None):
+    """utils/audio/align.py:105-129: dur[b, i-1] = #{t: mel2token[b, t] == i} for i = 1..T_txt (index 0 dropped)."""
+    m = np.asarray(mel2token, dtype=np.int64)
+    dur = np.zeros((m.shape[0], T_txt + 1), dtype=np.int64)
+    for b in range(m.shape[0]):
+        np.add.at(dur[b], m[b], 1)
+    dur = dur[:, 1:]
+    return dur if max_dur is None else np.minimum(dur, max_dur)
+
+
 def rand_slice_ids(u, t_len, segment_size):
     """modules/commons/utils.py:95-99: ids = (u * (t_len - segment + 1)).long() with u ~ U[0,1) fp32 from the
     CPU generator; the product is taken in fp32 then truncated."""

@@ -279,6 +279,10 @@ def gen_integer():
     mel2ph = torch.randint(0, Tph + 1, (B, T), generator=gi)
     mel2ph[2, 20:] = 0
     save("expand_states", h=h, mel2ph=mel2ph, y=expand_states(h, mel2ph))
+    # frames per token (utils/audio/align.py:105-129; caller tasks/base.py:342)
+    from utils.audio.align import mel2token_to_dur
+    save("mel2token_to_dur", mel2ph=mel2ph, dur=mel2token_to_dur(mel2ph, Tph), dur_clamped=mel2token_to_dur(mel2ph, Tph, max_dur=4),
+         dur_1d=mel2token_to_dur(mel2ph[0], Tph), dur_auto=mel2token_to_dur(mel2ph[:, :11]))
     # make_positions / sinusoidal embedding (rel_transformer.py:59-100)
     inp = rnd(17, B, T)
     inp[0, 5] = 0.0

@@ -54,3 +54,60 @@ def test_strided_shard_and_max_time_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _ddp_worker(rank, world, port, q):
+    """Training-path collective: the discriminator loss of visinger_amd.train under stock DDP over gloo.
+    Each rank sees its strided shard; the all-reduced gradient must equal the single-process gradient on the global
+    batch.  (The frame slicing in front of it is a HIP op and is covered on the GPU; here the segments are pre-sliced.)"""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from visinger_amd.dp import shard_batch
+        from visinger_amd.models.visinger import MultiPeriodDiscriminator
+        from visinger_amd.train import discriminator_loss
+        torch.manual_seed(7)                                   # same weights on every rank
+        disc = MultiPeriodDiscriminator()
+        g = torch.Generator().manual_seed(11)
+        real = torch.rand(2 * world, 1, 1200, generator=g) - 0.5
+        fake = 0.3 * torch.randn(2 * world, 1, 1200, generator=g)
+
+        def grads(net, real, fake):
+            disc.zero_grad(set_to_none=True)
+            d_tgt, d_gen, _, _ = net(real, fake)
+            loss = discriminator_loss(d_tgt, d_gen)
+            loss.backward()
+            return torch.cat([p.grad.flatten() for p in disc.parameters()]).clone(), float(loss)
+
+        full, loss_full = grads(disc, real, fake)
+        ddp = DDP(disc, find_unused_parameters=True)
+        r, f = shard_batch([real, fake], rank, world)
+        mine, loss_mine = grads(ddp, r, f)
+        losses = [None] * world
+        dist.all_gather_object(losses, loss_mine)
+        scale = float(full.abs().max())
+        ok = float((mine - full).abs().max()) <= 2e-5 * scale and abs(sum(losses) / world - loss_full) <= 1e-5 * abs(loss_full)
+        q.put((rank, bool(ok)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:   # surface the failure instead of letting the parent wait for the queue
+        q.put((rank, repr(e)))
+        raise
+
+
+def test_ddp_gradient_allreduce_matches_global_batch_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(res) == [(0, True), (1, True)]

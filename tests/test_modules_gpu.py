@@ -223,6 +223,14 @@ def test_integer_paths_bit_exact():
     torch.manual_seed(1234)
     ys, ids = rand_slice_segments(cu(a["x"]), 8)
     assert np.array_equal(ids.cpu().numpy(), a["rand_ids"]) and np.array_equal(ys.cpu().numpy(), a["rand_y"])
+    from visinger_amd.models.commons.align_ops import mel2token_to_dur
+    _, a = load_golden("mel2token_to_dur")
+    m2p, Tph = cu(a["mel2ph"]), a["dur"].shape[1]
+    d = mel2token_to_dur(m2p, Tph)
+    assert d.dtype == torch.int64 and np.array_equal(d.cpu().numpy(), a["dur"])
+    assert np.array_equal(mel2token_to_dur(m2p, Tph, max_dur=4).cpu().numpy(), a["dur_clamped"])
+    assert np.array_equal(mel2token_to_dur(m2p[0], Tph).cpu().numpy(), a["dur_1d"])
+    assert np.array_equal(mel2token_to_dur(m2p[:, :11]).cpu().numpy(), a["dur_auto"])
 
 
 def test_fused_path_refuses_autograd():
@@ -255,6 +263,9 @@ def test_index_ops_random_large(oracle):
     ids = r.integers(0, T - 32 + 1, (B,)).astype(np.int64)
     ids[0], ids[1] = 0, T - 32
     assert np.array_equal(slice_segments(cu(z), cu(ids), 32).cpu().numpy(), oracle.slice_segments(z, ids, 32))
+    from visinger_amd.ops import mel2token_to_dur
+    assert np.array_equal(mel2token_to_dur(cu(m2p), Tp).cpu().numpy(), oracle.mel2token_to_dur(m2p, Tp))
+    assert int(mel2token_to_dur(cu(m2p), Tp).sum()) == int((m2p > 0).sum())          # every non-padding frame counted once
 
 
 def test_discriminators_gpu():

@@ -180,6 +180,12 @@ def test_integer_paths_bit_exact(oracle):
     assert np.array_equal(ids, a["rand_ids"])
     assert np.array_equal(oracle.slice_segments(a["x"], ids, 8), a["rand_y"])
     assert [oracle.get_padding(k, d) for k in (3, 5, 7, 11) for d in (1, 3, 5)] == a["pads"].tolist()
+    _, a = load_golden("mel2token_to_dur")
+    Tph = a["dur"].shape[1]
+    assert np.array_equal(oracle.mel2token_to_dur(a["mel2ph"], Tph), a["dur"])
+    assert np.array_equal(oracle.mel2token_to_dur(a["mel2ph"], Tph, max_dur=4), a["dur_clamped"])
+    assert np.array_equal(oracle.mel2token_to_dur(a["mel2ph"][:1], Tph)[0], a["dur_1d"])
+    assert np.array_equal(oracle.mel2token_to_dur(a["mel2ph"][:, :11], int(a["mel2ph"][:, :11].max())), a["dur_auto"])
 
 
 def test_visinger_tiny_infer(oracle):

@@ -76,6 +76,7 @@ def lib():
     L.vs_expand_states.argtypes = [_f32p, vp, _f32p, i64, i64, i64, i64, ci, ci, vp]
     L.vs_make_positions.argtypes = [_f32p, vp, i64, i64, i64, vp]
     L.vs_slice_segments.argtypes = [_f32p, vp, _f32p, i64, i64, i64, i64, vp]
+    L.vs_mel2token_to_dur.argtypes = [vp, vp, i64, i64, i64, i64, vp]
     _lib = L
     return L
 

@@ -3,6 +3,7 @@
 //   vs_expand_states    models/commons/align_ops.py:22-26   (1-based gather with a zero pad row)
 //   vs_make_positions   modules/rel_transformer.py:78-88    (cumsum(x != pad) * (x != pad) + pad, int64)
 //   vs_slice_segments   modules/commons/utils.py:86-92      (per-item window of the time axis)
+//   vs_mel2token_to_dur utils/audio/align.py:105-129        (frames per token: integer histogram of the alignment)
 #include "vs_internal.h"
 
 namespace vs {
@@ -50,6 +51,22 @@ __global__ void slice_segments_kernel(const float *__restrict__ x, const long lo
     out[e] = (t >= 0 && t < T) ? x[((long long)b * C + c) * T + t] : 0.f;
 }
 
+// dur[b, i-1] += 1 for every frame whose (1-based) token index is i in [1, T_txt]; index 0 is padding.  Integer
+// atomics: order-independent, hence bit-exact.
+__global__ void mel2token_hist_kernel(const long long *__restrict__ m2t, unsigned long long *__restrict__ dur, int B, int T,
+                                      int T_txt) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)B * T) return;
+    const int b = (int)(e / T);
+    const long long i = m2t[e];
+    if (i > 0 && i <= T_txt) atomicAdd(&dur[(long long)b * T_txt + (i - 1)], 1ull);
+}
+
+__global__ void clamp_max_kernel(long long *__restrict__ v, long long n, long long hi) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && v[e] > hi) v[e] = hi;
+}
+
 }  // namespace vs
 
 using namespace vs;
@@ -82,6 +99,21 @@ int vs_slice_segments(const float *x, const int64_t *ids_str, float *out, int64_
     hipLaunchKernelGGL(slice_segments_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), x,
                        (const long long *)ids_str, out, (int)B, (int)C, (int)T, (int)segment_size);
     VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_mel2token_to_dur(const int64_t *mel2token, int64_t *dur, int64_t B, int64_t T_frames, int64_t T_tokens, int64_t max_dur,
+                        void *stream) {
+    VS_REQUIRE(mel2token && dur && B > 0 && T_frames > 0 && T_tokens > 0, "vs_mel2token_to_dur: bad arguments");
+    VS_CHECK_HIP(hipMemsetAsync(dur, 0, sizeof(int64_t) * (size_t)(B * T_tokens), as_stream(stream)));
+    hipLaunchKernelGGL(mel2token_hist_kernel, dim3((unsigned)ceil_div(B * T_frames, 256)), dim3(256), 0, as_stream(stream),
+                       (const long long *)mel2token, (unsigned long long *)dur, (int)B, (int)T_frames, (int)T_tokens);
+    VS_CHECK_HIP(hipGetLastError());
+    if (max_dur >= 0) {
+        hipLaunchKernelGGL(clamp_max_kernel, dim3((unsigned)ceil_div(B * T_tokens, 256)), dim3(256), 0, as_stream(stream),
+                           (long long *)dur, (long long)(B * T_tokens), (long long)max_dur);
+        VS_CHECK_HIP(hipGetLastError());
+    }
     return VS_OK;
 }
 

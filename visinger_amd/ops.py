@@ -227,3 +227,14 @@ def slice_segments(x, ids_str, segment_size):
     out = torch.empty((B, C, segment_size), device=x.device, dtype=torch.float32)
     L.check(lib.vs_slice_segments(L.ptr(x), _i64ptr(ids), L.ptr(out), B, C, T, segment_size, L.stream_ptr()))
     return out
+
+
+def mel2token_to_dur(mel2token, T_txt, max_dur=None):
+    """a9 / 8f-3: dur[b, i-1] = number of frames aligned to token i (utils/audio/align.py:105-129), int64, bit-exact."""
+    lib = L.require_gpu()
+    m = mel2token.to(dtype=torch.int64).contiguous()
+    B, T = m.shape
+    dur = torch.empty((B, int(T_txt)), device=m.device, dtype=torch.int64)
+    L.check(lib.vs_mel2token_to_dur(_i64ptr(m), _i64ptr(dur), B, T, int(T_txt), -1 if max_dur is None else int(max_dur),
+                                    L.stream_ptr()))
+    return dur
