@@ -62,11 +62,16 @@ def build_model(seed=1234):
     return model.eval(), hp
 
 
-def cpu_baseline(model, hp, budget_s=15.0):
+def cpu_baseline(model, hp, budget_s=12.0, backend="c"):
     """The CPU oracle (fp32 'port' of the reference arithmetic, oracle/) timed on a bounded sample of the SAME
-    workload (same weights, same synthetic input recipe): B=1, T_mel sized from a T_mel=32 probe to ~budget_s."""
+    workload (same weights, same synthetic input recipe): B=1, T_mel sized from a T_mel=32 probe to ~budget_s.
+    backend "c": the C/OpenMP restatement; "torch": the same composition with the convolutions (98 % of the CPU time) on
+    stock PyTorch CPU kernels with torch.set_num_threads(all cores) -- the reference's own CPU execution engine."""
     from oracle import visinger_oracle as orc
     orc.build()
+    orc.CONV_BACKEND = backend
+    if backend == "torch":
+        torch.set_num_threads(os.cpu_count() or 1)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     hpo = dict(hp, use_pitch_embed=False)   # the runnable reference configuration (SURVEY.md 3.5-1)
     cores = os.cpu_count() or 1
@@ -79,12 +84,14 @@ def cpu_baseline(model, hp, budget_s=15.0):
 
     T = 32
     n, dt = run(T)
-    T2 = int(min(512, 32 * max(1, 2 ** int(np.log2(max(1.0, budget_s / max(dt, 1e-3)))))))
+    T2 = int(min(4096, 32 * max(1, 2 ** int(np.log2(max(1.0, budget_s / max(dt, 1e-3)))))))
     if T2 > T:
         T = T2
         n, dt = run(T)
+    orc.CONV_BACKEND = "c"
+    what = "C+numpy port (OpenMP" if backend == "c" else "numpy composition with torch-CPU oneDNN convolutions (torch threads"
     return {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ fp32 C+numpy port (OpenMP, {cores} threads), B=1 T_mel={T} hop={HOP}: {n} samples in "
+            "sample": f"oracle/ fp32 {what}, {cores} threads), B=1 T_mel={T} hop={HOP}: {n} samples in "
                       f"{dt:.2f}s; text-encoder + frame-prior + flow-inverse + generator"}
 
 
@@ -228,6 +235,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, hp)
+            out["cpu_baseline_torch"] = cpu_baseline(model, hp, backend="torch")
             out["flow_logdet"] = flow_logdet_check(model, dev)
             out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
         print(json.dumps(out), flush=True)

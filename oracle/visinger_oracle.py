@@ -56,6 +56,21 @@ def _c(a, dtype):
 
 _i64 = ctypes.c_int64
 
+# "c" = the C restatement below (the referee, and the `port` CPU baseline); "torch" = the same composition with the two
+# convolution primitives executed by stock PyTorch CPU kernels (torch.nn.functional, oneDNN) -- the second CPU baseline
+# BASELINE.md 4 asks for ("stock-PyTorch CPU model of identical architecture"), used by bench.py only.
+CONV_BACKEND = "c"
+
+
+def _torch_conv(x, w, bias, transposed, **kw):
+    import torch
+    import torch.nn.functional as F
+    t = [None if a is None else torch.from_numpy(a) for a in (x, w, bias)]
+    with torch.no_grad():
+        y = (F.conv_transpose1d if transposed else F.conv1d)(t[0], t[1], t[2], **kw)
+    return y.numpy()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # primitives
 
@@ -85,6 +100,8 @@ def conv1d(x, w, bias=None, dilation=1, padding=0, dtype=np.float64):
     Cout, Cin2, K = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
     Tout = T + 2 * padding - dilation * (K - 1)
+    if CONV_BACKEND == "torch":
+        return _torch_conv(x, w, bias, False, dilation=dilation, padding=padding)
     y = np.empty((B, Cout, Tout), dtype=dtype)
     _lib(dtype).orc_conv1d(_p(x), _p(w), _p(bias), _p(y), _i64(B), _i64(Cin), _i64(Cout), _i64(T), _i64(K),
                            _i64(dilation), _i64(padding))
@@ -98,6 +115,8 @@ def conv_transpose1d(x, w, bias=None, stride=1, padding=0, dtype=np.float64):
     Cin2, Cout, K = w.shape
     assert Cin == Cin2
     Tout = (T - 1) * stride - 2 * padding + K
+    if CONV_BACKEND == "torch":
+        return _torch_conv(x, w, bias, True, stride=stride, padding=padding)
     y = np.empty((B, Cout, Tout), dtype=dtype)
     _lib(dtype).orc_conv_transpose1d(_p(x), _p(w), _p(bias), _p(y), _i64(B), _i64(Cin), _i64(Cout), _i64(T),
                                      _i64(K), _i64(stride), _i64(padding))

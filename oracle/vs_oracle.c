@@ -48,23 +48,31 @@ API void orc_weightnorm(const real *v, const real *g, real *w, int64_t rows, int
 
 /* y[b, co, t] = bias[co] + sum_{ci, k} w[co, ci, k] * x[b, ci, t + k*dil - pad]   (zero padding, stride 1)
  * x: [B, Cin, T]   w: [Cout, Cin, K]   y: [B, Cout, Tout],  Tout = T + 2*pad - dil*(K-1) */
+#define ORC_TCHUNK 2048   /* time-axis chunk: the parallel loop runs over (b, co, chunk) so that B=1 still fills the cores */
+
 API void orc_conv1d(const real *x, const real *w, const real *bias, real *y, int64_t B, int64_t Cin, int64_t Cout,
                     int64_t T, int64_t K, int64_t dil, int64_t pad) {
     const int64_t Tout = T + 2 * pad - dil * (K - 1);
-#pragma omp parallel for collapse(2) schedule(static)
+    const int64_t nchunk = (Tout + ORC_TCHUNK - 1) / ORC_TCHUNK;
+#pragma omp parallel for collapse(3) schedule(static)
     for (int64_t b = 0; b < B; ++b) {
         for (int64_t co = 0; co < Cout; ++co) {
-            real *yr = y + (b * Cout + co) * Tout;
-            const real b0 = bias ? bias[co] : (real)0;
-            for (int64_t t = 0; t < Tout; ++t) yr[t] = b0;
-            for (int64_t ci = 0; ci < Cin; ++ci) {
-                const real *xr = x + (b * Cin + ci) * T;
-                for (int64_t k = 0; k < K; ++k) {
-                    const real wv = w[(co * Cin + ci) * K + k];
-                    const int64_t off = k * dil - pad;          /* x index = t + off */
-                    int64_t t0 = off < 0 ? -off : 0;
-                    int64_t t1 = T - off < Tout ? T - off : Tout;
-                    for (int64_t t = t0; t < t1; ++t) yr[t] += wv * xr[t + off];
+            for (int64_t ch = 0; ch < nchunk; ++ch) {
+                const int64_t c0 = ch * ORC_TCHUNK, c1 = c0 + ORC_TCHUNK < Tout ? c0 + ORC_TCHUNK : Tout;
+                real *yr = y + (b * Cout + co) * Tout;
+                const real b0 = bias ? bias[co] : (real)0;
+                for (int64_t t = c0; t < c1; ++t) yr[t] = b0;
+                for (int64_t ci = 0; ci < Cin; ++ci) {
+                    const real *xr = x + (b * Cin + ci) * T;
+                    for (int64_t k = 0; k < K; ++k) {
+                        const real wv = w[(co * Cin + ci) * K + k];
+                        const int64_t off = k * dil - pad;          /* x index = t + off */
+                        int64_t t0 = off < 0 ? -off : 0;
+                        int64_t t1 = T - off < Tout ? T - off : Tout;
+                        if (t0 < c0) t0 = c0;
+                        if (t1 > c1) t1 = c1;
+                        for (int64_t t = t0; t < t1; ++t) yr[t] += wv * xr[t + off];
+                    }
                 }
             }
         }
@@ -76,19 +84,25 @@ API void orc_conv1d(const real *x, const real *w, const real *bias, real *y, int
 API void orc_conv_transpose1d(const real *x, const real *w, const real *bias, real *y, int64_t B, int64_t Cin,
                               int64_t Cout, int64_t T, int64_t K, int64_t stride, int64_t pad) {
     const int64_t Tout = (T - 1) * stride - 2 * pad + K;
-#pragma omp parallel for collapse(2) schedule(static)
+    const int64_t nchunk = (Tout + ORC_TCHUNK - 1) / ORC_TCHUNK;
+#pragma omp parallel for collapse(3) schedule(static)
     for (int64_t b = 0; b < B; ++b) {
         for (int64_t co = 0; co < Cout; ++co) {
-            real *yr = y + (b * Cout + co) * Tout;
-            const real b0 = bias ? bias[co] : (real)0;
-            for (int64_t n = 0; n < Tout; ++n) yr[n] = b0;
-            for (int64_t ci = 0; ci < Cin; ++ci) {
-                const real *xr = x + (b * Cin + ci) * T;
-                for (int64_t k = 0; k < K; ++k) {
-                    const real wv = w[(ci * Cout + co) * K + k];
-                    for (int64_t m = 0; m < T; ++m) {
-                        const int64_t n = m * stride - pad + k;
-                        if (n >= 0 && n < Tout) yr[n] += wv * xr[m];
+            for (int64_t ch = 0; ch < nchunk; ++ch) {
+                const int64_t c0 = ch * ORC_TCHUNK, c1 = c0 + ORC_TCHUNK < Tout ? c0 + ORC_TCHUNK : Tout;
+                real *yr = y + (b * Cout + co) * Tout;
+                const real b0 = bias ? bias[co] : (real)0;
+                for (int64_t n = c0; n < c1; ++n) yr[n] = b0;
+                for (int64_t ci = 0; ci < Cin; ++ci) {
+                    const real *xr = x + (b * Cin + ci) * T;
+                    for (int64_t k = 0; k < K; ++k) {
+                        const real wv = w[(ci * Cout + co) * K + k];
+                        /* n = m*stride - pad + k in [c0, c1)  <=>  m in [ceil((c0+pad-k)/stride), ceil((c1+pad-k)/stride)) */
+                        int64_t lo = c0 + pad - k, hi = c1 + pad - k;
+                        int64_t m0 = lo <= 0 ? 0 : (lo + stride - 1) / stride;
+                        int64_t m1 = hi <= 0 ? 0 : (hi + stride - 1) / stride;
+                        if (m1 > T) m1 = T;
+                        for (int64_t m = m0; m < m1; ++m) yr[m * stride - pad + k] += wv * xr[m];
                     }
                 }
             }
