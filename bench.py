@@ -62,6 +62,28 @@ def build_model(seed=1234):
     return model.eval(), hp
 
 
+def usable_cores():
+    """host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota when there is one
+    (os.cpu_count() reports the machine's cores even inside a quota-limited container)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(model, hp, budget_s=12.0, backend="c"):
     """The CPU oracle (fp32 'port' of the reference arithmetic, oracle/) timed on a bounded sample of the SAME
     workload (same weights, same synthetic input recipe): B=1, T_mel sized from a T_mel=32 probe to ~budget_s.
@@ -70,11 +92,13 @@ def cpu_baseline(model, hp, budget_s=12.0, backend="c"):
     from oracle import visinger_oracle as orc
     orc.build()
     orc.CONV_BACKEND = backend
+    cores = usable_cores()
+    orc.set_threads(cores)
     if backend == "torch":
-        torch.set_num_threads(os.cpu_count() or 1)
+        cores = min(cores, 32)      # oneDNN on a B=1 conv does not scale past a few dozen threads (and thrashes at 256)
+        torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     hpo = dict(hp, use_pitch_embed=False)   # the runnable reference configuration
-    cores = os.cpu_count() or 1
 
     def run(T):
         text, pitch, dur, mel2ph, spk, noise = [t.numpy() for t in synthetic_batch(1, T, max(1, T // 8), 64, 1234, "cpu")]

@@ -46,6 +46,11 @@ def _lib(dtype):
     return _LIBS[tag]
 
 
+def set_threads(n):
+    """OpenMP threads of the C primitives (both precisions); returns the count in effect."""
+    return min(_lib(np.float64).orc_set_threads(int(n)), _lib(np.float32).orc_set_threads(int(n)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

@@ -35,6 +35,14 @@ typedef REAL real;
 
 API int orc_real_bytes(void) { return (int)sizeof(real); }
 
+#ifdef _OPENMP
+#include <omp.h>
+/* threads of the parallel loops below (the CPU-baseline leg sets it to the cores the process may actually use) */
+API int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+API int orc_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* w[r, :] = g[r] * v[r, :] / ||v[r, :]||_2      (rows = dim 0 of the weight, cols = product of the rest) */
 API void orc_weightnorm(const real *v, const real *g, real *w, int64_t rows, int64_t cols) {
 #pragma omp parallel for schedule(static)

@@ -246,3 +246,63 @@ def test_errors_are_reported_not_fatal():
     op = ConvOp(L.CONV1D, 16, 16, 3, 1, 1)
     with pytest.raises(L.VisingerHipError):
         op.forward(torch.zeros(1, 16, 8, device="cuda"))   # weights not set
+
+
+# F(2,3) minimal-filtering path (conv_wino_kernel): every (k, dilation) of the resblocks + the FFN k=9, the three
+# workgroup shapes (C_out % 128 == 0, % 64 == 0, odd tile counts), aligned lengths (vector epilogue, interior + ragged
+# last tile) and unaligned lengths (element-wise epilogue everywhere), with every fused epilogue option.
+WINO_CASES = [
+    # (B, Cin, Cout, T, k, dil)
+    (2, 128, 128, 1024, 3, 1), (1, 128, 128, 1000, 3, 3), (1, 128, 128, 772, 3, 5),
+    (1, 64, 64, 2048, 7, 1), (2, 64, 64, 1300, 7, 3), (1, 64, 64, 1504, 7, 5),
+    (1, 32, 32, 4096, 11, 1), (1, 32, 32, 2600, 11, 3), (2, 32, 32, 2500, 11, 5),
+    (1, 256, 256, 520, 3, 1), (1, 192, 768, 300, 9, 1), (1, 768, 192, 300, 9, 1),
+    (1, 40, 96, 333, 5, 1), (1, 32, 32, 7, 3, 1), (1, 128, 128, 129, 7, 5),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,k,dil", WINO_CASES)
+def test_conv1d_winograd_path(oracle, monkeypatch, B, Cin, Cout, T, k, dil):
+    from visinger_amd.ops import ConvOp
+    monkeypatch.setenv("VS_WINO_FORCE", "1")     # also the shapes the dispatch heuristic leaves on the direct engine
+    r = rng(B * 977 + Cin + 3 * Cout + T + 11 * k + dil)
+    x = r.standard_normal((B, Cin, T)).astype(np.float32)
+    v = r.standard_normal((Cout, Cin, k)).astype(np.float32)
+    g = (0.5 + r.random((Cout, 1, 1))).astype(np.float32)
+    bias = r.standard_normal(Cout).astype(np.float32)
+    res = r.standard_normal((B, Cout, T)).astype(np.float32)
+    accb = r.standard_normal((B, Cout, T)).astype(np.float32)
+    mask = np.ones((B, T), np.float32)
+    mask[-1, (2 * T) // 3:] = 0
+    w = oracle.weight_norm(v, g)
+    pad = (k * dil - dil) // 2
+    op = ConvOp(L.CONV1D, Cin, Cout, k, dil, pad)
+    assert op.kernel_instance().startswith("conv_wino_kernel"), op.kernel_instance()
+    op.set_weights(dev(v), dev(g), dev(bias))
+    conv = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w, bias, dilation=dil, padding=pad)
+    y = op.forward(dev(x), in_act=L.IN_LRELU)
+    close(y, conv)
+    y = op.forward(dev(x), in_act=L.IN_LRELU, res=dev(res), acc=dev(accb), scale=1.0 / 3.0)
+    close(y, (conv + res + accb) / 3.0)
+    convm = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)) * mask[:, None], w, bias, dilation=dil, padding=pad)
+    y = op.forward(dev(x), in_act=L.IN_LRELU_MASK, mask=dev(mask), res=dev(res), out_act=L.OUT_TANH, out_mask=True)
+    close(y, np.tanh(convm + res) * mask[:, None])
+
+
+def test_winograd_matches_direct_engine_at_size(monkeypatch):
+    """size-independent property at a resblock-sized launch: the F(2,3) path and the direct path agree to fp32 rounding"""
+    from visinger_amd.ops import ConvOp
+    torch.manual_seed(3)
+    B, C, T, k, dil = 4, 128, 16384, 7, 3
+    x = torch.randn(B, C, T, device="cuda")
+    w = torch.randn(C, C, k, device="cuda") / (C * k) ** 0.5
+    bias = torch.randn(C, device="cuda")
+    op = ConvOp(L.CONV1D, C, C, k, dil, (k * dil - dil) // 2)
+    op.set_weights(w, None, bias)
+    monkeypatch.setenv("VS_WINO_FORCE", "1")
+    y_w = op.forward(x, in_act=L.IN_LRELU, res=x)
+    monkeypatch.delenv("VS_WINO_FORCE")
+    monkeypatch.setenv("VS_NO_WINO", "1")
+    y_d = op.forward(x, in_act=L.IN_LRELU, res=x)
+    torch.cuda.synchronize()
+    assert float((y_w - y_d).abs().max()) <= 2e-5 * (1.0 + float(y_d.abs().max()))

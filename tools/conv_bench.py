@@ -40,9 +40,9 @@ if __name__ == "__main__":
     tot = 0.0
     for C, T in ((256, 8192), (128, 65536), (64, 131072), (32, 262144)):
         for k in (3, 7, 11):
-            for d in (1, 5):
+            for d in (1, 3, 5):
                 ms = bench(f"resblock C={C} k={k} d={d}", L.CONV1D, C, C, k, d, T, in_act=L.IN_LRELU, res=True)
-                tot += ms * (2 if d == 1 else 1) * 1.5   # 6 convs per k: 4 with d=1, 1 d=3, 1 d=5 (approx weight)
+                tot += ms * (4 if d == 1 else 1)   # 6 convs per (stage, k): convs1 d=1,3,5 + convs2 d=1 x3
     bench("ups0 512->256 k16 u8", L.CONV_TRANSPOSE1D, 512, 256, 16, 8, 1024, in_act=L.IN_LRELU)
     bench("ups1 256->128 k16 u8", L.CONV_TRANSPOSE1D, 256, 128, 16, 8, 8192, in_act=L.IN_LRELU)
     bench("ups2 128->64 k4 u2", L.CONV_TRANSPOSE1D, 128, 64, 4, 2, 65536, in_act=L.IN_LRELU)
@@ -52,6 +52,6 @@ if __name__ == "__main__":
     bench("1x1 192->192 T=1024", L.CONV1D, 192, 192, 1, 1, 1024)
     bench("1x1 192->384 T=1024", L.CONV1D, 192, 384, 1, 1, 1024)
     bench("ffn1 192->768 k9", L.CONV1D, 192, 768, 9, 1, 1024, out_act=L.OUT_RELU)
-    bench("ffn2 768->192 k1", L.CONV1D, 768, 192, 1, 1, 1024)
+    bench("ffn2 768->192 k9", L.CONV1D, 768, 192, 9, 1, 1024)
     bench("wavenet in 192->384 k5 (gate)", L.CONV1D_PAIRED, 192, 384, 5, 1, 1024, pair_mode=L.PAIR_GATE)
     print(f"approx resblock total {tot:.1f} ms")

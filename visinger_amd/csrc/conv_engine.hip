@@ -78,6 +78,7 @@ struct ConvParams {
     int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
     int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
     int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
+    int dbg;                    // perturbation experiments (VS_WINO_DBG), 0 in production
     unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
 };
 
@@ -511,6 +512,358 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     }
 }
 
+// One half-step of conv_wino_kernel: 4 input-channel pairs of one tap group, F(2,3): four products per pair column.
+// x values of channel pair cp + 1 are read from LDS under the MFMAs of pair cp; the V's of a pair are all formed before its
+// first MFMA (a VALU result consumed by the very next MFMA costs wait states).  xa/xb: LDS addresses of (x0, x2) and (x1, x3)
+// of the wave's two pair tiles -- with dilation 1 the even and odd columns of the window are staged in separate halves of
+// each LDS row, so both are unit-stride across lanes (a stride-2 read is a 2-way bank conflict); otherwise xb = xa + DIL.
+// (A partial last tap group could run as F(2,2) / direct form into the same accumulators -- k=7: 10 instead of 12 MFMAs --
+// but any control flow with MFMAs on the accumulators in both arms makes hipcc spill them; the taps are zero-padded.)
+template <int DIL>
+__device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float (&a)[16], const float *xa0, const float *xb0,
+                                               const float *xa1, const float *xb1, int RP) {
+    constexpr int S2 = (DIL == 1) ? 1 : 2 * DIL;      // distance x0 -> x2 (and x1 -> x3) in LDS words
+    const float *xa[2] = {xa0, xa1}, *xb[2] = {xb0, xb1};
+    float xc[2][4], xn[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        xc[j][0] = xa[j][0]; xc[j][2] = xa[j][S2];
+        xc[j][1] = xb[j][0]; xc[j][3] = xb[j][S2];
+    }
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {
+        if (cp + 1 < 4) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                xn[j][0] = xa[j][(cp + 1) * 2 * RP]; xn[j][2] = xa[j][(cp + 1) * 2 * RP + S2];
+                xn[j][1] = xb[j][(cp + 1) * 2 * RP]; xn[j][3] = xb[j][(cp + 1) * 2 * RP + S2];
+            }
+        }
+        float v[4][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            v[0][j] = xc[j][0] - xc[j][2];
+            v[1][j] = xc[j][1] + xc[j][2];
+            v[2][j] = xc[j][2] - xc[j][1];
+            v[3][j] = xc[j][1] - xc[j][3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[xi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp * 4 + xi], v[xi][j], acc[xi][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xc[j][q] = xn[j][q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Minimal-filtering (Winograd F(2,3)) variant of the engine for the stride-1 "same" convolutions with >= 3 taps
+// (the HiFi-GAN resblock convs k in {3,7,11}, dilation {1,3,5}, decoder.py:72-87 -- 87 % of the synthesis FLOPs -- and the
+// FFN k=9 convs, rel_transformer.py:332-333).  The taps are cut into groups of three; for one group and one pair of
+// outputs (y[t], y[t+d]) the six products of the direct form become four:
+//     V0 = x0 - x2, V1 = x1 + x2, V2 = x2 - x1, V3 = x1 - x3                 (x_j = x[t + (3g + j) d - pad])
+//     U0 = w0, U1 = (w0 + w1 + w2)/2, U2 = (w0 - w1 + w2)/2, U3 = w2          (packed once, pack_wino_kernel)
+//     M_xi += U_xi . V_xi  (contraction over input channels: the MFMA)        y[t] = M0+M1+M2, y[t+d] = M1-M2-M3
+// so the matrix pipe does 4/6 of the direct work (k=9: 12/18; k=11: 16/22 and k=7: 12/14 with the zero-padded last group).  The
+// transforms use the points {0, 1, -1, inf} only: coefficients 1 and 1/2, error growth ~2x an fp32 dot product.
+// Same skeleton as conv_mfma_kernel: activations staged once per 16-channel chunk in LDS (the V's are formed per
+// wave from four shifted LDS reads: 1 ds_read + 1 VALU per MFMA), weights as fragments from L2 through a 3-deep
+// register ring, LDS-transposed vector epilogue.  A wave owns 32 rows x PW "pair columns" (c -> outputs t(c), t(c)+d
+// with t(c) = (c / d) * 2d + c % d, a contiguous run of 2*PW outputs when d divides PW) x 4 xi = 8 accumulator tiles.
+template <int DIL, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(const ConvParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int PW = (64 / DIL) * DIL;         // valid pair columns per wave (of 64)
+    constexpr int NBW = 2 * PW;                  // outputs per wave
+    constexpr int BN = NBW * WAVES_N;
+    constexpr int MAXW = BN + MAX_SPAN;
+    constexpr int RPW = CK / NW;
+    constexpr int CIT = (MAXW + 63) / 64;
+    constexpr int CWP = NBW + 8;                 // row pitch of the epilogue transposition buffer (+ dump columns)
+    static_assert(CK % NW == 0, "CK must be a multiple of the wave count");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M;
+    const int wn = wave / WAVES_M;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * BN;
+    const int mt0 = blockIdx.y * WAVES_M + wm;
+    const int W = p.W;
+    const int G = p.KT;                          // tap groups
+    // LDS row: dilation 1 -> even columns of the window at [0, Wh), odd columns at [H, H + Wh), H = 16 mod 32 (the staging
+    // writes of a half-wave then cover all 32 banks); otherwise the window as it is.
+    const int Wh = (W + 1) >> 1;
+    const int H = ((Wh + 15) & ~31) + 16;
+    const int RP = (DIL == 1) ? H + Wh : W;
+    float *const buf0 = smem;
+    float *const buf1 = smem + CK * RP;
+    const float *const xb = p.x + (long long)b * p.x_bs;
+    const float *const maskb = p.mask ? p.mask + (long long)b * p.Tin : nullptr;
+    const int lhalf = lane >> 5;
+    const int l31 = lane & 31;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // pair column -> first output of the pair, relative to the wave's first output
+    int posr[2], posw[2];
+    bool cvalid[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = j * 32 + l31;
+        cvalid[j] = c < PW;
+        const int t = (c / DIL) * (2 * DIL) + (c % DIL);
+        posr[j] = cvalid[j] ? t : 0;         // idle columns read a valid LDS address
+        posw[j] = cvalid[j] ? t : NBW;       // and write to the dump columns of the transposition buffer
+    }
+
+    float st[RPW][CIT];
+    float mk[CIT];
+    const int in_act = p.in_act;
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.Cin * p.Tin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t msrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(maskb ? maskb : xb), 0, p.Tin * 4, 0x00020000);
+    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
+        const int nbase = n0 + p.lo + lane;
+        if (in_act >= VS_IN_MASK) {
+#pragma unroll
+            for (int i = 0; i < CIT; ++i)
+                mk[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msrc, nbase * 4 + i * 256, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int ci = min(chunk * CK + wave + NW * j, p.Cin - 1);
+            const int voff = (ci * p.Tin + nbase) * 4;
+#pragma unroll
+            for (int i = 0; i < CIT; ++i)
+                st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
+        }
+    };
+    auto stage_store = [&](float *buf, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CIT; ++i) {
+            const int col = lane + 64 * i;
+            const int n = n0 + p.lo + col;
+            const bool okn = (n >= 0) && (n < p.Tin);
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const bool ok = okn && (chunk * CK + wave + NW * j < p.Cin);
+                float v = ok ? st[j][i] : 0.f;
+                v = (in_act == VS_IN_LRELU || in_act == VS_IN_LRELU_MASK) ? lrelu(v) : v;
+                v = (in_act >= VS_IN_MASK) ? v * mk[i] : v;
+                const int idx = (DIL == 1) ? ((col & 1) ? H : 0) + (col >> 1) : col;
+                if (col < W) buf[(wave + NW * j) * RP + idx] = v;
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------ main loop
+    // step s = ((chunk * G + g) * 2 + half): 4 channel pairs x 4 xi x 2 pair tiles = 32 MFMAs on 16 weight fragments,
+    // which are contiguous in the packed array (one base pointer, immediate offsets).
+    const int nsteps = p.nchunks * G * 2;
+    // (the four xi fragments of a channel pair are interleaved per lane: one 16-byte load each, 1 KiB per wave-instruction)
+    const float *const wbase = p.wp + (long long)mt0 * nsteps * (16 * 64) + lane * 4;
+    float a0[16], a1[16], a2[16];
+    auto load_a = [&](float (&dst)[16], int step_) __attribute__((always_inline)) {
+        const float *src = wbase + (long long)step_ * (16 * 64);
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+            const float4 t = *reinterpret_cast<const float4 *>(src + cp * 256);
+            dst[cp * 4 + 0] = t.x; dst[cp * 4 + 1] = t.y; dst[cp * 4 + 2] = t.z; dst[cp * 4 + 3] = t.w;
+        }
+    };
+    // ring depth: 3 slots (fragments requested two half-steps ahead), 2 for the widest workgroup shape (its 36 staging
+    // registers do not leave room for the third slot)
+    constexpr int RING = (WAVES_N == 4) ? 2 : 3;
+    if (nsteps > 0) load_a(a0, 0);
+    if (RING == 3 && nsteps > 1) load_a(a1, 1);
+
+    stage_load(0);
+    stage_store(buf0, 0);
+    if (p.nchunks > 1) stage_load(1);
+    __syncthreads();
+
+    int chunk = 0, g = 0, half = 0, s = 0;
+    auto step = [&](float (&acur)[16], float (&apre)[16]) __attribute__((always_inline)) {
+        const float *cur = (chunk & 1) ? buf1 : buf0;
+        if (s + (RING - 1) < nsteps && !((p.dbg & 1) && s > 3)) load_a(apre, s + (RING - 1));
+        if (g == 0 && half == 0) {
+            if (chunk + 1 < p.nchunks && !(p.dbg & 2)) stage_store((chunk & 1) ? buf0 : buf1, chunk + 1);
+            if (chunk + 2 < p.nchunks && !(p.dbg & 2)) stage_load(chunk + 2);
+        }
+        const float *xq[4];
+        {
+            const float *rowp = cur + (half * 8 + lhalf) * RP;
+            const int t3 = 3 * g;
+            if constexpr (DIL == 1) {
+                const int ga = (t3 & 1) ? H + (t3 >> 1) : (t3 >> 1);             // x0, x2
+                const int gb = (t3 & 1) ? ((t3 + 1) >> 1) : H + (t3 >> 1);       // x1, x3
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int e = wn * PW + (posr[j] >> 1);
+                    xq[2 * j] = rowp + e + ga;
+                    xq[2 * j + 1] = rowp + e + gb;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    xq[2 * j] = rowp + wn * NBW + posr[j] + t3 * DIL;
+                    xq[2 * j + 1] = xq[2 * j] + DIL;
+                }
+            }
+        }
+        wino_half_step<DIL>(acc, acur, xq[0], xq[1], xq[2], xq[3], RP);
+        ++s;
+        if (++half == 2) {
+            half = 0;
+            if (++g == G) {
+                __syncthreads();
+                g = 0;
+                ++chunk;
+            }
+        }
+    };
+    if constexpr (RING == 3) {
+        while (s < nsteps) {
+            step(a0, a2);
+            if (s < nsteps) step(a1, a0);
+            if (s < nsteps) step(a2, a1);
+        }
+    } else {
+        while (s < nsteps) {       // nsteps is even
+            step(a0, a1);
+            step(a1, a0);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------- epilogue
+    // output transform in place: acc[0] <- y[t(c)], acc[3] <- y[t(c) + d]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m1 = acc[1][j][r], m2 = acc[2][j][r];
+            acc[0][j][r] = acc[0][j][r] + m1 + m2;
+            acc[3][j][r] = m1 - m2 - acc[3][j][r];
+        }
+
+    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
+    const OutSpec o = p.out[0];
+    const int tile_row0 = mt0 * 32;
+    const bool has_res = o.res != nullptr, has_acc = o.acc != nullptr;
+    const bool use_mask = (o.out_mask != 0);
+    float *const yb = o.y + (long long)b * o.y_bs;
+    const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
+    const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
+    const int nw = n0 + wn * NBW;                // first output of this wave
+    float badd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = min(tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, p.M - 1);
+        badd[r] = p.biasp[row];
+        if (bbias) badd[r] += bbias[row];
+    }
+
+    if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M)) {
+        constexpr int VEC = (DIL == 1) ? 4 : 2;
+        constexpr int LPR = NBW / VEC;           // lanes per row
+        constexpr int RPI = 64 / LPR;            // rows per wave-instruction
+        constexpr int NIT = 8 / RPI;
+        typedef float vecf __attribute__((ext_vector_type(VEC)));
+        float *const Lw = smem + wave * 8 * CWP;
+        const int lrow = lane / LPR;
+        const int cv = (lane % LPR) * VEC;
+        const bool active = lane < LPR * RPI;
+        const int colg = nw + cv;
+        vecf mv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) mv[e] = 1.f;
+        if (use_mask && active) mv = *reinterpret_cast<const vecf *>(maskb + colg);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            vecf r4[NIT], a4[NIT];
+            long long goff[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                goff[it] = (long long)(tile_row0 + 8 * ps + it * RPI + lrow) * p.Tout + colg;
+                if (active) {
+                    if (has_res) r4[it] = *reinterpret_cast<const vecf *>(resp + goff[it]);
+                    if (has_acc) a4[it] = *reinterpret_cast<const vecf *>(accp + goff[it]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float y0 = acc[0][j][4 * ps + q] + badd[4 * ps + q], y1 = acc[3][j][4 * ps + q] + badd[4 * ps + q];
+                    if constexpr (DIL == 1) {      // the pair is adjacent: one 8-byte write, unit stride across lanes
+                        *reinterpret_cast<float2 *>(Lw + (q + 4 * lhalf) * CWP + posw[j]) = make_float2(y0, y1);
+                    } else {
+                        Lw[(q + 4 * lhalf) * CWP + posw[j]] = y0;
+                        Lw[(q + 4 * lhalf) * CWP + posw[j] + DIL] = y1;
+                    }
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    vecf v = *reinterpret_cast<const vecf *>(Lw + (it * RPI + lrow) * CWP + cv);
+                    if (has_res) v += r4[it];
+                    if (has_acc) v += a4[it];
+                    v *= o.scale;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if (o.out_act == VS_OUT_TANH) v[e] = tanh_fast(v[e]);
+                        else if (o.out_act == VS_OUT_RELU) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    v *= mv;
+                    *reinterpret_cast<vecf *>(yb + goff[it]) = v;
+                }
+            }
+        }
+    } else {
+        // edge workgroups (ragged last time tile): element-wise, predicated stores, clamped loads
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int col = nw + posr[j] + hh * DIL;
+                const bool okc = cvalid[j] && (col < p.N);
+                const int colc = min(col, p.Tout - 1);
+                const float mval = use_mask ? maskb[colc] : 1.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    const int rowc = min(row, p.M - 1);
+                    const long long off = (long long)rowc * p.Tout + colc;
+                    float v = (hh == 0 ? acc[0][j][r] : acc[3][j][r]) + badd[r];
+                    if (has_res) v += resp[off];
+                    if (has_acc) v += accp[off];
+                    v *= o.scale;
+                    if (o.out_act == VS_OUT_TANH) v = tanh_fast(v);
+                    else if (o.out_act == VS_OUT_RELU) v = fmaxf(v, 0.f);
+                    v *= mval;
+                    if (okc && row < p.M) yb[off] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight-norm row scales and packing
 
@@ -599,6 +952,40 @@ __global__ void pack_conv_kernel(const PackParams q) {
                 }
             }
         }
+    }
+    q.wp[e] = val;
+}
+
+// Winograd F(2,3) weight transform + fragment packing for conv_wino_kernel:
+//   Up[m_tile][chunk][group][half][ci_pair(4)][64 lanes][xi(4)], lane l <-> (row m_tile*32 + (l&31), ci = chunk*16 + half*8 +
+//   2*ci_pair + (l>>5)); taps beyond k are zeros (the last group of k = 7 / 11 is partial).
+__global__ void pack_wino_kernel(const PackParams q, int G, int nchunks) {
+    const long long total = (long long)q.MT_alloc * nchunks * G * 2 * 16 * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int xi = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const int cp4 = (int)((e >> 8) & 3);
+    long long t = e >> 10;
+    const int half = (int)(t & 1);
+    t >>= 1;
+    const int g = (int)(t % G);
+    t /= G;
+    const int chunk = (int)(t % nchunks);
+    const int mt = (int)(t / nchunks);
+    const int m = mt * 32 + (lane & 31);
+    int ci = chunk * CK + half * 8 + cp4 * 2 + (lane >> 5);
+    float val = 0.f;
+    if (m < q.c_out && ci < q.c_in) {
+        if (q.flags & VS_CONV_FLIP_IN) ci = q.c_in - 1 - ci;
+        const int row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
+        const float sc = q.scale ? q.scale[row] : 1.f;
+        const float *wr = q.w + ((long long)row * q.c_in + ci) * q.k;
+        const int k0 = 3 * g;
+        const float w0 = (k0 < q.k) ? wr[k0] * sc : 0.f;
+        const float w1 = (k0 + 1 < q.k) ? wr[k0 + 1] * sc : 0.f;
+        const float w2 = (k0 + 2 < q.k) ? wr[k0 + 2] * sc : 0.f;
+        val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
     }
     q.wp[e] = val;
 }
@@ -745,6 +1132,8 @@ struct vs_conv {
     int M, MT, MT_alloc, KT, CP, nchunks, off0, tstep, lo, span, dmin, Hh;
     bool weights_set = false;
     vs::DevBuf wp, biasp, scale, weff, beff;   // weff/beff: unpacked effective weights (c_out <= 4 VALU path)
+    vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), when wino_groups > 0
+    int wino_groups = 0;                       // ceil(k / 3) if the conv is eligible for the F(2,3) path, else 0
     bool has_bias = false;
 };
 
@@ -765,6 +1154,34 @@ static int launch_cfg(const ConvParams &p, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
+}
+
+template <int DIL, int WAVES_M, int WAVES_N>
+static int launch_wino(const ConvParams &p, hipStream_t s) {
+    constexpr int NBW = 2 * ((64 / DIL) * DIL);
+    constexpr int BN = NBW * WAVES_N;
+    auto kern = conv_wino_kernel<DIL, WAVES_M, WAVES_N>;
+    const int Wh = (p.W + 1) >> 1, H = ((Wh + 15) & ~31) + 16;
+    const int RP = (DIL == 1) ? H + Wh : p.W;      // LDS row pitch, as computed by the kernel
+    const size_t lds = sizeof(float) * std::max<size_t>((size_t)2 * CK * RP, (size_t)WAVES_M * WAVES_N * 8 * (NBW + 8));
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, WAVES_M), (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+template <int DIL>
+static int launch_wino_dil(ConvParams &p, int MT, int span_w, hipStream_t s) {
+    constexpr int NBW = 2 * ((64 / DIL) * DIL);
+    if (MT % 4 == 0) { p.W = NBW + span_w; return launch_wino<DIL, 4, 1>(p, s); }
+    if (MT % 2 == 0) { p.W = 2 * NBW + span_w; return launch_wino<DIL, 2, 2>(p, s); }
+    p.W = 4 * NBW + span_w;
+    return launch_wino<DIL, 1, 4>(p, s);
 }
 
 extern "C" {
@@ -841,6 +1258,10 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     h->MT_alloc = (int)ceil_div(h->MT, MT_ALLOC) * MT_ALLOC;
     h->nchunks = (int)ceil_div(c_in, CK);
     h->CP = h->nchunks * (CK / 2);
+    // F(2,3) minimal-filtering path: stride-1 "same" convs with >= 3 taps, dilation 1/3/5, whole 32-row tiles
+    if (kind == VS_CONV1D && k >= 3 && (k & 1) && (dil == 1 || dil == 3 || dil == 5) && pad == dil * (k - 1) / 2 &&
+        c_out % 32 == 0 && 3 * (int)ceil_div(k, 3) * dil <= MAX_SPAN)
+        h->wino_groups = (int)ceil_div(k, 3);
     *out = h;
     return VS_OK;
 }
@@ -875,6 +1296,14 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags;
     const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
+    if (h->wino_groups) {
+        const size_t nw = (size_t)h->MT_alloc * h->nchunks * h->wino_groups * 2 * 16 * 64;
+        VS_TRY(h->wpw.reserve(nw * sizeof(float)));
+        PackParams qw = q;
+        qw.wp = h->wpw.as<float>();
+        hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)ceil_div((long long)nw, 256)), dim3(256), 0, s, qw, h->wino_groups,
+                           h->nchunks);
+    }
     if (h->kind == VS_CONV1D && h->c_out <= 4) {
         const long long cols = (long long)h->c_in * h->k;
         VS_TRY(h->weff.reserve((size_t)h->c_out * cols * sizeof(float)));
@@ -999,6 +1428,24 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         }
         ok = ok && (!p.mask || al16(p.mask)) && (!p.split_row || p.split_row % 32 == 0);
         p.fast_epi = ok ? 1 : 0;
+    }
+    // F(2,3) path where it measured faster than the direct engine (tools/conv_bench.py, B=32 production shapes): every
+    // dilation-1 conv (k=3: +9..17 %, k=7: +0..4 %, k=9: +32..39 %, k=11: +19..21 %) and the k >= 9 convs of >= 64 rows at any
+    // dilation (+3..14 %); the dilated k=3 / k=7 convs lose 2..25 % (idle pair columns, 8-byte epilogue runs, fewer MFMAs
+    // to hide the same staging behind) and stay on the direct engine.  VS_WINO_FORCE=1 / VS_NO_WINO=1: test / A-B switches.
+    const bool wino_pays = (h->dil == 1) || (h->k >= 9 && h->c_out >= 64) || getenv("VS_WINO_FORCE");
+    if (h->wino_groups && wino_pays && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
+        ConvParams q = p;
+        q.wp = h->wpw.as<float>();
+        q.KT = h->wino_groups;
+        q.lo = -h->pad;
+        if (const char *e = getenv("VS_WINO_DBG")) q.dbg = atoi(e);
+        // the vector epilogue stores float4 (dilation 1) / float2 runs: same alignment preconditions as the direct engine's
+        // (Tout % 4 == 0 checked above covers both)
+        const int span_w = 3 * h->wino_groups * h->dil;
+        if (h->dil == 1) return launch_wino_dil<1>(q, h->MT, span_w, s);
+        if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, s);
+        return launch_wino_dil<5>(q, h->MT, span_w, s);
     }
     // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,
     // coupling `pre` and last res/skip convs) AND the launch is short (T_mel-sized): there 64 x 256 blocks waste no MFMA

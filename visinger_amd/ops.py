@@ -2,6 +2,8 @@
 device pointers and the current HIP stream out.  Used by visinger_amd.modules.* and by the GPU parity tests."""
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -72,11 +74,23 @@ class ConvOp:
             return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
         if self.kind == L.CONV1D and self.c_out <= 4:
             return "conv_small_kernel"
+        pays = self.dil == 1 or (self.k >= 9 and self.c_out >= 64) or os.environ.get("VS_WINO_FORCE")
+        if self.wino_eligible() and pays and not os.environ.get("VS_NO_WINO"):
+            mt = self.c_out // 32
+            cfg = "4,1" if mt % 4 == 0 else ("2,2" if mt % 2 == 0 else "1,4")
+            return f"conv_wino_kernel<{self.dil},{cfg}>"
         rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
         mt = -(-rows // 32)
         if mt >= 3:
             return "conv_mfma_kernel<1,8,4,1>"      # (or <1,4,2,2> for short 6-tile launches; same family)
         return "conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>"
+
+    def wino_eligible(self):
+        """mirrors vs_conv_create: stride-1 'same' conv, odd k >= 3, dilation 1/3/5, whole 32-row tiles -> F(2,3) path
+        (taken by vs_conv_forward unless the call splits rows or uses a coupling output mode)"""
+        k, d = self.k, self.dil
+        return (self.kind == L.CONV1D and k >= 3 and k % 2 == 1 and d in (1, 3, 5) and self.pad == d * (k - 1) // 2 and
+                self.c_out % 32 == 0 and 3 * -(-k // 3) * d <= 64)
 
     def algorithmic_flops(self, B, T):
         """2*MAC of the convolution itself (what torch.utils.flop_counter reports for the reference's op)."""
