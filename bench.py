@@ -156,7 +156,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected
     from inside the timed run: they need rocprofv3 and one pass per counter); None when not recorded."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")) as f:
             return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
         return None
@@ -247,7 +247,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(name),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
-                                         "recorded run: profiles/r01_b_pmc_traffic.json)",
+                                         "recorded run: profiles/r01_c_pmc_traffic.json)",
                          "launches_per_step": d["launches"] / args.steps,
                          "avg_launch_ms": d["ms"] / d["launches"],
                          "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
