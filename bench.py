@@ -108,7 +108,7 @@ def cpu_baseline(model, hp, budget_s=12.0, backend="c"):
 
     T = 32
     n, dt = run(T)
-    T2 = int(min(4096, 32 * max(1, 2 ** int(np.log2(max(1.0, budget_s / max(dt, 1e-3)))))))
+    T2 = int(min(1024, 32 * max(1, 2 ** int(np.log2(max(1.0, budget_s / max(dt, 1e-3)))))))   # <= the workload's T_mel (attention is O(T^2))
     if T2 > T:
         T = T2
         n, dt = run(T)

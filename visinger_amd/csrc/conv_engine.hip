@@ -6,9 +6,10 @@
 //
 //     D[m, n] = sum_{tap} sum_{ci}  Wp[tap][m][ci] * f(x[b, ci, n + off(tap)])
 //
-//   * A operand = weights, pre-packed ONCE on the device into fragment order Wp[m_tile][tap][ci_pair][64 lanes]
-//     (lane l holds W[m_tile*32 + (l&31)][2*ci_pair + (l>>5)]) so a wave fetches one fragment with a single
-//     coalesced 256-B load (served by L2/L1: the weights of a conv are <= 3 MB and shared by every workgroup);
+//   * A operand = weights, pre-packed ONCE on the device into fragment order Wp[m_tile][tap][chunk][quad][64 lanes][4]
+//     (lane l holds W[m_tile*32 + (l&31)][2*ci_pair + (l>>5)] for the four ci_pairs of the quad) so a wave fetches four
+//     fragments with one coalesced 1-KiB load (served by L2/L1: the weights of a conv are <= 3 MB and shared by every
+//     workgroup);
 //   * B operand = activations, staged ONCE per (ci-chunk, time tile + halo) into LDS as Xs[ci][n]; every tap reads
 //     a shifted window of the same LDS rows (conflict-free ds_read_b32: 32 consecutive dwords per half-wave), so
 //     HBM/L2 sees each activation once per M-block no matter how many taps the conv has;
@@ -185,20 +186,40 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
                 st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
         }
     };
+    // The zero-fill of the halo only exists in the first / last time tiles and in a partial last channel chunk, and the input
+    // transform is one of four: both are wave-uniform, so the per-element work of the common case (interior tile, leaky-relu)
+    // is mul + max + ds_write instead of compare / select / compare / select / multiply-select / predicated write.
+    const bool time_edge = (n0 + p.lo < 0) || (n0 + p.lo + W > p.Tin);
     auto stage_store = [&](float *buf, int chunk) __attribute__((always_inline)) {
+        auto run = [&](auto edge_tag, auto act_tag) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int i = 0; i < CIT; ++i) {
-            const int col = lane + 64 * i;
-            const int n = n0 + p.lo + col;
-            const bool okn = (n >= 0) && (n < p.Tin);
+            for (int i = 0; i < CIT; ++i) {
+                const int col = lane + 64 * i;
+                const int n = n0 + p.lo + col;
+                const bool okn = (n >= 0) && (n < p.Tin);
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                const bool ok = okn && (chunk * CK + wave + NW * j < p.Cin);
-                float v = ok ? st[j][i] : 0.f;
-                v = (in_act == VS_IN_LRELU || in_act == VS_IN_LRELU_MASK) ? lrelu(v) : v;
-                v = (in_act >= VS_IN_MASK) ? v * mk[i] : v;
-                if (col < W) buf[(wave + NW * j) * W + col] = v;
+                for (int j = 0; j < RPW; ++j) {
+                    float v = st[j][i];
+                    if constexpr (EDGE) v = (okn && (chunk * CK + wave + NW * j < p.Cin)) ? v : 0.f;
+                    if constexpr (ACT == VS_IN_LRELU || ACT == VS_IN_LRELU_MASK) v = fmaxf(v, 0.1f * v);
+                    if constexpr (ACT >= VS_IN_MASK) v *= mk[i];
+                    if (64 * (i + 1) <= BN || col < W) buf[(wave + NW * j) * W + col] = v;      // W >= BN
+                }
             }
+        };
+        const bool edge = time_edge || (chunk * CK + CK > p.Cin);
+        if (edge) {
+            if (in_act == VS_IN_NONE) run(std::true_type{}, std::integral_constant<int, VS_IN_NONE>{});
+            else if (in_act == VS_IN_LRELU) run(std::true_type{}, std::integral_constant<int, VS_IN_LRELU>{});
+            else if (in_act == VS_IN_MASK) run(std::true_type{}, std::integral_constant<int, VS_IN_MASK>{});
+            else run(std::true_type{}, std::integral_constant<int, VS_IN_LRELU_MASK>{});
+        } else {
+            if (in_act == VS_IN_NONE) run(std::false_type{}, std::integral_constant<int, VS_IN_NONE>{});
+            else if (in_act == VS_IN_LRELU) run(std::false_type{}, std::integral_constant<int, VS_IN_LRELU>{});
+            else if (in_act == VS_IN_MASK) run(std::false_type{}, std::integral_constant<int, VS_IN_MASK>{});
+            else run(std::false_type{}, std::integral_constant<int, VS_IN_LRELU_MASK>{});
         }
     };
 
@@ -222,14 +243,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     const int nsteps = p.nchunks * ntaps;
     const float *wbase[MT_W];
 #pragma unroll
-    for (int i = 0; i < MT_W; ++i) wbase[i] = p.wp + (long long)(mt0 + i) * p.KT * p.CP * 64 + lane;
+    for (int i = 0; i < MT_W; ++i) wbase[i] = p.wp + (long long)(mt0 + i) * p.KT * p.CP * 64 + lane * 4;
     float a0[MT_W][CK / 2], a1[MT_W][CK / 2], a2[MT_W][CK / 2];
+    // (the 8 fragments of a step are stored as two lane-interleaved quads: two 16-byte loads, 1 KiB per wave-instruction)
     auto load_a = [&](float (&dst)[MT_W][CK / 2], int chunk, int tap) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < MT_W; ++i)
+        for (int i = 0; i < MT_W; ++i) {
+            const float *src = wbase[i] + ((long long)tap * p.nchunks + chunk) * (CK / 2) * 64;
 #pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp)
-                dst[i][cp] = wbase[i][((long long)tap * p.CP + chunk * (CK / 2) + cp) * 64];
+            for (int qd = 0; qd < 2; ++qd) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + qd * 256);
+                dst[i][qd * 4 + 0] = t.x; dst[i][qd * 4 + 1] = t.y; dst[i][qd * 4 + 2] = t.z; dst[i][qd * 4 + 3] = t.w;
+            }
+        }
     };
     // (chunk, tap) of the step two ahead of the current one
     int pc = 0, pt = tap_b;
@@ -653,21 +679,38 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
                 st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
         }
     };
+    const bool time_edge = (n0 + p.lo < 0) || (n0 + p.lo + W > p.Tin);
     auto stage_store = [&](float *buf, int chunk) __attribute__((always_inline)) {
+        auto run = [&](auto edge_tag, auto act_tag) __attribute__((always_inline)) {   // (see conv_mfma_kernel)
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int i = 0; i < CIT; ++i) {
-            const int col = lane + 64 * i;
-            const int n = n0 + p.lo + col;
-            const bool okn = (n >= 0) && (n < p.Tin);
-#pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                const bool ok = okn && (chunk * CK + wave + NW * j < p.Cin);
-                float v = ok ? st[j][i] : 0.f;
-                v = (in_act == VS_IN_LRELU || in_act == VS_IN_LRELU_MASK) ? lrelu(v) : v;
-                v = (in_act >= VS_IN_MASK) ? v * mk[i] : v;
+            for (int i = 0; i < CIT; ++i) {
+                const int col = lane + 64 * i;
+                const int n = n0 + p.lo + col;
+                const bool okn = (n >= 0) && (n < p.Tin);
                 const int idx = (DIL == 1) ? ((col & 1) ? H : 0) + (col >> 1) : col;
-                if (col < W) buf[(wave + NW * j) * RP + idx] = v;
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    float v = st[j][i];
+                    if constexpr (EDGE) v = (okn && (chunk * CK + wave + NW * j < p.Cin)) ? v : 0.f;
+                    if constexpr (ACT == VS_IN_LRELU || ACT == VS_IN_LRELU_MASK) v = fmaxf(v, 0.1f * v);
+                    if constexpr (ACT >= VS_IN_MASK) v *= mk[i];
+                    if (64 * (i + 1) <= BN || col < W) buf[(wave + NW * j) * RP + idx] = v;      // W >= BN
+                }
             }
+        };
+        const bool edge = time_edge || (chunk * CK + CK > p.Cin);
+        if (edge) {
+            if (in_act == VS_IN_NONE) run(std::true_type{}, std::integral_constant<int, VS_IN_NONE>{});
+            else if (in_act == VS_IN_LRELU) run(std::true_type{}, std::integral_constant<int, VS_IN_LRELU>{});
+            else if (in_act == VS_IN_MASK) run(std::true_type{}, std::integral_constant<int, VS_IN_MASK>{});
+            else run(std::true_type{}, std::integral_constant<int, VS_IN_LRELU_MASK>{});
+        } else {
+            if (in_act == VS_IN_NONE) run(std::false_type{}, std::integral_constant<int, VS_IN_NONE>{});
+            else if (in_act == VS_IN_LRELU) run(std::false_type{}, std::integral_constant<int, VS_IN_LRELU>{});
+            else if (in_act == VS_IN_MASK) run(std::false_type{}, std::integral_constant<int, VS_IN_MASK>{});
+            else run(std::false_type{}, std::integral_constant<int, VS_IN_LRELU_MASK>{});
         }
     };
 
@@ -917,12 +960,17 @@ __global__ void pack_conv_kernel(const PackParams q) {
         q.biasp[m] = bv;
     }
     if (e >= total) return;
-    const int lane = (int)(e & 63);
-    long long t = e >> 6;
-    const int cp = (int)(t % q.CP);
-    t /= q.CP;
+    // Wp[m_tile][tap][chunk][quad(2)][64 lanes][4]: lane l of quad qd holds channel pairs chunk*8 + qd*4 + (0..3)
+    const int sub = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const int quad = (int)((e >> 8) & 1);
+    long long t = e >> 9;
+    const int nchunks = q.CP / (CK / 2);
+    const int chunk = (int)(t % nchunks);
+    t /= nchunks;
     const int tap = (int)(t % q.KT);
     const int mt = (int)(t / q.KT);
+    const int cp = chunk * (CK / 2) + quad * 4 + sub;
     const int m = mt * 32 + (lane & 31);
     int ci = cp * 2 + (lane >> 5);
     float val = 0.f;
@@ -1429,12 +1477,14 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         ok = ok && (!p.mask || al16(p.mask)) && (!p.split_row || p.split_row % 32 == 0);
         p.fast_epi = ok ? 1 : 0;
     }
-    // F(2,3) path where it measured faster than the direct engine (tools/conv_bench.py, B=32 production shapes): every
-    // dilation-1 conv (k=3: +9..17 %, k=7: +0..4 %, k=9: +32..39 %, k=11: +19..21 %) and the k >= 9 convs of >= 64 rows at any
-    // dilation (+3..14 %); the dilated k=3 / k=7 convs lose 2..25 % (idle pair columns, 8-byte epilogue runs, fewer MFMAs
-    // to hide the same staging behind) and stay on the direct engine.  VS_WINO_FORCE=1 / VS_NO_WINO=1: test / A-B switches.
-    const bool wino_pays = (h->dil == 1) || (h->k >= 9 && h->c_out >= 64) || getenv("VS_WINO_FORCE");
-    if (h->wino_groups && wino_pays && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
+    // F(2,3) path where it measured faster than the direct engine (tools/conv_bench.py, B=32 production shapes): with an even
+    // number of 32-row tiles every dilation-1 conv (k=3: +10..17 %, k=7: +0..2 %, k=9: +36..44 %, k=11: +21..25 %) and the
+    // k >= 9 convs at any dilation (+7..16 %); with an odd tile count (C_out = 32: the 32 x 512 workgroup shape, 2-slot
+    // fragment ring) only k >= 9 at dilation 1 (+10 %).  The dilated k=3 / k=7 convs lose 2..25 % (idle pair columns, 8-byte
+    // epilogue runs, fewer MFMAs to hide the same staging behind) and stay on the direct engine.
+    // VS_WINO_FORCE=1 / VS_NO_WINO=1: test / A-B switches.
+    const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9);
+    if (h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
         ConvParams q = p;
         q.wp = h->wpw.as<float>();
         q.KT = h->wino_groups;

@@ -74,7 +74,9 @@ class ConvOp:
             return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
         if self.kind == L.CONV1D and self.c_out <= 4:
             return "conv_small_kernel"
-        pays = self.dil == 1 or (self.k >= 9 and self.c_out >= 64) or os.environ.get("VS_WINO_FORCE")
+        odd = (self.c_out // 32) % 2 == 1
+        pays = (self.k >= 9 and self.dil == 1) if odd else (self.dil == 1 or self.k >= 9)
+        pays = pays or os.environ.get("VS_WINO_FORCE")
         if self.wino_eligible() and pays and not os.environ.get("VS_NO_WINO"):
             mt = self.c_out // 32
             cfg = "4,1" if mt % 4 == 0 else ("2,2" if mt % 2 == 0 else "1,4")
