@@ -100,3 +100,31 @@ def test_full_gan_training_step_runs_and_updates():
                              global_step=2)
     raw, _ = ckpt.read_checkpoint(p)
     assert set(raw["state_dict"]) == {"model", "mel_disc"} and len(raw["optimizer_states"]) == 2
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,K,d_or_u,T", [("conv", 24, 40, 5, 1, 77), ("conv", 32, 32, 7, 3, 130), ("conv", 16, 48, 1, 1, 50),
+                                                      ("conv", 32, 32, 11, 5, 200), ("tconv", 32, 16, 8, 4, 37), ("tconv", 24, 12, 11, 5, 20),
+                                                      ("tconv", 16, 16, 4, 2, 64), ("tconv", 64, 32, 16, 8, 9), ("tconv", 20, 10, 7, 3, 15)])
+def test_conv_backward_matches_aten(kind, Cin, Cout, K, d_or_u, T):
+    """HIP-engine grad-input + GEMM grad-weight (visinger_amd.autograd.conv_backward) vs aten::convolution_backward (fp32)."""
+    from visinger_amd.autograd import conv_backward
+    from visinger_amd.modules.hipconv import HipConv1d, HipConvTranspose1d
+    torch.manual_seed(K * 100 + T)
+    B = 3
+    if kind == "conv":
+        m = HipConv1d(Cin, Cout, K, dilation=d_or_u, padding=d_or_u * (K - 1) // 2).cuda()
+        w = torch.randn(Cout, Cin, K, device="cuda") / (Cin * K) ** 0.5
+        y_shape = (B, Cout, T)
+        args = ([1], [m.padding[0]], [d_or_u], False)
+    else:
+        m = HipConvTranspose1d(Cin, Cout, K, d_or_u, padding=(K - d_or_u) // 2).cuda()
+        w = torch.randn(Cin, Cout, K, device="cuda") / (Cin * K) ** 0.5
+        y_shape = (B, Cout, (T - 1) * d_or_u - 2 * m.padding[0] + K)
+        args = ([d_or_u], [m.padding[0]], [1], True)
+    x = torch.randn(B, Cin, T, device="cuda")
+    gy = torch.randn(*y_shape, device="cuda")
+    gx, gw = conv_backward(m, x, w, gy, True, True)
+    rx, rw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, args[0], args[1], args[2], args[3], [0], 1, [True, True, False])
+    for got, ref in ((gx, rx), (gw, rw)):
+        assert got.shape == ref.shape
+        assert float((got - ref).abs().max()) <= 2e-5 * (1.0 + float(ref.abs().max()))

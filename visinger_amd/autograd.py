@@ -3,9 +3,9 @@
 Forward: every convolution still runs on the HIP conv engine (``HipConvFn``: the folded weight is re-packed each step
 because it changes each step); the elementwise neighbours that the inference path fuses into the conv epilogues
 (gates, residuals, masks, coupling updates, LayerNorm) and the attention core run as PyTorch-ROCm ops so that
-autograd records them.  Backward: PyTorch-ROCm ops throughout -- the conv backward recomputes the op with
-``torch.nn.functional`` under ``enable_grad`` and differentiates that (training throughput is not the benchmark
-metric; backward HIP kernels are the next stage).  The arithmetic restated here follows the same reference lines as the
+autograd records them.  Backward: the conv grad-input runs on the HIP conv engine again (`conv_backward`: correlation
+with the reversed / transposed weight; transposed convs through their de-interleaved phases), the conv grad-weight is a
+library batched GEMM over shifted windows, everything else is PyTorch-ROCm autograd -- no MIOpen on the generator side.  The arithmetic restated here follows the same reference lines as the
 inference modules; `tests/test_train_gpu.py` checks train-mode forward == eval-mode (fused HIP) forward and the
 gradients against the reference's own autograd (golden vectors).
 """
@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
+from .ops import ConvOp
 
 LRELU_SLOPE = 0.1
 
@@ -36,22 +37,69 @@ class HipConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, b = ctx.saved_tensors
-        m = ctx.module
         need = ctx.needs_input_grad
-        with torch.enable_grad():
-            x_ = x.detach().requires_grad_(need[0])
-            w_ = w.detach().requires_grad_(need[1])
-            b_ = b.detach().requires_grad_(need[2]) if ctx.has_bias else None
-            if m._kind == L.CONV_TRANSPOSE1D:
-                y = F.conv_transpose1d(x_, w_, b_, stride=m.stride, padding=m.padding)
-            else:
-                y = F.conv1d(x_, w_, b_, stride=1, padding=m.padding, dilation=m.dilation)
-            wanted = [t for t, n in ((x_, need[0]), (w_, need[1]), (b_, need[2] and ctx.has_bias)) if n]
-            grads = list(torch.autograd.grad(y, wanted, gy.contiguous())) if wanted else []
-        out = []
-        for n in (need[0], need[1], need[2] and ctx.has_bias):
-            out.append(grads.pop(0) if n else None)
-        return out[0], out[1], out[2], None
+        gy = gy.contiguous()
+        gx, gw = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]))
+        gb = gy.sum((0, 2)) if (need[2] and ctx.has_bias) else None
+        return gx, gw, gb, None
+
+
+def _bwd_op(module, key, *args):
+    """ConvOp handles of the backward-data convs, cached on the module next to the forward ones"""
+    ops = module.__dict__.setdefault("_hip_bwd_ops", {})
+    if key not in ops:
+        ops[key] = ConvOp(*args)
+    return ops[key]
+
+
+def conv_backward(m, x, w, gy, need_x, need_w):
+    """Gradients of y = conv(x, w) for a HipConv1d / HipConvTranspose1d `m` (stride-1 dilated conv, or stride-u transposed
+    conv), MIOpen-free:
+
+    * grad-input runs on the HIP conv engine itself: for a conv it is the correlation of gy with the tap-reversed,
+      channel-transposed weight (padding d(K-1) - p); for a transposed conv the stride-u gather
+      gx[ci, m] = sum_{co,k} w[ci,co,k] gy[co, m u - p + k] becomes a stride-1 conv over the u de-interleaved phases of gy
+      stacked as u*C_out input channels with ceil(K/u) taps;
+    * grad-weight is a plain contraction over (batch, time) of gy with the K shifted windows of x: one library (rocBLAS)
+      batched GEMM per conv through torch.einsum on a strided window view -- "plain library GEMM" territory.
+    """
+    B, Cin, T = x.shape
+    K = w.shape[2]
+    gx = gw = None
+    if m._kind != L.CONV_TRANSPOSE1D:
+        Cout, d, p = w.shape[0], m.dilation[0], m.padding[0]
+        Tout = gy.shape[2]
+        if need_x:
+            pb = d * (K - 1) - p
+            assert pb >= 0, "conv backward-data: padding larger than the receptive field is not supported"
+            op = _bwd_op(m, "dx", L.CONV1D, Cout, Cin, K, d, pb, 0)
+            op.set_weights(w.detach().flip(2).transpose(0, 1).contiguous(), None, None)
+            gx = op.forward(gy)
+        if need_w:
+            xp = F.pad(x, (p, p)) if p else x
+            Tp = xp.shape[2]
+            win = xp.as_strided((B, Cin, K, Tout), (Cin * Tp, Tp, d, 1))            # win[b,i,k,t] = xp[b,i,t + k d]
+            gw = torch.einsum("bot,bikt->oik", gy, win)
+    else:
+        Cout, u, p = w.shape[1], m.stride[0], m.padding[0]
+        Q = -(-K // u)
+        n_out = gy.shape[2]
+        Mq = T + Q - 1
+        # gyp[n'] = gy[n' - p], zero elsewhere, on n' in [0, Mq u);  G[b, r*Cout + co, j] = gyp[b, co, j u + r]
+        right = Mq * u - p - n_out
+        gyp = F.pad(gy, (p, max(right, 0)))[:, :, :Mq * u]
+        G = gyp.view(B, Cout, Mq, u).permute(0, 3, 1, 2).reshape(B, u * Cout, Mq)
+        if need_x:
+            wq = F.pad(w.detach(), (0, Q * u - K)).view(Cin, Cout, Q, u).permute(0, 3, 1, 2).reshape(Cin, u * Cout, Q)
+            op = _bwd_op(m, "dx", L.CONV1D, u * Cout, Cin, Q, 1, 0, 0)
+            op.set_weights(wq.contiguous(), None, None)
+            gx = op.forward(G.contiguous())                                             # [B, Cin, Mq - Q + 1 = T]
+        if need_w:
+            Gc = G.contiguous()
+            win = Gc.as_strided((B, u * Cout, Q, T), (u * Cout * Mq, Mq, 1, 1))        # win[b,j,q,m] = G[b,j,m + q]
+            g2 = torch.einsum("bim,bjqm->ijq", x, win)                                   # [Cin, u*Cout, Q]
+            gw = g2.view(Cin, u, Cout, Q).permute(0, 2, 3, 1).reshape(Cin, Cout, Q * u)[:, :, :K].contiguous()
+    return gx, gw
 
 
 def effective_weight(m):
