@@ -105,3 +105,22 @@ def test_long_form_T4096(oracle):
     assert maxerr(ye, ref_e) <= 1e-4
     assert peak < 2 * T * T * 4, f"attention must not materialise [T, T] scores (peak {peak} B)"
     assert float(((xr - cu(x)) * cu(mask)).abs().max()) <= 2e-4
+
+
+def test_config5_width_hidden512_heads2(oracle):
+    """BASELINE config-5 width in fp32: hidden 512, 2 heads (256 channels per head: wider than the streaming attention kernel's
+    register-resident query tile -> HIP q/k/v/o convs + PyTorch-ROCm [T, T] core), FFN 2048 with k=9 (F(2,3) conv path), on
+    a ragged batch, against the fp64 oracle."""
+    from visinger_amd.modules.rel_transformer import RelativeEncoder
+    T, C = 333, 512
+    enc = RelativeEncoder(C, 2048, 2, 1, kernel_size=9)
+    sde = _rand_sd(enc, 9)
+    enc = enc.cuda().eval()
+    r = np.random.default_rng(512)
+    x = r.standard_normal((2, C, T)).astype(np.float32)
+    mask = np.ones((2, 1, T), np.float32)
+    mask[1, :, 200:] = 0
+    ref = oracle.rel_encoder(sde, x, mask, None, n_heads=2, n_layers=1, kernel_size=9)
+    with torch.no_grad():
+        y = enc(cu(x), cu(mask))
+    assert maxerr(y, ref) <= 1e-4
