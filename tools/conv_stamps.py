@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visinger_amd import _lib as L
 from visinger_amd.ops import ConvOp
 
-C, k, d, T, B = int(os.environ.get("C", 128)), int(os.environ.get("K", 3)), 1, int(os.environ.get("T", 65536)), int(os.environ.get("B", 32))
+C, k, d, T, B = int(os.environ.get("C", 128)), int(os.environ.get("K", 3)), int(os.environ.get("D", 1)), int(os.environ.get("T", 65536)), int(os.environ.get("B", 32))
 op = ConvOp(L.CONV1D, C, C, k, d, (k * d - d) // 2)
 op.set_weights(torch.randn(C, C, k, device="cuda") * 0.05, None, torch.randn(C, device="cuda"))
 x = torch.randn(B, C, T, device="cuda"); y = torch.empty_like(x); res = torch.randn_like(x)
@@ -30,8 +30,18 @@ t0 = s[:, 0].min()
 st = (s[:, :4] - t0) / 100.0     # us
 print("workgroups", len(s), "launch span %.1f us" % st[:, 3].max())
 pro, main, epi = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
-for name, v in (("prologue", pro), ("main", main), ("epilogue", epi), ("total", st[:, 3] - st[:, 0])):
+issued = (s[:, 6] - s[:, 2]) / 100.0 if (s[:, 6] != 0).all() else epi * 0
+print("kernel:", op.kernel_instance())
+for name, v in (("prologue", pro), ("main", main), ("epilogue", epi), ("epi-issue", issued), ("total", st[:, 3] - st[:, 0])):
     print(f"{name:9s} mean {v.mean():8.2f}  p10 {np.percentile(v,10):8.2f}  p50 {np.percentile(v,50):8.2f}  p90 {np.percentile(v,90):8.2f}  max {v.max():8.2f} us")
+if (full[:, 8] != 0).all():
+    names = {8: "xform+bias issued", 9: "res loads issued", 10: "pass0 LDS written", 11: "pass0 stored", 12: "pass1 stored", 13: "pass2 stored", 6: "pass3 stored"}
+    prev = full[:, 2]
+    for slot in (8, 9, 10, 11, 12, 13, 6):
+        if (full[:, slot] != 0).all():
+            dlt = (full[:, slot] - prev) / 100.0
+            print(f"   epilogue +{names[slot]:20s} mean {dlt.mean():6.2f}  p50 {np.percentile(dlt,50):6.2f}  p90 {np.percentile(dlt,90):6.2f} us")
+            prev = full[:, slot]
 cyc = (s[:, 5] - s[:, 4]).astype(np.float64)
 print("main-loop shader cycles: mean %.0f ; implied clock %.3f GHz" % (cyc.mean(), (cyc / (main * 1e3)).mean()))
 hw = s[:, 7] & 0xffffffff
@@ -47,6 +57,12 @@ ts = np.linspace(0, st[:, 3].max(), 400)
 in_epi = [(np.logical_and(st[:, 2] <= t, st[:, 3] > t)).sum() for t in ts]
 in_main = [(np.logical_and(st[:, 1] <= t, st[:, 2] > t)).sum() for t in ts]
 print("in-epilogue count: mean %.1f max %d ; in-main mean %.1f" % (np.mean(in_epi), np.max(in_epi), np.mean(in_main)))
+ts2 = np.linspace(0, st[:, 3].max(), 4000)
+ie = np.array([(np.logical_and(st[:, 2] <= t, st[:, 3] > t)).sum() for t in ts2])
+for lo, hi in ((0.0, 0.1), (0.3, 0.4), (0.6, 0.7), (0.85, 0.95)):
+    seg = ie[int(lo * len(ie)):int(hi * len(ie))]
+    print("  in-epilogue over [%.0f%%, %.0f%%] of the launch: p5 %d p25 %d p50 %d p75 %d p95 %d max %d" % (
+        lo * 100, hi * 100, *np.percentile(seg, [5, 25, 50, 75, 95]).astype(int), seg.max()))
 # starts per round
 starts = np.sort(st[:, 0])
 print("start-time quantiles:", np.percentile(starts, [0, 5, 6.3, 12.5, 25, 50, 75, 100]).round(1))

@@ -13,6 +13,6 @@ def bench(C,k,d,T,B=32):
     for _ in range(5): op.forward(x,y=y,res=res,in_act=L.IN_LRELU)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/5*1e3
-for dbg in ("0","1","2","3"):
+for dbg in sys.argv[1:]:
     os.environ["VS_WINO_DBG"]=dbg
-    print("dbg",dbg, "C128 k11: %.0f us  k3: %.0f us   C64 k11: %.0f" % (bench(128,11,1,65536), bench(128,3,1,65536), bench(64,11,1,131072)), flush=True)
+    print("dbg",dbg, "C128 k11: %.0f us  k3: %.0f us  k7: %.0f   C64 k11: %.0f  k3: %.0f" % (bench(128,11,1,65536), bench(128,3,1,65536), bench(128,7,1,65536), bench(64,11,1,131072), bench(64,3,1,131072)), flush=True)

@@ -79,7 +79,7 @@ struct ConvParams {
     int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
     int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
     int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
-    int dbg;                    // perturbation experiments (VS_WINO_DBG), 0 in production
+    int dbg;                    // perturbation experiments (VS_WINO_DBG: 1 = no weight-fragment loads, 2 = no staging), 0 in production
     unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
 };
 
@@ -150,13 +150,32 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         tap_e = min(p.KT, hi_t);
     }
 
+    // The accumulators start from the bias (+ the per-item conditioning bias) of their row instead of zero: the same 128
+    // v_mov, and the epilogue loses one VALU add per element -- a VALU instruction of a wave in its epilogue waits for a gap
+    // in the co-resident workgroup's MFMA stream (~one MFMA slot each, tools/conv_stamps.py), so epilogue time is
+    // proportional to its VALU count.
+    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
     f32x16 acc[MT_W][NT_W];
 #pragma unroll
     for (int i = 0; i < MT_W; ++i)
 #pragma unroll
-        for (int j = 0; j < NT_W; ++j)
+        for (int r = 0; r < 16; ++r) {
+            const int rt = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = (mt0 + i) * 32 + rt;                 // virtual row (biasp is zero-padded to whole tiles)
+            float bv = p.biasp[m];
+            if (bbias) {
+                int row;
+                if constexpr (MT_W == 2) {                     // paired rows: tile 2q -> c, tile 2q+1 -> Hh + c
+                    row = (i & 1) * p.Hh + min((mt0 >> 1) * 32 + rt, p.Hh - 1);
+                } else {
+                    const int mc = min(m, p.M - 1);
+                    row = (p.kind == VS_CONV_TRANSPOSE1D) ? mc % p.c_out : mc;
+                }
+                bv += bbias[row];
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < NT_W; ++j) acc[i][j][r] = bv;
+        }
 
     float st[RPW][CIT];
     float mk[CIT];
@@ -322,7 +341,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     // All loops have constant trip counts and no early exits (acc[][][] must stay in registers); every global
     // LOAD is unconditional on a clamped address and issued NT_W at a time ahead of its uses, only the STORES are
     // predicated -- a predicated load would cost a branch and a full vmcnt(0) drain per element.
-    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
     int ncol[NT_W];
 #pragma unroll
     for (int j = 0; j < NT_W; ++j) ncol[j] = n0 + (wn * NT_W + j) * 32 + l31;
@@ -344,9 +362,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
                 const int c = pair * 32 + rt;
                 const bool okc = c < p.Hh;
                 const int cc = min(c, p.Hh - 1);
-                const int cm = pair * 64 + rt;   // virtual row of the first half
-                float b0 = p.biasp[cm], b1 = p.biasp[cm + 32];
-                if (bbias) { b0 += bbias[cc]; b1 += bbias[p.Hh + cc]; }
                 float x1[NT_W];
                 if (pmode != VS_PAIR_GATE) {
 #pragma unroll
@@ -355,7 +370,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
                 }
 #pragma unroll
                 for (int j = 0; j < NT_W; ++j) {
-                    const float v0 = acc[0][j][r] + b0, v1 = acc[1][j][r] + b1;
+                    const float v0 = acc[0][j][r], v1 = acc[1][j][r];
                     const bool ok = okc && ncol[j] < p.N;
                     float outv;
                     if (pmode == VS_PAIR_GATE) {
@@ -421,13 +436,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
             const int colg = n0 + wn * CW + c4;
             float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (use_mask) m4 = *reinterpret_cast<const float4 *>(maskb + colg);
-            float badd[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                badd[r] = p.biasp[row];
-                if (bbias) badd[r] += bbias[row];
-            }
             const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
             const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
 #pragma unroll
@@ -444,20 +452,20 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
                     for (int j = 0; j < NT_W; ++j)
-                        Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = acc[i][j][4 * ps + q] + badd[4 * ps + q];
+                        Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = acc[i][j][4 * ps + q];
                 }
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     float4 v = *reinterpret_cast<const float4 *>(Lw + (it * RPI + lrow) * CW + c4);
                     if (has_res) { v.x += r4[it].x; v.y += r4[it].y; v.z += r4[it].z; v.w += r4[it].w; }
                     if (has_acc) { v.x += a4[it].x; v.y += a4[it].y; v.z += a4[it].z; v.w += a4[it].w; }
-                    v.x *= o.scale; v.y *= o.scale; v.z *= o.scale; v.w *= o.scale;
+                    if (o.scale != 1.f) { v.x *= o.scale; v.y *= o.scale; v.z *= o.scale; v.w *= o.scale; }
                     if (o.out_act == VS_OUT_TANH) {
                         v.x = tanh_fast(v.x); v.y = tanh_fast(v.y); v.z = tanh_fast(v.z); v.w = tanh_fast(v.w);
                     } else if (o.out_act == VS_OUT_RELU) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w;
+                    if (use_mask) { v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w; }
                     *reinterpret_cast<float4 *>(yb + goff[it]) = v;
                 }
             }
@@ -476,7 +484,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
             constexpr bool WITH_ACC = decltype(acc_tag)::value;
 #pragma unroll
             for (int nb = 0; nb < 16 / RB; ++nb) {
-                float rv[RB][NT_W], av[WITH_ACC ? RB : 1][NT_W], badd[RB];
+                float rv[RB][NT_W], av[WITH_ACC ? RB : 1][NT_W];
                 int roff[RB], phase_[RB];
                 bool okm[RB];
 #pragma unroll
@@ -488,9 +496,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
                     if (transposed) { phase = mc / p.c_out; row = mc - phase * p.c_out; }
                     okm[q] = (m < p.M) && (row >= p.row_lo) && (row < p.row_hi);
                     phase_[q] = phase;
-                    float bd = p.biasp[mc];
-                    if (bbias) bd += bbias[row];
-                    badd[q] = bd;
                     roff[q] = (row - row_sub) * p.Tout;       // < 2^31: one item's rows * T_out
                     // (res / acc are never combined with a transposed conv: host-checked)
                     const int voff = (roff[q] + ncol[0]) * 4;
@@ -508,7 +513,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
 #pragma unroll
                     for (int j = 0; j < NT_W; ++j) {
                         const int col = transposed ? ncol[j] * p.up + phase_[q] : ncol[j];
-                        const float v = acc[i][j][r] + badd[q];
+                        const float v = acc[i][j][r];
                         float outv;
                         if (o.mode == VS_OUT_LINEAR) {
                             outv = v + rv[q][j];
@@ -636,13 +641,22 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     const int lhalf = lane >> 5;
     const int l31 = lane & 31;
 
+    // M0 starts from the row's bias and M3 from its negative (y[t] = M0+M1+M2, y[t+d] = M1-M2-M3): see conv_mfma_kernel
+    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
     f32x16 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) {
+        const int row = mt0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        float bv = p.biasp[row];
+        if (bbias) bv += bbias[min(row, p.M - 1)];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 2; ++j) {
+            acc[0][j][r] = bv;
+            acc[1][j][r] = 0.f;
+            acc[2][j][r] = 0.f;
+            acc[3][j][r] = -bv;
+        }
+    }
 
     // pair column -> first output of the pair, relative to the wave's first output
     int posr[2], posw[2];
@@ -735,10 +749,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     if (nsteps > 0) load_a(a0, 0);
     if (RING == 3 && nsteps > 1) load_a(a1, 1);
 
+    stamp(p, 0);
     stage_load(0);
     stage_store(buf0, 0);
     if (p.nchunks > 1) stage_load(1);
     __syncthreads();
+    stamp(p, 1);
 
     int chunk = 0, g = 0, half = 0, s = 0;
     auto step = [&](float (&acur)[16], float (&apre)[16]) __attribute__((always_inline)) {
@@ -793,6 +809,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
         }
     }
 
+    stamp(p, 2);
     // ------------------------------------------------------------------------------------------------- epilogue
     // output transform in place: acc[0] <- y[t(c)], acc[3] <- y[t(c) + d]
 #pragma unroll
@@ -804,7 +821,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
             acc[3][j][r] = m1 - m2 - acc[3][j][r];
         }
 
-    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
     const OutSpec o = p.out[0];
     const int tile_row0 = mt0 * 32;
     const bool has_res = o.res != nullptr, has_acc = o.acc != nullptr;
@@ -813,13 +829,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
     const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
     const int nw = n0 + wn * NBW;                // first output of this wave
-    float badd[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = min(tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, p.M - 1);
-        badd[r] = p.biasp[row];
-        if (bbias) badd[r] += bbias[row];
-    }
 
     if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M)) {
         constexpr int VEC = (DIL == 1) ? 4 : 2;
@@ -836,47 +845,81 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
 #pragma unroll
         for (int e = 0; e < VEC; ++e) mv[e] = 1.f;
         if (use_mask && active) mv = *reinterpret_cast<const vecf *>(maskb + colg);
+        // Residual / accumulate reads: every 8-row pass needs one HBM round trip (2-3 us with the chip in its epilogues), and
+        // four of them in sequence were 11 us of a 50 us workgroup at k=3 (tools/conv_stamps.py) -- so the reads of ALL
+        // passes are issued before the first use (64 registers, free now that the fragment ring and the staging registers
+        // are dead); with an accumulate input as well, two passes at a time.  Loads of a batch precede its stores and every
+        // lane stores exactly the elements it loaded, so y may alias res / acc.
+        // SIMPLE = no accumulate input, no scale, no activation, no mask (the inner resblock convs: 5 of 6 launches): the
+        // per-element work is LDS read + residual add + store with no branch in it (every runtime `if` inside these unrolled
+        // loops is a scalar branch per element group, and the epilogue's instruction stream is what it costs).
+        auto run = [&](auto pb_tag, auto simple_tag, auto res_tag) __attribute__((always_inline)) {
+            constexpr int PB = decltype(pb_tag)::value;
+            constexpr bool SIMPLE = decltype(simple_tag)::value;
+            constexpr bool RES = decltype(res_tag)::value;
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            vecf r4[NIT], a4[NIT];
-            long long goff[NIT];
+            for (int pb = 0; pb < 4 / PB; ++pb) {
+                vecf r4[PB][NIT], a4[PB][NIT];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                goff[it] = (long long)(tile_row0 + 8 * ps + it * RPI + lrow) * p.Tout + colg;
-                if (active) {
-                    if (has_res) r4[it] = *reinterpret_cast<const vecf *>(resp + goff[it]);
-                    if (has_acc) a4[it] = *reinterpret_cast<const vecf *>(accp + goff[it]);
-                }
-            }
+                for (int u = 0; u < PB; ++u)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+                    for (int it = 0; it < NIT; ++it) {
+                        const long long goff = (long long)(tile_row0 + 8 * (pb * PB + u) + it * RPI + lrow) * p.Tout + colg;
+                        if (active) {
+                            if constexpr (RES) r4[u][it] = *reinterpret_cast<const vecf *>(resp + goff);
+                            if constexpr (!SIMPLE) {
+                                if (has_acc) a4[u][it] = *reinterpret_cast<const vecf *>(accp + goff);
+                            }
+                        }
+                    }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float y0 = acc[0][j][4 * ps + q] + badd[4 * ps + q], y1 = acc[3][j][4 * ps + q] + badd[4 * ps + q];
-                    if constexpr (DIL == 1) {      // the pair is adjacent: one 8-byte write, unit stride across lanes
-                        *reinterpret_cast<float2 *>(Lw + (q + 4 * lhalf) * CWP + posw[j]) = make_float2(y0, y1);
-                    } else {
-                        Lw[(q + 4 * lhalf) * CWP + posw[j]] = y0;
-                        Lw[(q + 4 * lhalf) * CWP + posw[j] + DIL] = y1;
+                for (int u = 0; u < PB; ++u) {
+                    const int ps = pb * PB + u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float y0 = acc[0][j][4 * ps + q], y1 = acc[3][j][4 * ps + q];
+                            if constexpr (DIL == 1) {      // the pair is adjacent: one 8-byte write, unit stride across lanes
+                                *reinterpret_cast<float2 *>(Lw + (q + 4 * lhalf) * CWP + posw[j]) = make_float2(y0, y1);
+                            } else {
+                                Lw[(q + 4 * lhalf) * CWP + posw[j]] = y0;
+                                Lw[(q + 4 * lhalf) * CWP + posw[j] + DIL] = y1;
+                            }
+                        }
+                    }
+                    if (active) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const long long goff = (long long)(tile_row0 + 8 * ps + it * RPI + lrow) * p.Tout + colg;
+                            vecf v = *reinterpret_cast<const vecf *>(Lw + (it * RPI + lrow) * CWP + cv);
+                            if constexpr (RES) v += r4[u][it];
+                            if constexpr (!SIMPLE) {
+                                if (has_acc) v += a4[u][it];
+                                v *= o.scale;
+                                if (o.out_act != VS_OUT_NONE) {
+#pragma unroll
+                                    for (int e = 0; e < VEC; ++e) {
+                                        if (o.out_act == VS_OUT_TANH) v[e] = tanh_fast(v[e]);
+                                        else if (o.out_act == VS_OUT_RELU) v[e] = fmaxf(v[e], 0.f);
+                                    }
+                                }
+                                v *= mv;
+                            }
+                            *reinterpret_cast<vecf *>(yb + goff) = v;
+                        }
                     }
                 }
             }
-            if (active) {
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    vecf v = *reinterpret_cast<const vecf *>(Lw + (it * RPI + lrow) * CWP + cv);
-                    if (has_res) v += r4[it];
-                    if (has_acc) v += a4[it];
-                    v *= o.scale;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        if (o.out_act == VS_OUT_TANH) v[e] = tanh_fast(v[e]);
-                        else if (o.out_act == VS_OUT_RELU) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    v *= mv;
-                    *reinterpret_cast<vecf *>(yb + goff[it]) = v;
-                }
-            }
+        };
+        const bool simple = !has_acc && o.scale == 1.f && o.out_act == VS_OUT_NONE && !use_mask;
+        if (simple) {
+            if (has_res) run(std::integral_constant<int, 4>{}, std::true_type{}, std::true_type{});
+            else run(std::integral_constant<int, 4>{}, std::true_type{}, std::false_type{});
+        } else if (has_res) {
+            run(std::integral_constant<int, 2>{}, std::false_type{}, std::true_type{});
+        } else {
+            run(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{});
         }
     } else {
         // edge workgroups (ragged last time tile): element-wise, predicated stores, clamped loads
@@ -893,7 +936,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
                     const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
                     const int rowc = min(row, p.M - 1);
                     const long long off = (long long)rowc * p.Tout + colc;
-                    float v = (hh == 0 ? acc[0][j][r] : acc[3][j][r]) + badd[r];
+                    float v = (hh == 0 ? acc[0][j][r] : acc[3][j][r]);
                     if (has_res) v += resp[off];
                     if (has_acc) v += accp[off];
                     v *= o.scale;
@@ -904,6 +947,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
                 }
             }
         }
+    }
+    if (p.stamps) {
+        stamp(p, 6);                     // epilogue issued
+        __builtin_amdgcn_s_waitcnt(0);   // all stores acknowledged
+        stamp(p, 3);
     }
 }
 
