@@ -48,3 +48,24 @@ def test_spectrogram_shapes_and_energy():
     tone = torch.sin(2 * np.pi * 3000.0 * t)[None]
     lin = audio.linear_spectrogram(tone, 2048, 1200, hop)
     assert abs(int(lin[0, 20].argmax()) - round(3000.0 / (24000 / 2048))) <= 1
+
+
+def test_wav_writer_and_bucketing(tmp_path):
+    """utils/audio/io.py:8-15 restated (visinger_amd/synth.py): int16 scaling with / without peak normalisation, the file
+    scipy reads back, and the length bucketing of the batched synthesis driver."""
+    import numpy as np
+    from scipy.io import wavfile
+    from visinger_amd.synth import bucket_by_length, save_wav, to_int16
+    wav = np.array([0.0, 0.25, -0.5, 0.125], np.float32)
+    assert to_int16(wav, norm=False).tolist() == [0, 8191, -16383, 4095]            # truncation toward zero, as astype does
+    assert to_int16(wav, norm=True).tolist() == [0, 16383, -32767, 8191]
+    path = str(tmp_path / "a.wav")
+    save_wav(wav, path, 22050, norm=True)
+    sr, data = wavfile.read(path)
+    assert sr == 22050 and data.dtype == np.int16 and data.tolist() == [0, 16383, -32767, 8191]
+    lengths = [100, 900, 400, 1000, 50, 410]
+    batches = bucket_by_length(lengths, max_frames_per_batch=2000)
+    assert sorted(i for b in batches for i in b) == list(range(6))                       # a partition
+    for b in batches:
+        assert max(lengths[i] for i in b) * len(b) <= 2000 or len(b) == 1               # padded-frame budget
+        assert [lengths[i] for i in b] == sorted((lengths[i] for i in b), reverse=True)  # longest first

@@ -46,6 +46,12 @@ def to_int16(wav, norm=True):
     return (wav * 32767.0).astype(np.int16)
 
 
+def save_wav(wav, path, sr, norm=False):
+    """utils/audio/io.py:8-12: write `wav` (float, nominally in [-1, 1]) as 16-bit PCM to path[:-4] + '.wav'."""
+    from scipy.io import wavfile
+    wavfile.write(path[:-4] + ".wav", sr, to_int16(wav, norm=norm))
+
+
 @torch.no_grad()
 def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None):
     """Run VISinger.forward(infer=True) over length-bucketed batches.  Returns a list of float32 waveforms trimmed to
