@@ -103,7 +103,8 @@ def test_conv1d_mask_in_out_relu_and_bias_b(oracle):
 
 
 @pytest.mark.parametrize("Cin,Cout,k,u,T", [(64, 32, 16, 8, 40), (32, 32, 4, 2, 300), (48, 24, 11, 5, 33),
-                                             (32, 16, 7, 3, 50), (512, 256, 16, 8, 16), (10, 6, 8, 4, 13)])
+                                             (32, 16, 7, 3, 50), (512, 256, 16, 8, 16), (10, 6, 8, 4, 13),
+                                             (48, 32, 11, 5, 159), (128, 64, 7, 3, 40)])     # padding row tiles + > 2 chunks
 def test_conv_transpose1d(oracle, Cin, Cout, k, u, T):
     from visinger_amd.ops import ConvOp
     r = rng(Cin + Cout + k + u)
@@ -306,3 +307,18 @@ def test_winograd_matches_direct_engine_at_size(monkeypatch):
     y_d = op.forward(x, in_act=L.IN_LRELU, res=x)
     torch.cuda.synchronize()
     assert float((y_w - y_d).abs().max()) <= 2e-5 * (1.0 + float(y_d.abs().max()))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_conv_engine_random_sweep(seed, monkeypatch):
+    """tools/conv_fuzz.py: 150 random (shape, dilation / stride, fused option) cases per seed across every kernel instance"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import conv_fuzz
+    monkeypatch.setattr(sys, "argv", ["conv_fuzz.py", "150", str(seed)])
+    monkeypatch.delenv("VS_WINO_FORCE", raising=False)
+    try:
+        conv_fuzz.main()
+    finally:
+        os.environ.pop("VS_WINO_FORCE", None)

@@ -148,6 +148,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         }
         tap_b = max(0, lo_t);
         tap_e = min(p.KT, hi_t);
+        // a wave whose tiles are all padding (M tiles rounded up to the workgroup) has no tap of its own, but it still owns
+        // LDS rows of every chunk and a seat at every chunk barrier: give it one tap (its packed weights are zeros)
+        if (tap_e <= tap_b) { tap_b = 0; tap_e = 1; }
     }
 
     // The accumulators start from the bias (+ the per-item conditioning bias) of their row instead of zero: the same 128
