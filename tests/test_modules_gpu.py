@@ -284,3 +284,15 @@ def test_discriminators_gpu():
             lt, ft = m.cuda()(cu(a["y"]))
         close(lt, a[f"p{p}_logits"], atol=1e-4)
         close(ft[-1], a[f"p{p}_fmap_last"], atol=1e-4)
+
+
+def test_modules_random_sweep(monkeypatch):
+    """tools/module_fuzz.py: 60 random (hyper-parameters, batch, length, ragged mask) cases over WaveNet, coupling layer /
+    block (both directions, log-det), generator (random upsampling stacks, ResBlock1/2), relative encoder and posterior
+    encoder, against the fp64 oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import module_fuzz
+    monkeypatch.setattr(sys, "argv", ["module_fuzz.py", "60", "7"])
+    module_fuzz.main()
