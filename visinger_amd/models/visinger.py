@@ -28,123 +28,130 @@ DEFAULT_MAX_TARGET_POSITIONS = 2000
 
 
 class VISinger(nn.Module):
-    """models/visinger.py:18-135"""
+    """Drop-in for the reference model class (models/visinger.py:18-135).  The sub-modules are registered under the
+    reference's attribute names (text_encoder, embed_positions, pitch_predictor, phoneme_predictor, frame_prior,
+    posterior_encoder, flow, decoder, spk_id_proj, spk_embed_proj), which fixes the state-dict layout; `forward` keeps the
+    reference's arguments and result keys and is organised as prior -> (posterior | sampling) -> decode."""
 
     def __init__(self, ph_dict_size, pitch_size, dur_size, hparams, out_dims=None):
         super().__init__()
-        self.hparams = deepcopy(hparams)
-        self.enc_layers = hparams["enc_layers"]
-        self.dec_blocks = hparams["dec_blocks"]
-        self.hidden_size = hparams["hidden_size"]
-        self.use_pos_embed = hparams["use_pos_embed"]
-        self.segment_size = hparams["segment_size"]
-        self.out_dims = hparams["num_mel_bins"] if out_dims is None else out_dims
-        if hparams["use_spk_id"]:
-            self.spk_id_proj = Embedding(hparams["num_spk"], hparams["gin_channels"])
-        if hparams['use_spk_embed']:
-            self.spk_embed_proj = nn.Linear(256, hparams["gin_channels"], bias=True)
-        self.text_encoder = TextEncoder(ph_dict_size, pitch_size, dur_size, self.hidden_size,
-                                        hparams["ffn_filter_channels"], hparams["num_heads"], self.enc_layers,
-                                        hparams["ffn_kernel_size"], hparams["p_dropout"], True)
-        self.embed_positions = SinusoidalPositionalEmbedding(self.hidden_size, 0, init_size=DEFAULT_MAX_TARGET_POSITIONS)
-        if hparams["use_pitch_embed"]:
-            self.pitch_predictor = PitchPredictor(self.hidden_size, hparams["ffn_filter_channels"], hparams["num_heads"],
-                                                  n_layers=hparams["pitch_predictor_layers"],
-                                                  kernel_size=hparams['ffn_kernel_size'], p_dropout=hparams["p_dropout"],
-                                                  gin_channels=hparams["gin_channels"], out_dim=2)
-        if hparams["use_phoneme_pred"]:
-            self.phoneme_predictor = PhonemePredictor(ph_dict_size, self.hidden_size, hparams["ffn_filter_channels"],
-                                                      hparams["num_heads"], n_layers=hparams["phoneme_predictor_layers"],
-                                                      kernel_size=hparams["ffn_kernel_size"], p_dropout=hparams["p_dropout"])
-        self.frame_prior = FramePriorNetwork(self.hidden_size, hparams["ffn_filter_channels"], hparams["num_heads"],
-                                             hparams["frame_prior_layers"], hparams["ffn_kernel_size"],
-                                             p_dropout=hparams["p_dropout"], gin_channels=1)
-        self.posterior_encoder = PosteriorEncoder(hparams["num_linear_bins"], self.hidden_size, self.hidden_size, 5, 1, 16,
-                                                  gin_channels=hparams["gin_channels"])
-        self.flow = ResidualCouplingBlock(self.hidden_size, self.hidden_size, 5, 1, 4, gin_channels=hparams["gin_channels"])
-        self.decoder = Generator(self.hidden_size, hparams["dec_blocks"], hparams["dec_kernel_size"],
-                                 hparams["dec_dilation_sizes"], hparams["upsample_rates"],
-                                 hparams["initial_upsample_channels"], hparams["upsample_kernel_sizes"],
-                                 gin_channels=hparams["gin_channels"])
+        hp = self.hparams = deepcopy(hparams)
+        width = self.hidden_size = hp["hidden_size"]
+        self.enc_layers, self.dec_blocks = hp["enc_layers"], hp["dec_blocks"]
+        self.use_pos_embed, self.segment_size = hp["use_pos_embed"], hp["segment_size"]
+        self.out_dims = hp["num_mel_bins"] if out_dims is None else out_dims
+        gin = hp["gin_channels"]
+        # transformer settings shared by the text encoder, the predictors and the frame prior
+        tf = dict(filter_channels=hp["ffn_filter_channels"], n_heads=hp["num_heads"], kernel_size=hp["ffn_kernel_size"],
+                  p_dropout=hp["p_dropout"])
+
+        if hp["use_spk_id"]:
+            self.spk_id_proj = Embedding(hp["num_spk"], gin)
+        if hp["use_spk_embed"]:
+            self.spk_embed_proj = nn.Linear(256, gin, bias=True)
+        self.text_encoder = TextEncoder(ph_dict_size, pitch_size, dur_size, width, tf["filter_channels"], tf["n_heads"],
+                                        self.enc_layers, tf["kernel_size"], tf["p_dropout"], True)
+        self.embed_positions = SinusoidalPositionalEmbedding(width, 0, init_size=DEFAULT_MAX_TARGET_POSITIONS)
+        if hp["use_pitch_embed"]:
+            self.pitch_predictor = PitchPredictor(width, n_layers=hp["pitch_predictor_layers"], gin_channels=gin, out_dim=2, **tf)
+        if hp["use_phoneme_pred"]:
+            self.phoneme_predictor = PhonemePredictor(ph_dict_size, width, n_layers=hp["phoneme_predictor_layers"], **tf)
+        self.frame_prior = FramePriorNetwork(width, tf["filter_channels"], tf["n_heads"], hp["frame_prior_layers"],
+                                             tf["kernel_size"], p_dropout=tf["p_dropout"], gin_channels=1)
+        # posterior WaveNet: kernel 5, dilation rate 1, 16 layers; flow: 4 couplings of 4 WaveNet layers (visinger.py:62-66)
+        self.posterior_encoder = PosteriorEncoder(hp["num_linear_bins"], width, width, 5, 1, 16, gin_channels=gin)
+        self.flow = ResidualCouplingBlock(width, width, 5, 1, 4, gin_channels=gin)
+        self.decoder = Generator(width, hp["dec_blocks"], hp["dec_kernel_size"], hp["dec_dilation_sizes"], hp["upsample_rates"],
+                                 hp["initial_upsample_channels"], hp["upsample_kernel_sizes"], gin_channels=gin)
+
+    # ---- pieces of forward ----------------------------------------------------------------------------------------------
+    def _prior(self, text_tokens, pitch_tokens, dur_tokens, mel2ph, spk_embed, spk_id, f0, uv, ret):
+        """frame mask, speaker condition and the prior's (mu_p, logs_p): visinger.py:73-90"""
+        frame_mask = (mel2ph > 0).float().unsqueeze(1)                                     # [B, 1, T]
+        h = self.text_encoder(text_tokens, pitch_tokens, dur_tokens, mel2ph) * frame_mask  # [B, H, T]
+        if self.use_pos_embed:
+            pos = self.embed_positions(h.shape[0], h.shape[2], h.transpose(1, 2)[..., 0])
+            h = h + pos.transpose(1, 2)
+        spk = self.speaker_embedding(spk_embed, spk_id).transpose(1, 2)
+        cond = None
+        if self.hparams["use_pitch_embed"]:
+            # [B, 1, T] -> [B, T, 1]: FramePriorNetwork transposes its condition back (see the module docstring)
+            cond = self.forward_pitch(h, f0, uv, spk, frame_mask, ret).transpose(1, 2)
+        mu_p, logs_p = self.frame_prior(h, frame_mask, cond)
+        return frame_mask, spk, mu_p, logs_p
+
+    def _posterior_branch(self, mel, frame_mask, spk, mu_p, logs_p, noise_q, u_slice, ret):
+        """training side: posterior sample, phoneme CTC head, flow forward, KL, random segment decode (visinger.py:91-104)"""
+        z_q, _, logs_q = self.posterior_encoder(mel.transpose(1, 2), frame_mask, g=spk, noise=noise_q)
+        if self.hparams["use_phoneme_pred"]:
+            ret["ph_pred"] = self.phoneme_predictor(z_q, frame_mask) * frame_mask
+        z_p = ret["z_p"] = self.flow(z_q, frame_mask, g=spk) * frame_mask
+        kl = (logs_p - logs_q - 0.5) + 0.5 * (z_p - mu_p) ** 2 * torch.exp(-2.0 * logs_p)
+        ret["kl"] = (kl * frame_mask).sum() / frame_mask.sum()
+        if u_slice is None:
+            z_seg, ret["ids_slice"] = rand_slice_segments(z_q, self.segment_size)
+        else:   # injected uniform draws: the same fp32 product + truncation as modules/commons/utils.py:97-98
+            ids = (u_slice.to(device=z_q.device) * (z_q.size(2) - self.segment_size + 1)).to(dtype=torch.long)
+            z_seg, ret["ids_slice"] = slice_segments(z_q, ids, self.segment_size), ids
+        ret["wav_out"] = self.decoder(z_seg, g=spk).squeeze(1)
+
+    def _sample_and_decode(self, frame_mask, spk, mu_p, logs_p, noise, ret):
+        """synthesis side: reparameterised prior sample, flow inverse, full-length decode (visinger.py:105-110)"""
+        eps = torch.randn_like(mu_p) if noise is None else noise
+        z_p = (mu_p + eps * torch.exp(logs_p)) * frame_mask
+        z_q = self.flow(z_p, frame_mask, g=spk, reverse=True) * frame_mask
+        ret["wav_out"] = self.decoder(z_q * frame_mask, g=spk).squeeze(1)
 
     def forward(self, text_tokens, pitch_tokens, dur_tokens, mel2ph, spk_embed=None, spk_id=None, f0=None, uv=None,
                 mel=None, infer=False, noise=None, noise_q=None, u_slice=None, **kwargs):
         ret = {}
-        tgt_nonpadding = (mel2ph > 0).float().unsqueeze(1)
-        prior_inp = self.text_encoder(text_tokens, pitch_tokens, dur_tokens, mel2ph)  # [B, H, T]
-        prior_inp = prior_inp * tgt_nonpadding
-        if self.use_pos_embed:
-            pos_in = prior_inp.transpose(1, 2)[..., 0]
-            positions = self.embed_positions(prior_inp.shape[0], prior_inp.shape[2], pos_in)
-            prior_inp = prior_inp + positions.transpose(1, 2)
-        spk_emb = self.speaker_embedding(spk_embed, spk_id).transpose(1, 2)
-        cond_pitch = None
-        if self.hparams["use_pitch_embed"]:
-            cond_pitch = self.forward_pitch(prior_inp, f0, uv, spk_emb, tgt_nonpadding, ret)  # [B, 1, T]
-            cond_pitch = cond_pitch.transpose(1, 2)   # see module docstring: FramePriorNetwork transposes it back
-        mu_p, logs_p = self.frame_prior(prior_inp, tgt_nonpadding, cond_pitch)
-        if not infer:
-            z_q, _, logs_q = self.posterior_encoder(mel.transpose(1, 2), tgt_nonpadding, g=spk_emb, noise=noise_q)
-            if self.hparams["use_phoneme_pred"]:
-                ret["ph_pred"] = self.phoneme_predictor(z_q, tgt_nonpadding) * tgt_nonpadding
-            z_p = ret["z_p"] = self.flow(z_q, tgt_nonpadding, g=spk_emb) * tgt_nonpadding
-            kl = (logs_p - logs_q - 0.5) + 0.5 * ((z_p - mu_p) ** 2) * torch.exp(-2. * logs_p)
-            ret["kl"] = (kl * tgt_nonpadding).sum() / tgt_nonpadding.sum()
-            if u_slice is None:
-                z_slice, ret["ids_slice"] = rand_slice_segments(z_q, self.segment_size)
-            else:  # injected uniform draws: the same fp32 product + truncation as modules/commons/utils.py:97-98
-                ids = (u_slice.to(device=z_q.device) * (z_q.size(2) - self.segment_size + 1)).to(dtype=torch.long)
-                z_slice, ret["ids_slice"] = slice_segments(z_q, ids, self.segment_size), ids
-            ret["wav_out"] = self.decoder(z_slice, g=spk_emb).squeeze(1)
+        frame_mask, spk, mu_p, logs_p = self._prior(text_tokens, pitch_tokens, dur_tokens, mel2ph, spk_embed, spk_id, f0, uv, ret)
+        if infer:
+            self._sample_and_decode(frame_mask, spk, mu_p, logs_p, noise, ret)
         else:
-            if noise is None:
-                noise = torch.randn_like(mu_p)
-            z_p = (mu_p + noise * torch.exp(logs_p)) * tgt_nonpadding
-            z_q = self.flow(z_p, tgt_nonpadding, g=spk_emb, reverse=True) * tgt_nonpadding
-            ret["wav_out"] = self.decoder(z_q * tgt_nonpadding, g=spk_emb).squeeze(1)
+            self._posterior_branch(mel, frame_mask, spk, mu_p, logs_p, noise_q, u_slice, ret)
         return ret
 
     def speaker_embedding(self, spk_embed=None, spk_id=None):
-        speaker_embed = 0
-        if self.hparams['use_spk_embed']:
-            speaker_embed = speaker_embed + self.spk_embed_proj(spk_embed)[:, None, :]
-        if self.hparams['use_spk_id']:
-            speaker_embed = speaker_embed + self.spk_id_proj(spk_id)[:, None, :]
-        return speaker_embed
+        """sum of the enabled speaker conditions, [B, 1, gin] (visinger.py:114-120)"""
+        parts = []
+        if self.hparams["use_spk_embed"]:
+            parts.append(self.spk_embed_proj(spk_embed)[:, None, :])
+        if self.hparams["use_spk_id"]:
+            parts.append(self.spk_id_proj(spk_id)[:, None, :])
+        return sum(parts) if parts else 0
 
     def forward_pitch(self, pitch_inp, f0, uv, spk_emb, tgt_nonpadding, ret):
-        if self.hparams['predictor_grad'] != 1:
-            pitch_inp = pitch_inp.detach() + self.hparams['predictor_grad'] * (pitch_inp - pitch_inp.detach())
-        ret['f0_pred'] = pitch_pred = self.pitch_predictor(pitch_inp, tgt_nonpadding, spk_emb)
+        """pitch predictor + the f0 condition of the frame prior (visinger.py:122-135): predicted f0 / voicing when no ground
+        truth is given; the gradient into the prior input is scaled by `predictor_grad`."""
+        scale = self.hparams["predictor_grad"]
+        if scale != 1:
+            stopped = pitch_inp.detach()
+            pitch_inp = stopped + scale * (pitch_inp - stopped)
+        pred = ret["f0_pred"] = self.pitch_predictor(pitch_inp, tgt_nonpadding, spk_emb)      # [B, T, 2]
         if f0 is None:
-            f0 = pitch_pred[:, :, 0]
-            v = (pitch_pred[:, :, 1] <= 0)
+            f0, voiced = pred[:, :, 0], pred[:, :, 1] <= 0
         else:
-            v = (uv == 0)
-        f0 = (f0 * v).unsqueeze(1) * tgt_nonpadding
-        return f0
+            voiced = uv == 0
+        return (f0 * voiced).unsqueeze(1) * tgt_nonpadding
 
 
 class MultiPeriodDiscriminator(nn.Module):
-    """models/visinger.py:138-158: one scale discriminator + period discriminators (2, 3, 5, 7, 11) applied to the real
-    and the generated waveform."""
+    """models/visinger.py:138-158: the scale discriminator followed by the period discriminators (2, 3, 5, 7, 11), each applied
+    to the real and to the generated waveform.  Returns (logits_real, logits_generated, fmaps_real, fmaps_generated), one entry
+    per discriminator, in that order."""
+
+    PERIODS = (2, 3, 5, 7, 11)
 
     def __init__(self, use_spectral_norm=False):
         super().__init__()
-        discs = [DiscriminatorS(use_spectral_norm=use_spectral_norm)]
-        discs += [DiscriminatorP(p, use_spectral_norm=use_spectral_norm) for p in (2, 3, 5, 7, 11)]
-        self.discriminators = nn.ModuleList(discs)
+        self.discriminators = nn.ModuleList(
+            [DiscriminatorS(use_spectral_norm=use_spectral_norm)] +
+            [DiscriminatorP(period, use_spectral_norm=use_spectral_norm) for period in self.PERIODS])
 
     def forward(self, y, y_hat):
-        y_d_rs, y_d_gs, fmap_rs, fmap_gs = [], [], [], []
-        for d in self.discriminators:
-            y_d_r, fmap_r = d(y)
-            y_d_g, fmap_g = d(y_hat)
-            y_d_rs.append(y_d_r)
-            y_d_gs.append(y_d_g)
-            fmap_rs.append(fmap_r)
-            fmap_gs.append(fmap_g)
-        return y_d_rs, y_d_gs, fmap_rs, fmap_gs
+        real, fake = zip(*((disc(y), disc(y_hat)) for disc in self.discriminators))      # ((logit, fmap), ...) per input
+        return [r[0] for r in real], [f[0] for f in fake], [r[1] for r in real], [f[1] for f in fake]
 
 
 # Hyper-parameters of config/models/visinger.yaml:8-45 (+ datasets/svs/csd/preprocess.yaml), as a plain dict.

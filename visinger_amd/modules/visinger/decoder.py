@@ -22,34 +22,44 @@ from ..hipconv import HipConv1d, HipConvTranspose1d, mask2d, _forward_only_guard
 LRELU_SLOPE = 0.1
 
 
+def _wn(conv):
+    """old-style weight norm (weight_g / weight_v parameters: the reference checkpoints' layout)"""
+    return weight_norm(conv)
+
+
+def _same_convs(channels, kernel_size, dilations):
+    """weight-normed channels -> channels convs with length-preserving padding, N(0, 0.01)-initialised (decoder.py:72-87)"""
+    convs = nn.ModuleList(_wn(HipConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)))
+                          for d in dilations)
+    convs.apply(init_weights)
+    return convs
+
+
+def _strip(convs):
+    for conv in convs:
+        remove_weight_norm(conv)
+
+
 class Generator(nn.Module):
     """decoder.py:13-65"""
 
     def __init__(self, initial_channel, resblock, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates,
                  upsample_initial_channel, upsample_kernel_sizes, gin_channels=0):
-        super(Generator, self).__init__()
-        self.num_kernels = len(resblock_kernel_sizes)
-        self.num_upsamples = len(upsample_rates)
-        self.conv_pre = HipConv1d(initial_channel, upsample_initial_channel, 7, 1, padding=3)
-        resblock = ResBlock1 if resblock == '1' else ResBlock2
-
-        self.ups = nn.ModuleList()
-        for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
-            self.ups.append(weight_norm(
-                HipConvTranspose1d(upsample_initial_channel // (2 ** i), upsample_initial_channel // (2 ** (i + 1)),
-                                   k, u, padding=(k - u) // 2)))
-
-        self.resblocks = nn.ModuleList()
-        for i in range(len(self.ups)):
-            ch = upsample_initial_channel // (2 ** (i + 1))
-            for _, (k, d) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
-                self.resblocks.append(resblock(ch, k, d))
-
-        self.conv_post = HipConv1d(ch, 1, 7, 1, padding=3, bias=False)
+        super().__init__()
+        self.num_kernels, self.num_upsamples = len(resblock_kernel_sizes), len(upsample_rates)
+        block_cls = {"1": ResBlock1}.get(resblock, ResBlock2)
+        widths = [upsample_initial_channel >> i for i in range(self.num_upsamples + 1)]      # channel count halves per stage
+        self.conv_pre = HipConv1d(initial_channel, widths[0], 7, 1, padding=3)
+        # stage i: weight-normed transposed conv widths[i] -> widths[i+1] (stride u, "same * u" padding), then one resblock per
+        # (kernel size, dilation tuple), all on widths[i+1] channels, registered flat: resblocks[i * num_kernels + j]
+        self.ups = nn.ModuleList(_wn(HipConvTranspose1d(widths[i], widths[i + 1], k, u, padding=(k - u) // 2))
+                                 for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)))
+        self.resblocks = nn.ModuleList(block_cls(widths[i + 1], k, d) for i in range(self.num_upsamples)
+                                       for k, d in zip(resblock_kernel_sizes, resblock_dilation_sizes))
+        self.conv_post = HipConv1d(widths[-1], 1, 7, 1, padding=3, bias=False)
         self.ups.apply(init_weights)
-
         if gin_channels != 0:
-            self.cond = HipConv1d(gin_channels, upsample_initial_channel, 1)
+            self.cond = HipConv1d(gin_channels, widths[0], 1)
 
     def forward(self, x, g=None):
         if autograd.training_path(self):
@@ -70,25 +80,19 @@ class Generator(nn.Module):
         return self.conv_post.run(x, in_act=L.IN_LRELU, out_act=L.OUT_TANH)
 
     def remove_weight_norm(self):
-        for l in self.ups:
-            remove_weight_norm(l)
-        for l in self.resblocks:
-            l.remove_weight_norm()
+        _strip(self.ups)
+        for block in self.resblocks:
+            block.remove_weight_norm()
 
 
 class ResBlock1(torch.nn.Module):
     """decoder.py:68-110"""
 
     def __init__(self, channels, kernel_size=3, dilation=(1, 3, 5)):
-        super(ResBlock1, self).__init__()
-        self.convs1 = nn.ModuleList([
-            weight_norm(HipConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)))
-            for d in dilation])
-        self.convs1.apply(init_weights)
-        self.convs2 = nn.ModuleList([
-            weight_norm(HipConv1d(channels, channels, kernel_size, 1, dilation=1, padding=get_padding(kernel_size, 1)))
-            for _ in dilation])
-        self.convs2.apply(init_weights)
+        super().__init__()
+        # pair j: convs1[j] dilated by dilation[j], convs2[j] undilated; all weight-normed, "same" padding
+        self.convs1 = _same_convs(channels, kernel_size, dilation)
+        self.convs2 = _same_convs(channels, kernel_size, [1] * len(dilation))
 
     def _run_fused(self, x, out, first=True, scale=1.0, mask=None):
         """out = ((out if not first else 0) + resblock(x)) * scale   [* mask];  x is left untouched."""
@@ -117,21 +121,16 @@ class ResBlock1(torch.nn.Module):
         return self._run_fused(x, torch.empty_like(x), mask=mask2d(x_mask, B, T))
 
     def remove_weight_norm(self):
-        for l in self.convs1:
-            remove_weight_norm(l)
-        for l in self.convs2:
-            remove_weight_norm(l)
+        _strip(self.convs1)
+        _strip(self.convs2)
 
 
 class ResBlock2(nn.Module):
     """decoder.py:113-137"""
 
     def __init__(self, channels, kernel_size=3, dilation=(1, 3)):
-        super(ResBlock2, self).__init__()
-        self.convs = nn.ModuleList([
-            weight_norm(HipConv1d(channels, channels, kernel_size, 1, dilation=d, padding=get_padding(kernel_size, d)))
-            for d in dilation])
-        self.convs.apply(init_weights)
+        super().__init__()
+        self.convs = _same_convs(channels, kernel_size, dilation)
 
     def _run_fused(self, x, out, first=True, scale=1.0, mask=None):
         n = len(self.convs)
@@ -156,5 +155,4 @@ class ResBlock2(nn.Module):
         return self._run_fused(x, torch.empty_like(x), mask=mask2d(x_mask, B, T))
 
     def remove_weight_norm(self):
-        for l in self.convs:
-            remove_weight_norm(l)
+        _strip(self.convs)
