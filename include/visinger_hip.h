@@ -108,6 +108,16 @@ typedef struct vs_conv_io {
 } vs_conv_io_t;
 
 VS_API int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream);
+
+/* Weight gradient of a stride-1 (dilated) conv, the backward of nn.Conv1d under the training step (trainer.py:306-384 ->
+ * autograd of encoder.py / flow.py / decoder.py convs):  gw[co, ci, k] = sum_{b,t} gy[b, co, t] * x[b, ci, t + k*dil - pad],
+ * x read as 0 outside [0, T_in).  gy: [B, c_out, T_out], x: [B, c_in, T_in].  The reduction over (b, t) is cut into slices
+ * that each write one partial plane: gw_planes is [vs_conv_wgrad_planes(...)][c_out, c_in, k], every plane fully written, and
+ * gw = sum of the planes (deterministic; the caller reduces).  k <= 16, (k-1)*dil <= 64.
+ * (The grad-input is vs_conv_forward with the reversed / transposed weight.)                                            */
+VS_API int vs_conv_wgrad_planes(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out, int k);
+VS_API int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_out, int64_t c_in,
+                         int64_t T_out, int64_t T_in, int k, int dil, int pad, void *stream);
 /* length of the time axis produced for an input of length T */
 VS_API int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T);
 

@@ -128,3 +128,42 @@ def test_conv_backward_matches_aten(kind, Cin, Cout, K, d_or_u, T):
     for got, ref in ((gx, rx), (gw, rw)):
         assert got.shape == ref.shape
         assert float((got - ref).abs().max()) <= 2e-5 * (1.0 + float(ref.abs().max()))
+
+
+def test_training_forward_follows_weight_updates():
+    """The training path folds weight_g * v / ||v|| into a NEW tensor every step; the caching allocator places it at the
+    previous step's address with version 0, so the packed-weight cache must not be keyed on (data_ptr, version) there:
+    three 'optimizer steps' in a row, each forward must use the current weights."""
+    import torch.nn.functional as F
+    from torch.nn.utils import weight_norm
+    from visinger_amd.modules.hipconv import HipConv1d
+    torch.manual_seed(5)
+    m = weight_norm(HipConv1d(24, 40, 5, padding=2)).cuda().train()
+    x = torch.randn(2, 24, 100, device="cuda")
+    for step in range(3):
+        y = m(x)
+        w = torch._weight_norm(m.weight_v, m.weight_g, 0)
+        ref = F.conv1d(x, w, m.bias, padding=2)
+        assert float((y - ref).abs().max()) <= 2e-5 * (1 + float(ref.abs().max())), step
+        with torch.no_grad():
+            m.weight_v.mul_(1.5).add_(0.1)
+            m.weight_g.add_(0.3)
+            m.bias.sub_(0.2)
+        del y, w, ref
+
+
+def test_wavenet_odd_split_two_pass_epilogue_stays_in_bounds():
+    """hidden = 16: the res/skip conv splits its 32 rows at 16 (not a tile multiple) and runs as two row-windowed passes; the
+    second pass addresses its destination through a pointer moved back by split_row rows, and the epilogue's unconditional
+    loads for the rows of the OTHER pass used to land below the buffer (a page fault when it starts a mapping)."""
+    from visinger_amd.modules.visinger.encoder import WaveNet
+    torch.manual_seed(6)
+    m = WaveNet(16, 5, 1, 3, gin_channels=0).cuda().eval()
+    x = torch.randn(2, 16, 48, device="cuda")
+    mask = torch.ones(2, 1, 48, device="cuda")
+    with torch.no_grad():
+        for _ in range(20):
+            torch.cuda.empty_cache()                       # fresh mappings: destinations start at segment boundaries
+            y = m(x, mask)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()

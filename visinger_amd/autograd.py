@@ -4,8 +4,8 @@ Forward: every convolution still runs on the HIP conv engine (``HipConvFn``: the
 because it changes each step); the elementwise neighbours that the inference path fuses into the conv epilogues
 (gates, residuals, masks, coupling updates, LayerNorm) and the attention core run as PyTorch-ROCm ops so that
 autograd records them.  Backward: the conv grad-input runs on the HIP conv engine again (`conv_backward`: correlation
-with the reversed / transposed weight; transposed convs through their de-interleaved phases), the conv grad-weight is a
-library batched GEMM over shifted windows, everything else is PyTorch-ROCm autograd -- no MIOpen on the generator side.  The arithmetic restated here follows the same reference lines as the
+with the reversed / transposed weight; transposed convs through their de-interleaved phases), the conv grad-weight on
+vs_conv_wgrad (csrc/conv_backward.hip), everything else is PyTorch-ROCm autograd -- no MIOpen on the generator side.  The arithmetic restated here follows the same reference lines as the
 inference modules; `tests/test_train_gpu.py` checks train-mode forward == eval-mode (fused HIP) forward and the
 gradients against the reference's own autograd (golden vectors).
 """
@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .ops import ConvOp
+from .ops import ConvOp, conv_wgrad
 
 LRELU_SLOPE = 0.1
 
@@ -27,7 +27,7 @@ class HipConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, module):
         x = x.contiguous().float()
         op = module._op(bind=False)
-        op.set_weights(w.detach().contiguous(), None, None if b is None else b.detach())
+        op.set_weights(w.detach().contiguous(), None, None if b is None else b.detach(), force=True)
         y = op.forward(x)
         ctx.module = module
         ctx.save_for_backward(x, w, b if b is not None else x.new_empty(0))
@@ -60,8 +60,9 @@ def conv_backward(m, x, w, gy, need_x, need_w):
       channel-transposed weight (padding d(K-1) - p); for a transposed conv the stride-u gather
       gx[ci, m] = sum_{co,k} w[ci,co,k] gy[co, m u - p + k] becomes a stride-1 conv over the u de-interleaved phases of gy
       stacked as u*C_out input channels with ceil(K/u) taps;
-    * grad-weight is a plain contraction over (batch, time) of gy with the K shifted windows of x: one library (rocBLAS)
-      batched GEMM per conv through torch.einsum on a strided window view -- "plain library GEMM" territory.
+    * grad-weight is the long-thin GEMM gw[co, ci, k] = sum_{b,t} gy[b, co, t] x[b, ci, t + k d - p] on its own MFMA kernel
+      (csrc/conv_backward.hip, vs_conv_wgrad); for a transposed conv the same kernel with x in the role of gy over the
+      phase-stacked gradient.
     """
     B, Cin, T = x.shape
     K = w.shape[2]
@@ -73,13 +74,10 @@ def conv_backward(m, x, w, gy, need_x, need_w):
             pb = d * (K - 1) - p
             assert pb >= 0, "conv backward-data: padding larger than the receptive field is not supported"
             op = _bwd_op(m, "dx", L.CONV1D, Cout, Cin, K, d, pb, 0)
-            op.set_weights(w.detach().flip(2).transpose(0, 1).contiguous(), None, None)
+            op.set_weights(w.detach().flip(2).transpose(0, 1).contiguous(), None, None, force=True)
             gx = op.forward(gy)
         if need_w:
-            xp = F.pad(x, (p, p)) if p else x
-            Tp = xp.shape[2]
-            win = xp.as_strided((B, Cin, K, Tout), (Cin * Tp, Tp, d, 1))            # win[b,i,k,t] = xp[b,i,t + k d]
-            gw = torch.einsum("bot,bikt->oik", gy, win)
+            gw = conv_wgrad(gy, x, K, d, p)
     else:
         Cout, u, p = w.shape[1], m.stride[0], m.padding[0]
         Q = -(-K // u)
@@ -92,12 +90,11 @@ def conv_backward(m, x, w, gy, need_x, need_w):
         if need_x:
             wq = F.pad(w.detach(), (0, Q * u - K)).view(Cin, Cout, Q, u).permute(0, 3, 1, 2).reshape(Cin, u * Cout, Q)
             op = _bwd_op(m, "dx", L.CONV1D, u * Cout, Cin, Q, 1, 0, 0)
-            op.set_weights(wq.contiguous(), None, None)
+            op.set_weights(wq.contiguous(), None, None, force=True)
             gx = op.forward(G.contiguous())                                             # [B, Cin, Mq - Q + 1 = T]
         if need_w:
-            Gc = G.contiguous()
-            win = Gc.as_strided((B, u * Cout, Q, T), (u * Cout * Mq, Mq, 1, 1))        # win[b,j,q,m] = G[b,j,m + q]
-            g2 = torch.einsum("bim,bjqm->ijq", x, win)                                   # [Cin, u*Cout, Q]
+            # gw2[ci, j, q] = sum_{b,m} x[b, ci, m] * G[b, j, m + q]: the same kernel with x in the role of the output gradient
+            g2 = conv_wgrad(x, G.contiguous(), Q, 1, 0)                                   # [Cin, u*Cout, Q]
             gw = g2.view(Cin, u, Cout, Q).permute(0, 2, 3, 1).reshape(Cin, Cout, Q * u)[:, :, :K].contiguous()
     return gx, gw
 

@@ -499,7 +499,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
                     if (transposed) { phase = mc / p.c_out; row = mc - phase * p.c_out; }
                     okm[q] = (m < p.M) && (row >= p.row_lo) && (row < p.row_hi);
                     phase_[q] = phase;
-                    roff[q] = (row - row_sub) * p.Tout;       // < 2^31: one item's rows * T_out
+                    // (rows below row_lo belong to the other pass of a two-pass split launch: they are not stored, and their
+                    // loads must not reach below the destination, whose pointer was moved back by split_row rows)
+                    roff[q] = (max(row, p.row_lo) - row_sub) * p.Tout;       // < 2^31: one item's rows * T_out
                     // (res / acc are never combined with a transposed conv: host-checked)
                     const int voff = (roff[q] + ncol[0]) * 4;
 #pragma unroll
@@ -1483,6 +1485,12 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     VS_REQUIRE(!need_mask || io->mask, "vs_conv_forward: mask required but NULL");
     VS_REQUIRE(Tout == io->T || !need_mask || h->kind != VS_CONV_TRANSPOSE1D, "mask with transposed conv unsupported");
     hipStream_t s = as_stream(stream);
+    static const bool trace = getenv("VS_TRACE") != nullptr;   // debug: one line per launch on stderr
+    if (trace)
+        fprintf(stderr, "[vs_conv_forward] kind %d %d->%d k%d d%d pad%d flags%u B%d T%d Tout%d in_act%d split%d mode%d,%d res%d acc%d "
+                        "mask%d bias_b%d pair%d x%p y%p y1%p\n", h->kind, h->c_in, h->c_out, h->k, h->dil, h->pad, h->flags, p.B, p.Tin,
+                p.Tout, p.in_act, p.split_row, p.out[0].mode, p.out[1].mode, p.out[0].res != nullptr, p.out[0].acc != nullptr,
+                p.mask != nullptr, p.bias_b != nullptr, p.pair_mode, (const void *)p.x, (void *)p.out[0].y, (void *)p.out[1].y);
 
     if (h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT)) && !p.split_row &&
         !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {

@@ -104,18 +104,20 @@ class ConvOp:
     def rows_out(self):
         return self.c_out // 2 if self.kind == L.CONV1D_PAIRED else self.c_out
 
-    def set_weights(self, w, g=None, bias=None):
+    def set_weights(self, w, g=None, bias=None, force=False):
         """w: weight or weight_v; g: weight_g or None; bias or None (contiguous fp32 CUDA tensors).
-        Re-packs only when a tensor changed (data_ptr / in-place version)."""
+        Re-packs only when a tensor changed (data_ptr / in-place version) -- valid for PARAMETERS, whose storage persists;
+        callers that pass temporaries (the training path's folded weight: a new tensor every step, which the allocator
+        happily places at the previous step's address with version 0) must pass force=True."""
         key = tuple((t.data_ptr(), t._version) if t is not None else None for t in (w, g, bias))
-        if key == self._wkey:
+        if key == self._wkey and not force:
             return
         w = w.detach()
         g = None if g is None else g.detach()
         bias = None if bias is None else bias.detach()
         L.check(self.lib.vs_conv_set_weights(self.h, L.ptr(w.contiguous()), L.ptr(None if g is None else g.contiguous()),
                                              L.ptr(None if bias is None else bias.contiguous()), L.stream_ptr()))
-        self._wkey = key
+        self._wkey = None if force else key
 
     def forward(self, x, *, B=None, T=None, x_bs=0, in_act=L.IN_NONE, mask=None, bias_b=None, bias_b_bs=0,
                 y=None, y_bs=0, res=None, res_bs=0, acc=None, acc_bs=0, scale=1.0, out_act=L.OUT_NONE, out_mask=False,
@@ -254,3 +256,16 @@ def mel2token_to_dur(mel2token, T_txt, max_dur=None):
     L.check(lib.vs_mel2token_to_dur(_i64ptr(m), _i64ptr(dur), B, T, int(T_txt), -1 if max_dur is None else int(max_dur),
                                     L.stream_ptr()))
     return dur
+
+
+def conv_wgrad(gy, x, k, dil=1, pad=0):
+    """8f-1: weight gradient of a stride-1 conv, gw[co, ci, k] = sum_{b,t} gy[b, co, t] * x[b, ci, t + k*dil - pad]
+    (vs_conv_wgrad writes one partial plane per reduction slice; the planes are summed here)."""
+    lib = L.require_gpu()
+    gy, x = gy.contiguous().float(), x.contiguous().float()
+    B, Cout, Tout = gy.shape
+    Cin, Tin = x.shape[1], x.shape[2]
+    planes = lib.vs_conv_wgrad_planes(B, Cout, Cin, Tout, int(k))
+    part = torch.empty((planes, Cout, Cin, k), device=x.device, dtype=torch.float32)
+    L.check(lib.vs_conv_wgrad(L.ptr(gy), L.ptr(x), L.ptr(part), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad), L.stream_ptr()))
+    return part.sum(0) if planes > 1 else part[0]
