@@ -172,7 +172,48 @@ def case_posterior(rng):
     return f"posterior cin{cin} H{H} L{L} gin{gin} B{B} T{T}", max(err(zz, z, True), err(mm, mu, True), err(ll, logs, True)), 5e-5
 
 
-CASES = [case_wavenet, case_flow, case_generator, case_encoder, case_posterior]
+def case_attention(rng):
+    from visinger_amd.modules.rel_transformer import MultiHeadAttention
+    nh = int(rng.choice([1, 2, 3, 4]))
+    dk = int(rng.choice([4, 16, 31, 32, 64, 96, 128, 160]))
+    C = nh * dk
+    ws = None if rng.random() < 0.25 else int(rng.choice([1, 2, 4, 7]))
+    share = bool(rng.random() < 0.6)
+    B, T = int(rng.integers(1, 4)), int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 100, 129, 300]))
+    m = MultiHeadAttention(C, C, nh, window_size=ws, heads_share=share)
+    sd = rand_sd(m, rng)
+    m = m.cuda().eval()
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    if rng.random() < 0.3:
+        mask = None
+        ref = orc.mha_rel(sd, x, x, None, n_heads=nh, window_size=ws)
+    else:
+        mask = ragged_mask(rng, B, T)
+        ref = orc.mha_rel(sd, x, x, mask, n_heads=nh, window_size=ws)
+    with torch.no_grad():
+        xx = cu(x)
+        y = m(xx, xx, frame_mask=None if mask is None else cu(mask[:, 0]))
+    return f"attention nh{nh} dk{dk} ws{ws} share{int(share)} mask{int(mask is not None)} B{B} T{T}", err(y, ref, True), 5e-5
+
+
+def case_index_ops(rng):
+    from visinger_amd.ops import expand_states, make_positions, mel2token_to_dur, slice_segments
+    B, Tp, T, H = int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.choice([1, 7, 64, 65, 300])), int(rng.choice([1, 5, 192]))
+    h = rng.standard_normal((B, Tp, H)).astype(np.float32)
+    m2p = rng.integers(0, Tp + 1, (B, T)).astype(np.int64)
+    ok = np.array_equal(expand_states(cu(h), cu(m2p)).cpu().numpy(), orc.expand_states(h, m2p))
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    x[rng.random((B, T)) < 0.4] = 0.0
+    ok &= np.array_equal(make_positions(cu(x), 0).cpu().numpy(), orc.make_positions(x, 0))
+    ok &= np.array_equal(mel2token_to_dur(cu(m2p), Tp).cpu().numpy(), orc.mel2token_to_dur(m2p, Tp))
+    seg = int(rng.integers(1, T + 1))
+    z = rng.standard_normal((B, H, T)).astype(np.float32)
+    ids = rng.integers(0, T - seg + 1, (B,)).astype(np.int64)
+    ok &= np.array_equal(slice_segments(cu(z), cu(ids), seg).cpu().numpy(), orc.slice_segments(z, ids, seg))
+    return f"index ops B{B} Tp{Tp} T{T} H{H} seg{seg}", 0.0 if ok else 1.0, 0.5
+
+
+CASES = [case_wavenet, case_flow, case_generator, case_encoder, case_posterior, case_attention, case_index_ops]
 
 
 def main():
