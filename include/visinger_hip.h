@@ -142,6 +142,18 @@ VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma
                               int64_t C, int64_t T, float eps, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * a13 grouped / strided Conv1d of the scale discriminator (modules/discriminator.py:55-60) and its gradients.
+ *     x: [B, c_in, T], w: [c_out, c_in/groups, k], y / gy: [B, c_out, T_out], T_out = (T + 2*pad - k)/stride + 1.
+ *     vs_gconv1d_bwd_weight writes one plane per batch item, gw_planes [B][c_out, c_in/groups, k]; gw = their sum.
+ *     (The dense convs of both discriminators run on vs_conv_forward; strided ones through their de-interleaved phases.)  */
+VS_API int vs_gconv1d_fwd(const float *x, const float *w, const float *bias, float *y, int64_t B, int64_t c_in, int64_t c_out,
+                          int64_t T, int k, int stride, int pad, int groups, void *stream);
+VS_API int vs_gconv1d_bwd_data(const float *gy, const float *w, float *gx, int64_t B, int64_t c_in, int64_t c_out, int64_t T,
+                               int k, int stride, int pad, int groups, void *stream);
+VS_API int vs_gconv1d_bwd_weight(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_in, int64_t c_out,
+                                 int64_t T, int k, int stride, int pad, int groups, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * a9  integer frame bookkeeping -- values are moved, never recomputed: bit-exact.
  *     vs_expand_states:  models/commons/align_ops.py:22-26.  out[b, t, :] = mel2token[b, t] ? h[b, mel2token[b,t]-1, :] : 0.
  *                        h: [B, T_tokens, C] (h_channels_first = 0) or [B, C, T_tokens] (1); out likewise with T_frames.

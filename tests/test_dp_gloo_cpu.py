@@ -59,7 +59,9 @@ def test_strided_shard_and_max_time_world2():
 def _ddp_worker(rank, world, port, q):
     """Training-path collective: the discriminator loss of visinger_amd.train under stock DDP over gloo.
     Each rank sees its strided shard; the all-reduced gradient must equal the single-process gradient on the global
-    batch.  (The frame slicing in front of it is a HIP op and is covered on the GPU; here the segments are pre-sliced.)"""
+    batch.  The product discriminators run on HIP kernels only (no CPU path), so a small PyTorch network with the same
+    calling convention -- (real, generated) -> (logits_real, logits_generated, fmaps, fmaps) -- stands in for them here:
+    what is under test is the shard + all-reduce plumbing and the loss, not the convolutions."""
     try:
         sys.path.insert(0, ROOT)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -68,10 +70,20 @@ def _ddp_worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from torch.nn.parallel import DistributedDataParallel as DDP
         from visinger_amd.dp import shard_batch
-        from visinger_amd.models.visinger import MultiPeriodDiscriminator
         from visinger_amd.train import discriminator_loss
+
+        class StandInDiscriminators(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.nets = torch.nn.ModuleList(
+                    torch.nn.Sequential(torch.nn.Conv1d(1, 8, 15, s, padding=7), torch.nn.LeakyReLU(0.1),
+                                        torch.nn.Conv1d(8, 1, 3, 1, padding=1)) for s in (1, 2, 3))
+
+            def forward(self, y, y_hat):
+                return [n(y).flatten(1) for n in self.nets], [n(y_hat).flatten(1) for n in self.nets], [], []
+
         torch.manual_seed(7)                                   # same weights on every rank
-        disc = MultiPeriodDiscriminator()
+        disc = StandInDiscriminators()
         g = torch.Generator().manual_seed(11)
         real = torch.rand(2 * world, 1, 1200, generator=g) - 0.5
         fake = 0.3 * torch.randn(2 * world, 1, 1200, generator=g)

@@ -269,7 +269,7 @@ def test_index_ops_random_large(oracle):
 
 
 def test_discriminators_gpu():
-    """a13 on the GPU (PyTorch-ROCm ops, reference state-dict layout) vs the reference's golden outputs."""
+    """a13 on the HIP kernels (MFMA engine + grouped VALU kernels, reference state-dict layout) vs the reference golden outputs."""
     from test_oracle_golden import _disc_weights
     from visinger_amd.modules.discriminator import DiscriminatorP, DiscriminatorS
     _, a = load_golden("discriminators")
@@ -296,3 +296,55 @@ def test_modules_random_sweep(monkeypatch):
     import module_fuzz
     monkeypatch.setattr(sys, "argv", ["module_fuzz.py", "60", "7"])
     module_fuzz.main()
+
+
+def _torch_reference_discriminator(m, x):
+    """the reference's forward (modules/discriminator.py:28-47, 64-75) on the same parameter holders, PyTorch ops"""
+    import torch.nn.functional as F
+    fmap = []
+    if hasattr(m, "period"):
+        b, c, t = x.shape
+        if t % m.period:
+            x = F.pad(x, (0, m.period - t % m.period), "reflect")
+        x = x.view(b, c, -1, m.period)
+    for conv in m.convs:
+        x = F.leaky_relu(conv(x), 0.1)
+        fmap.append(x)
+    x = m.conv_post(x)
+    fmap.append(x)
+    return torch.flatten(x, 1, -1), fmap
+
+
+@pytest.mark.parametrize("which", ["S", "P2", "P3", "P5", "P11"])
+def test_discriminator_gradients_match_pytorch_autograd(which):
+    """a13 on the HIP kernels: logits, every feature map, the input gradient and every parameter gradient against PyTorch
+    autograd on the identical parameter holders (LSGAN + feature-matching shaped objective, waveform length not a multiple of
+    the period)."""
+    from visinger_amd.modules.discriminator import DiscriminatorP, DiscriminatorS
+    torch.manual_seed(17)
+    m = (DiscriminatorS() if which == "S" else DiscriminatorP(int(which[1:]))).cuda()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() > 1 and p_.shape[1:].numel() > 1:
+                p_.copy_(torch.randn_like(p_) / p_.shape[1:].numel() ** 0.5)
+    x = (0.5 * torch.randn(2, 1, 1237, device="cuda")).requires_grad_(True)
+    target = [None]
+
+    def objective(fn):
+        logits, fmap = fn(m, x)
+        loss = ((1 - logits) ** 2).mean() + sum(f.abs().mean() for f in fmap)
+        grads = torch.autograd.grad(loss, [x] + list(m.parameters()))
+        return logits.detach(), [f.detach() for f in fmap], [g.detach() for g in grads]
+
+    lo_h, fm_h, gr_h = objective(lambda mod, inp: mod(inp))
+    lo_r, fm_r, gr_r = objective(_torch_reference_discriminator)
+
+    def rel(a, b_):
+        return float((a - b_).abs().max()) / (1e-6 + float(b_.abs().max()))
+
+    assert lo_h.shape == lo_r.shape and rel(lo_h, lo_r) <= 2e-5
+    for a, b_ in zip(fm_h, fm_r):
+        assert a.shape == b_.shape and rel(a, b_) <= 2e-5
+    names = ["x"] + [n for n, _ in m.named_parameters()]
+    for n, a, b_ in zip(names, gr_h, gr_r):
+        assert a.shape == b_.shape and rel(a, b_) <= 2e-4, (n, rel(a, b_))

@@ -79,6 +79,9 @@ def lib():
     L.vs_mel2token_to_dur.argtypes = [vp, vp, i64, i64, i64, i64, vp]
     L.vs_conv_wgrad.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, i64, ci, ci, ci, vp]
     L.vs_conv_wgrad_planes.argtypes = [i64, i64, i64, i64, ci]
+    L.vs_gconv1d_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
+    L.vs_gconv1d_bwd_data.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
+    L.vs_gconv1d_bwd_weight.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
     _lib = L
     return L
 

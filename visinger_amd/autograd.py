@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .ops import ConvOp, conv_wgrad
+from .ops import ConvOp, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_weight, gconv1d_fwd
 
 LRELU_SLOPE = 0.1
 
@@ -97,6 +97,127 @@ def conv_backward(m, x, w, gy, need_x, need_w):
             g2 = conv_wgrad(x, G.contiguous(), Q, 1, 0)                                   # [Cin, u*Cout, Q]
             gw = g2.view(Cin, u, Cout, Q).permute(0, 2, 3, 1).reshape(Cin, Cout, Q * u)[:, :, :K].contiguous()
     return gx, gw
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# discriminator convs: dense convs with a stride, and grouped strided convs
+
+
+def _cached_op(holder, key, *args):
+    ops_ = holder.__dict__.setdefault("_hip_disc_ops", {})
+    if key not in ops_:
+        ops_[key] = ConvOp(*args)
+    return ops_[key]
+
+
+def _phase_geometry(T, K, stride, pad):
+    Tout = (T + 2 * pad - K) // stride + 1
+    Q = -(-K // stride)
+    return Tout, Q, Tout + Q - 1
+
+
+def _phase_stack(x, stride, pad, Hq):
+    """x [B, C, T] -> [B, stride*C, Hq]: channel r*C + c holds the phase-r samples xpad[c, j*stride + r] of the zero-padded x"""
+    B, C, T = x.shape
+    right = Hq * stride - T - pad
+    xp = F.pad(x, (pad, max(right, 0)))[:, :, :Hq * stride]
+    return xp.view(B, C, Hq, stride).permute(0, 3, 1, 2).reshape(B, stride * C, Hq).contiguous()
+
+
+def _phase_weights(w, stride, Q):
+    """w [Cout, C, K] -> [Cout, stride*C, Q] with w2[co, r*C + c, q] = w[co, c, q*stride + r] (zero beyond K)"""
+    Cout, C, K = w.shape
+    return F.pad(w, (0, Q * stride - K)).view(Cout, C, Q, stride).permute(0, 3, 1, 2).reshape(Cout, stride * C, Q).contiguous()
+
+
+class StridedConv1dFn(torch.autograd.Function):
+    """y = conv1d(x, w, b, stride, padding) (dilation 1, dense) on the HIP conv engine: a stride-s conv is the stride-1 conv of the
+    s de-interleaved phases of the padded input stacked as s*C channels with ceil(K/s) taps (`_phase_stack`); its gradients are
+    the engine's grad-input / vs_conv_wgrad on that form, un-stacked.
+
+    The period discriminators present hundreds of SHORT items (B*p columns of 10-300 positions): the engine tiles time per item
+    (256 columns), so the N explicitly padded items are laid end to end as ONE sequence [1, s*C, N*Hq] -- the zero padding
+    between them is already part of each item, outputs at positions that straddle two items are discarded (and enter the
+    gradients as zeros).  `holder` caches the engine handles."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, holder):
+        x, w = x.contiguous().float(), w.contiguous().float()
+        N, C, T = x.shape
+        Cout, _, K = w.shape
+        Tout, Q, Hq = _phase_geometry(T, K, stride, pad)
+        X = _phase_stack(x, stride, pad, Hq) if stride > 1 else F.pad(x, (pad, pad))            # [N, s*C, Hq]
+        XF = X.permute(1, 0, 2).reshape(1, stride * C, N * Hq).contiguous()                    # items end to end
+        w2 = _phase_weights(w, stride, Q) if stride > 1 else w
+        op = _cached_op(holder, ("fwd", C, Cout, K, stride), L.CONV1D, stride * C, Cout, Q, 1, 0, 0)
+        op.set_weights(w2.detach(), None, None if b is None else b.detach(), force=True)
+        yF = op.forward(XF)                                                                     # [1, Cout, N*Hq - Q + 1]
+        y = F.pad(yF, (0, Q - 1)).view(Cout, N, Hq)[:, :, :Tout].permute(1, 0, 2).contiguous()
+        ctx.save_for_backward(XF, w2)
+        ctx.cfg = (N, C, T, K, stride, pad, Q, Hq, Tout, b is not None, holder)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        XF, w2 = ctx.saved_tensors
+        N, C, T, K, stride, pad, Q, Hq, Tout, has_bias, holder = ctx.cfg
+        Cout = w2.shape[0]
+        gy = gy.contiguous().float()
+        gyF = torch.zeros((Cout, N, Hq), device=gy.device, dtype=torch.float32)
+        gyF[:, :, :Tout] = gy.permute(1, 0, 2)
+        gyF = gyF.view(1, Cout, N * Hq)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            op = _cached_op(holder, ("dx", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, 0)
+            op.set_weights(w2.flip(2).transpose(0, 1).contiguous(), None, None, force=True)
+            gXF = op.forward(gyF)[:, :, :N * Hq]                                                # [1, s*C, N*Hq]
+            gX = gXF.reshape(stride * C, N, Hq).permute(1, 0, 2)                                # [N, s*C, Hq]
+            if stride > 1:
+                gxp = gX.reshape(N, stride, C, Hq).permute(0, 2, 3, 1).reshape(N, C, Hq * stride)
+            else:
+                gxp = gX
+            short = pad + T - gxp.shape[2]
+            gx = (F.pad(gxp, (0, short)) if short > 0 else gxp)[:, :, pad:pad + T].contiguous()
+        if ctx.needs_input_grad[1]:
+            if Cout * stride * C >= 256 * 256:
+                # wide layers (512 / 1024 channels): per tap a plain [Cout x P] x [P x s*C] GEMM over the folded sequence --
+                # library GEMM territory (rocBLAS); vs_conv_wgrad's 32 x 32 tiles re-read both operands once per tile pair
+                Lf = N * Hq
+                g2 = torch.stack([gyF[0][:, :Lf - q] @ XF[0][:, q:].t() for q in range(Q)], dim=2)
+            else:
+                g2 = conv_wgrad(gyF, XF, Q, 1, 0)                                               # [Cout, s*C, Q]
+            gw = g2.view(Cout, stride, C, Q).permute(0, 2, 3, 1).reshape(Cout, C, Q * stride)[:, :, :K].contiguous() if stride > 1 else g2
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2))
+        return gx, gw, gb, None, None, None
+
+
+class GroupedConv1dFn(torch.autograd.Function):
+    """grouped / strided conv1d on the VALU kernels of csrc/grouped_conv.hip (forward, grad-input, grad-weight)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, groups):
+        x, w = x.contiguous().float(), w.contiguous().float()
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, groups, b is not None)
+        return gconv1d_fwd(x, w, None if b is None else b.detach(), stride, pad, groups)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, groups, has_bias = ctx.cfg
+        gy = gy.contiguous().float()
+        gx = gconv1d_bwd_data(gy, w, x.shape[2], stride, pad, groups) if ctx.needs_input_grad[0] else None
+        gw = gconv1d_bwd_weight(gy, x, w.shape[2], stride, pad, groups) if ctx.needs_input_grad[1] else None
+        gb = gy.sum((0, 2)) if (has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None
+
+
+def disc_conv1d(holder, x, w, b, stride, pad, groups=1):
+    """conv1d of the discriminators: dense -> MFMA engine, grouped -> VALU kernels; differentiable in x, w, b"""
+    if groups == 1:
+        return StridedConv1dFn.apply(x, w, b, stride, pad, holder)
+    return GroupedConv1dFn.apply(x, w, b, stride, pad, groups)
 
 
 def effective_weight(m):

@@ -1492,7 +1492,10 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
                 p.Tout, p.in_act, p.split_row, p.out[0].mode, p.out[1].mode, p.out[0].res != nullptr, p.out[0].acc != nullptr,
                 p.mask != nullptr, p.bias_b != nullptr, p.pair_mode, (const void *)p.x, (void *)p.out[0].y, (void *)p.out[1].y);
 
-    if (h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT)) && !p.split_row &&
+    // (the VALU kernel reduces over c_in * k serially per thread: right for conv_post 32 -> 1 and the pitch head 192 -> 2, which
+    // stream a long input once; the discriminators' 1024 -> 1 conv_post over a few thousand positions needs the parallelism of
+    // the MFMA tiles even at 1 valid row in 32)
+    if (h->kind == VS_CONV1D && h->c_out <= 4 && h->c_in * h->k <= 2048 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT)) && !p.split_row &&
         !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {
         SmallParams q;
         q.x = p.x; q.x_bs = p.x_bs; q.w = h->weff.as<float>(); q.bias = h->has_bias ? h->beff.as<float>() : nullptr;

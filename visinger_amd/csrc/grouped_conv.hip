@@ -1,0 +1,146 @@
+// grouped_conv.hip -- the grouped, strided 1-D convolutions of the HiFi-GAN scale discriminator (SURVEY.md 8a row a13,
+// reference modules/discriminator.py:55-60: Conv1d(16, 64, 41, 4, groups=4), (64, 256, groups=16), (256, 1024, groups=64),
+// (1024, 1024, groups=256), all with 4 input channels per group) and their gradients, on gfx950.
+//
+// A group is a [C_out/G x 4*41] GEMV-sized problem: nothing for the matrix cores (a 32x32 MFMA tile would be > 85 % padding),
+// and the whole discriminator stack is ~2.6 GMAC per (real, generated) pair, so these are VALU kernels laid out for coalesced
+// HBM/L2 access; the dense convs of the discriminators run on the MFMA engine (conv_engine.hip).
+//
+//   y[b, co, n]   = bias[co] + sum_{ci in group(co), k} w[co, ci, k] * x[b, g*cig + ci, n*s + k - p]
+//   gx[b, c, t]   = sum_{co in group(c), k : (t + p - k) % s == 0} w[co, c - g*cig, k] * gy[b, co, (t + p - k) / s]
+//   gw[co, ci, k] = sum_{b, n} gy[b, co, n] * x[b, g*cig + ci, n*s + k - p]
+#include "vs_internal.h"
+
+namespace vs {
+
+struct GConvParams {
+    const float *x, *w, *bias, *gy;
+    float *y, *gx, *gw;
+    int B, Cin, Cout, T, Tout, K, stride, pad, groups, cig, cog;
+};
+
+// one thread per output element, n fastest (x reads of a wave: stride-s gather inside a few cache lines)
+__global__ void __launch_bounds__(256) gconv_fwd_kernel(const GConvParams p) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.B * p.Cout * p.Tout;
+    if (e >= total) return;
+    const int n = (int)(e % p.Tout);
+    const int co = (int)((e / p.Tout) % p.Cout);
+    const int b = (int)(e / ((long long)p.Tout * p.Cout));
+    const int g = co / p.cog;
+    const float *wr = p.w + (long long)co * p.cig * p.K;
+    const float *xb = p.x + ((long long)b * p.Cin + (long long)g * p.cig) * p.T;
+    float acc = p.bias ? p.bias[co] : 0.f;
+    const int t0 = n * p.stride - p.pad;
+    const int k_lo = max(0, -t0), k_hi = min(p.K, p.T - t0);
+    for (int ci = 0; ci < p.cig; ++ci) {
+        const float *xr = xb + (long long)ci * p.T + t0;
+        const float *wk = wr + ci * p.K;
+        for (int k = k_lo; k < k_hi; ++k) acc = fmaf(wk[k], xr[k], acc);
+    }
+    p.y[e] = acc;
+}
+
+// one thread per input element, t fastest
+__global__ void __launch_bounds__(256) gconv_bwd_data_kernel(const GConvParams p) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.B * p.Cin * p.T;
+    if (e >= total) return;
+    const int t = (int)(e % p.T);
+    const int c = (int)((e / p.T) % p.Cin);
+    const int b = (int)(e / ((long long)p.T * p.Cin));
+    const int g = c / p.cig, ci = c - g * p.cig;
+    const float *gyb = p.gy + ((long long)b * p.Cout + (long long)g * p.cog) * p.Tout;
+    const int tp = t + p.pad;
+    float acc = 0.f;
+    for (int k = tp % p.stride; k < p.K; k += p.stride) {      // taps with (t + p - k) divisible by the stride
+        const int n = (tp - k) / p.stride;
+        if (tp - k < 0 || n >= p.Tout) continue;
+        const float *wk = p.w + ((long long)g * p.cog * p.cig + ci) * p.K + k;
+        for (int co = 0; co < p.cog; ++co) acc = fmaf(wk[(long long)co * p.cig * p.K], gyb[(long long)co * p.Tout + n], acc);
+    }
+    p.gx[e] = acc;
+}
+
+// one workgroup per (co, batch item): thread j < cig*K owns gw[co, ci, k]; gy[b, co, n] is a broadcast, the x reads of a
+// wave are consecutive taps = consecutive addresses.  Partial sums over b are written as planes [B][Cout][cig*K]
+// and summed by the caller (deterministic, no atomics).
+__global__ void __launch_bounds__(256) gconv_bwd_weight_kernel(const GConvParams p) {
+    const int co = blockIdx.x, b = blockIdx.y;
+    const int j = threadIdx.x;
+    const int nj = p.cig * p.K;
+    const int g = co / p.cog;
+    const float *gyr = p.gy + ((long long)b * p.Cout + co) * p.Tout;
+    for (int jj = j; jj < nj; jj += 256) {
+        const int ci = jj / p.K, k = jj - ci * p.K;
+        const float *xr = p.x + ((long long)b * p.Cin + (long long)g * p.cig + ci) * p.T;
+        float acc = 0.f;
+        for (int n = 0; n < p.Tout; ++n) {
+            const int t = n * p.stride + k - p.pad;
+            if (t >= 0 && t < p.T) acc = fmaf(gyr[n], xr[t], acc);
+        }
+        p.gw[((long long)b * p.Cout + co) * nj + jj] = acc;
+    }
+}
+
+static int check(const GConvParams &p) {
+    VS_REQUIRE(p.B > 0 && p.Cin > 0 && p.Cout > 0 && p.T > 0 && p.K > 0 && p.stride > 0 && p.pad >= 0 && p.groups > 0,
+               "vs_gconv1d: bad dims");
+    VS_REQUIRE(p.Cin % p.groups == 0 && p.Cout % p.groups == 0, "vs_gconv1d: channels not divisible by groups");
+    VS_REQUIRE(p.Tout == (p.T + 2 * p.pad - p.K) / p.stride + 1 && p.Tout > 0, "vs_gconv1d: inconsistent output length");
+    return VS_OK;
+}
+
+static GConvParams make(int64_t B, int64_t c_in, int64_t c_out, int64_t T, int k, int stride, int pad, int groups) {
+    GConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.B = (int)B; p.Cin = (int)c_in; p.Cout = (int)c_out; p.T = (int)T; p.K = k; p.stride = stride; p.pad = pad; p.groups = groups;
+    p.Tout = (stride > 0 && T + 2 * pad >= k) ? (int)((T + 2 * pad - k) / stride + 1) : 0;
+    p.cig = groups > 0 ? (int)(c_in / groups) : 0;
+    p.cog = groups > 0 ? (int)(c_out / groups) : 0;
+    return p;
+}
+
+}  // namespace vs
+
+using namespace vs;
+
+extern "C" {
+
+int vs_gconv1d_fwd(const float *x, const float *w, const float *bias, float *y, int64_t B, int64_t c_in, int64_t c_out, int64_t T,
+                   int k, int stride, int pad, int groups, void *stream) {
+    VS_REQUIRE(x && w && y, "vs_gconv1d_fwd: NULL tensor");
+    GConvParams p = make(B, c_in, c_out, T, k, stride, pad, groups);
+    VS_TRY(check(p));
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    const long long total = (long long)p.B * p.Cout * p.Tout;
+    hipLaunchKernelGGL(gconv_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_gconv1d_bwd_data(const float *gy, const float *w, float *gx, int64_t B, int64_t c_in, int64_t c_out, int64_t T, int k,
+                        int stride, int pad, int groups, void *stream) {
+    VS_REQUIRE(gy && w && gx, "vs_gconv1d_bwd_data: NULL tensor");
+    GConvParams p = make(B, c_in, c_out, T, k, stride, pad, groups);
+    VS_TRY(check(p));
+    p.gy = gy; p.w = w; p.gx = gx;
+    const long long total = (long long)p.B * p.Cin * p.T;
+    hipLaunchKernelGGL(gconv_bwd_data_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_gconv1d_bwd_weight(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_in, int64_t c_out, int64_t T,
+                          int k, int stride, int pad, int groups, void *stream) {
+    VS_REQUIRE(gy && x && gw_planes, "vs_gconv1d_bwd_weight: NULL tensor");
+    GConvParams p = make(B, c_in, c_out, T, k, stride, pad, groups);
+    VS_TRY(check(p));
+    VS_REQUIRE(B <= 65535, "vs_gconv1d_bwd_weight: B too large for grid.y");
+    p.gy = gy; p.x = x; p.gw = gw_planes;
+    hipLaunchKernelGGL(gconv_bwd_weight_kernel, dim3((unsigned)p.Cout, (unsigned)p.B), dim3(256), 0, as_stream(stream), p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+}  // extern "C"

@@ -1,14 +1,25 @@
-"""HiFi-GAN period / scale discriminators with the reference's parameter names and shapes
-(``modules/discriminator.py:13-75``): ``convs.{i}.weight_g / weight_v / bias`` and ``conv_post.*``.
+"""HiFi-GAN period / scale discriminators on the MI355X-native kernels, with the reference's parameter
+names and shapes (``modules/discriminator.py:13-75``: ``convs.{i}.weight_g / weight_v / bias`` and ``conv_post.*``), so a
+reference checkpoint's ``mel_disc`` state loads unchanged.  Used by the training step only (BASELINE config 3).
 
-Used by the training step only (BASELINE config 3).  As SURVEY.md row a13 allows, this first version runs on plain
-PyTorch-ROCm ops (strided (k,1) Conv2d, grouped stride-4 Conv1d): the conv engine in csrc/ is stride-1/ungrouped.
-They are *not* part of the synthesis hot path and are not in the bench."""
+* The parameter holders stay ``nn.Conv1d`` / ``nn.Conv2d`` under ``weight_norm`` (or ``spectral_norm``) exactly as in the
+  reference; ``forward`` never calls them -- it fires their forward-pre hooks (which rebuild ``.weight`` from g / v,
+  differentiably) and hands weight and bias to ``visinger_amd.autograd.disc_conv1d``.
+* Dense convs (every period-discriminator layer, the first and the last two scale-discriminator layers) run on the MFMA conv
+  engine; a stride-3 conv as the stride-1 conv of its three de-interleaved input phases (``StridedConv1dFn``).  The period
+  discriminator's (k, 1) Conv2d over [B, C, H, p] is p independent 1-D convs: the waveform is folded once into [B*p, 1, H] and
+  stays in that layout; feature maps are returned as [B, C, H, p] VIEWS of it (same values as the reference's tensors).
+* The grouped stride-4 convs of the scale discriminator (4 input channels per group) run on the VALU kernels of
+  ``csrc/grouped_conv.hip``, forward and both gradients.
+* leaky_relu between the layers is a PyTorch-ROCm elementwise op (autograd records it).
+"""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import weight_norm, spectral_norm
 
+from .. import _lib as L
+from ..autograd import disc_conv1d
 from .commons.utils import get_padding
 
 LRELU_SLOPE = 0.1
@@ -18,6 +29,15 @@ _SCALE_LAYERS = ((16, 15, 1, 1, 7), (64, 41, 4, 4, 20), (256, 41, 4, 16, 20), (1
                  (1024, 5, 1, 1, 2))
 # out_channels of DiscriminatorP.convs -- discriminator.py:20-24 (the last one has stride 1)
 _PERIOD_CHANNELS = (32, 128, 512, 1024, 1024)
+
+
+def _live_params(conv, x):
+    """(weight [C_out, C_in/groups, k], bias) of a weight- / spectral-normed conv holder: its forward-pre hooks recompute
+    ``conv.weight`` from the underlying parameters, exactly what calling the module would do first"""
+    for hook in conv._forward_pre_hooks.values():
+        hook(conv, (x,))
+    w = conv.weight
+    return (w.squeeze(-1) if w.dim() == 4 else w), conv.bias
 
 
 class DiscriminatorP(nn.Module):
@@ -38,18 +58,29 @@ class DiscriminatorP(nn.Module):
         self.conv_post = norm_f(nn.Conv2d(c_in, 1, (3, 1), 1, padding=(1, 0)))
 
     def forward(self, x):
+        L.require_gpu()
         b, c, t = x.shape
-        rem = t % self.period
+        p = self.period
+        rem = t % p
         if rem:
-            x = F.pad(x, (0, self.period - rem), "reflect")
-        x = x.view(b, c, -1, self.period)
+            x = F.pad(x, (0, p - rem), "reflect")
+        h = x.shape[2] // p
+        # [B, 1, H, p] -> p independent columns: [B*p, 1, H]
+        cur = x.view(b, c, h, p).permute(0, 3, 1, 2).reshape(b * p, c, h)
+
+        def as_reference(y):          # [B*p, C, H'] -> the reference's [B, C, H', p] (a view)
+            return y.view(b, p, y.shape[1], y.shape[2]).permute(0, 2, 3, 1)
+
         fmap = []
         for conv in self.convs:
-            x = F.leaky_relu(conv(x), LRELU_SLOPE)
-            fmap.append(x)
-        x = self.conv_post(x)
-        fmap.append(x)
-        return torch.flatten(x, 1, -1), fmap
+            w, bias = _live_params(conv, cur)
+            cur = F.leaky_relu(disc_conv1d(conv, cur, w, bias, conv.stride[0], conv.padding[0]), LRELU_SLOPE)
+            fmap.append(as_reference(cur))
+        w, bias = _live_params(self.conv_post, cur)
+        cur = disc_conv1d(self.conv_post, cur, w, bias, 1, self.conv_post.padding[0])
+        out = as_reference(cur)
+        fmap.append(out)
+        return torch.flatten(out, 1, -1), fmap
 
 
 class DiscriminatorS(nn.Module):
@@ -66,10 +97,13 @@ class DiscriminatorS(nn.Module):
         self.conv_post = norm_f(nn.Conv1d(c_in, 1, 3, 1, padding=1))
 
     def forward(self, x):
+        L.require_gpu()
         fmap = []
         for conv in self.convs:
-            x = F.leaky_relu(conv(x), LRELU_SLOPE)
+            w, bias = _live_params(conv, x)
+            x = F.leaky_relu(disc_conv1d(conv, x, w, bias, conv.stride[0], conv.padding[0], conv.groups), LRELU_SLOPE)
             fmap.append(x)
-        x = self.conv_post(x)
+        w, bias = _live_params(self.conv_post, x)
+        x = disc_conv1d(self.conv_post, x, w, bias, 1, self.conv_post.padding[0])
         fmap.append(x)
         return torch.flatten(x, 1, -1), fmap

@@ -72,7 +72,7 @@ class ConvOp:
         if self.kind == L.CONV1D_PAIRED:
             mt = 2 * -(-(self.c_out // 2) // 32)
             return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
-        if self.kind == L.CONV1D and self.c_out <= 4:
+        if self.kind == L.CONV1D and self.c_out <= 4 and self.c_in * self.k <= 2048:
             return "conv_small_kernel"
         odd = (self.c_out // 32) % 2 == 1
         pays = (self.k >= 9 and self.dil == 1) if odd else (self.dil == 1 or self.k >= 9)
@@ -269,3 +269,39 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
     part = torch.empty((planes, Cout, Cin, k), device=x.device, dtype=torch.float32)
     L.check(lib.vs_conv_wgrad(L.ptr(gy), L.ptr(x), L.ptr(part), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad), L.stream_ptr()))
     return part.sum(0) if planes > 1 else part[0]
+
+
+def _gconv_out_len(T, k, stride, pad):
+    return (T + 2 * pad - k) // stride + 1
+
+
+def gconv1d_fwd(x, w, bias, stride, pad, groups):
+    """a13: grouped / strided conv1d (scale discriminator), y [B, c_out, T_out]."""
+    lib = L.require_gpu()
+    x, w = x.contiguous().float(), w.contiguous().float()
+    B, Cin, T = x.shape
+    Cout, _, k = w.shape
+    y = torch.empty((B, Cout, _gconv_out_len(T, k, stride, pad)), device=x.device, dtype=torch.float32)
+    L.check(lib.vs_gconv1d_fwd(L.ptr(x), L.ptr(w), L.ptr(None if bias is None else bias.contiguous().float()), L.ptr(y), B, Cin, Cout, T,
+                               k, stride, pad, groups, L.stream_ptr()))
+    return y
+
+
+def gconv1d_bwd_data(gy, w, T, stride, pad, groups):
+    lib = L.require_gpu()
+    gy, w = gy.contiguous().float(), w.contiguous().float()
+    B, Cout, _ = gy.shape
+    cig, k = w.shape[1], w.shape[2]
+    gx = torch.empty((B, cig * groups, T), device=gy.device, dtype=torch.float32)
+    L.check(lib.vs_gconv1d_bwd_data(L.ptr(gy), L.ptr(w), L.ptr(gx), B, cig * groups, Cout, T, k, stride, pad, groups, L.stream_ptr()))
+    return gx
+
+
+def gconv1d_bwd_weight(gy, x, k, stride, pad, groups):
+    lib = L.require_gpu()
+    gy, x = gy.contiguous().float(), x.contiguous().float()
+    B, Cout, _ = gy.shape
+    Cin, T = x.shape[1], x.shape[2]
+    planes = torch.empty((B, Cout, Cin // groups, k), device=x.device, dtype=torch.float32)
+    L.check(lib.vs_gconv1d_bwd_weight(L.ptr(gy), L.ptr(x), L.ptr(planes), B, Cin, Cout, T, k, stride, pad, groups, L.stream_ptr()))
+    return planes.sum(0)
