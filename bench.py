@@ -48,10 +48,10 @@ def synthetic_batch(B, T, Tph, ph_dict, seed, device, ragged=False):
     return [t.to(device) for t in (text, pitch, dur, mel2ph, spk, noise)]
 
 
-def build_model(seed=1234):
-    from visinger_amd.models.visinger import VISinger, hop256_hparams
+def build_model(seed=1234, hop=256):
+    from visinger_amd.models.visinger import REFERENCE_HPARAMS, VISinger, hop256_hparams
     torch.manual_seed(seed)
-    hp = hop256_hparams()
+    hp = hop256_hparams() if hop == 256 else dict(REFERENCE_HPARAMS)      # 300: the reference's own 24 kHz configuration
     model = VISinger(64, 117, 131, hp)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():    # non-trivial flow (post convs are zero-initialised in the reference)
@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1024, help="T_mel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
+                    help="256: the BASELINE.json benchmark variant (default); 300: the reference's own generator configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +191,9 @@ def main():
 
     from visinger_amd.ops import PROFILER
     from visinger_amd.dp import shard_batch, max_over_ranks
-    model, hp = build_model()
+    global HOP, SR
+    HOP, SR = args.hop, (22050 if args.hop == 256 else 24000)
+    model, hp = build_model(hop=args.hop)
     model = model.to(dev)
     B, T = args.batch, args.frames
     # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
