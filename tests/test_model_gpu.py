@@ -186,3 +186,30 @@ def test_batched_synthesis_driver_matches_single_items(tiny):
     assert np.abs(alone - both[0]).max() <= 1e-6
     pcm = synth.to_int16(both[0])
     assert pcm.dtype == np.int16 and np.abs(pcm).max() == 32767
+
+
+def test_synthesis_step_is_graph_capturable(tiny):
+    """The whole synthesis step (every ctypes launch goes to torch's current stream, no allocation through hipMalloc and no
+    host synchronisation after warm-up) can be captured into a HIP graph and replayed bit-identically -- what a serving loop
+    with fixed shapes would do (tools/graph_capture_check.py times it at the benchmark size)."""
+    model, a, _, _ = tiny
+    args = [cu(a[k]) for k in ("text", "pitch", "dur", "mel2ph")]
+    spk, noise = cu(a["spk_id"]), cu(a["noise"])
+
+    def step():
+        with torch.no_grad():
+            return model(*args, spk_id=spk, infer=True, noise=noise)["wav_out"]
+
+    ref = step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
