@@ -181,13 +181,18 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("VS_BENCH_BACKEND", "nccl")        # "gloo": rehearsal of the N > 1 path on a 1-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from visinger_amd.ops import PROFILER
     from visinger_amd.dp import shard_batch, max_over_ranks
@@ -221,7 +226,7 @@ def main():
     dt = time.perf_counter() - t0
     PROFILER.stop()
     assert wav.shape == (B, T * HOP) and bool(torch.isfinite(wav).all())
-    dt = max_over_ranks(dt, device=dev)
+    dt = max_over_ranks(dt, device=dev if backend == "nccl" else None)
     samples = B * world * T * HOP * args.steps
 
     if rank == 0:
