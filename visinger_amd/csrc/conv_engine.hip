@@ -428,7 +428,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
         // instead of 4-B stores split over two rows, and the per-element predicate / address arithmetic disappears.
         // (Measured on the element-wise path: 44 us of a 138 us workgroup at C=128, k=3 WITHOUT any store or
         // residual load -- instruction-issue-bound, not memory-bound.)
-        if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M)) {
+        // (a last tile with 8, 16 or 24 valid rows -- the 16-channel stage of the reference's hop-300 generator -- runs the
+        // same path with fewer 8-row passes)
+        if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M || (p.M % 8 == 0 && tile_row0 < p.M))) {
             constexpr int CW = 32 * NT_W;          // columns of this wave's tile
             constexpr int LPR = CW / 4;            // lanes per row (float4 each)
             constexpr int RPI = 64 / LPR;          // rows per wave-instruction
@@ -443,6 +445,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
             const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
+                if (tile_row0 + 8 * ps >= p.M) break;      // wave-uniform: rows beyond M do not exist
                 float4 r4[NIT], a4[NIT];
                 long long goff[NIT];
 #pragma unroll
