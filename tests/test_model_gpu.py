@@ -213,3 +213,14 @@ def test_synthesis_step_is_graph_capturable(tiny):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_synthesis_is_run_to_run_deterministic(tiny):
+    """No atomics and no data-dependent scheduling on the synthesis path: the same inputs give the same bits, run after run
+    (the only float atomics of the library are the flow's forward log-det accumulation, one add per wave, training side)."""
+    model, a, _, _ = tiny
+    args = [cu(a[k]) for k in ("text", "pitch", "dur", "mel2ph")]
+    spk, noise = cu(a["spk_id"]), cu(a["noise"])
+    with torch.no_grad():
+        runs = [model(*args, spk_id=spk, infer=True, noise=noise)["wav_out"].clone() for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
