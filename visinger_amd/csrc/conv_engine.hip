@@ -1566,9 +1566,10 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // coupling `pre` and last res/skip convs) AND the launch is short (T_mel-sized): there 64 x 256 blocks waste no MFMA
     // rows and give 1.5x the workgroups (a 256-workgroup launch fills only one slot per CU)
     int cfg;   // 0: <1,8,4,1> 128x256   1: <1,8,2,2> 64x512   2: <1,4,1,4> 32x512   3: <1,4,2,2> 64x256
-    if (h->MT >= 3) cfg = ((h->MT % 4) == 2 && (long long)p.N * p.B <= 65536) ? 3 : 0;
+    // (6 tiles on a LONG launch -- the stride-3 stage of the hop-300 generator, 192 virtual rows: 64 x 512 blocks, three in M)
+    if (h->MT >= 3) cfg = ((h->MT % 4) == 2) ? (((long long)p.N * p.B <= 65536) ? 3 : 1) : 0;
     else cfg = (h->MT == 2) ? 1 : 2;
-    if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : 0) : cfg;   // A/B switch
+    if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
     auto launch = [&](const ConvParams &q) -> int {
         switch (cfg) {
             case 0: return launch_cfg<1, 8, 4, 1>(q, s);

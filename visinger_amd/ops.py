@@ -84,7 +84,7 @@ class ConvOp:
         rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
         mt = -(-rows // 32)
         if mt >= 3:
-            return "conv_mfma_kernel<1,8,4,1>"      # (or <1,4,2,2> for short 6-tile launches; same family)
+            return "conv_mfma_kernel<1,8,4,1>"      # (or <1,4,2,2> / <1,8,2,2> for 6-tile launches; same family)
         return "conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>"
 
     def wino_eligible(self):
