@@ -40,25 +40,33 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // LDS, double-buffered: the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other
 // buffer after them (one barrier per tile).  The pre-scaled query tile lives in registers (it is the B operand of every
 // S^T MFMA), which keeps the LDS footprint at 74 KB for dk = 96 -> two workgroups per CU.
-template <int DT>
-__global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
+//
+// WIDE (heads of 129..256 channels, BASELINE config 5: hidden 512, 2 heads): the query tile moves from registers to LDS (32 KB
+// per wave) and the 128 registers it held go to the output accumulators; two waves per workgroup, K/V single-buffered and
+// filled through small register batches (155 KB of LDS, one workgroup per CU) -- a functional path for the stress shape, not a
+// tuned one.
+template <int DT, int NWV, bool WIDE>
+__global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const AttnParams p) {
     constexpr int DKR = DT * 32;                   // padded head dim (rows of the K / V tiles in LDS)
-    constexpr int KPT = DKR * 32 / 256;            // K (and V) tile elements staged per thread
+    constexpr int NTHR = 64 * NWV;
+    constexpr int KPT = DKR * 32 / NTHR;           // K (and V) tile elements staged per thread
+    constexpr int NBUF = WIDE ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int i0 = (blockIdx.x * NWV + wave) * 32;
     const int dk = p.dk, T = p.T;
     const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
 
-    float *Ks = smem;                              // [2][DKR][32]
-    float *Vs = Ks + 2 * DKR * 32;                 // [2][DKR][33]
-    float *Ms = Vs + 2 * DKR * 33;                 // [2][32]   key mask of the tile
-    float *QRs = Ms + 64;                          // [4][32][ATT_QRS]   rel-key logits
-    float *Sws = QRs + 4 * 32 * ATT_QRS;           // [4][32][ATT_QRS]   in-window raw scores
-    float *RVs = Sws + 4 * 32 * ATT_QRS;           // [ATT_MAXREL][dk] relative value embeddings
+    float *Ks = smem;                              // [NBUF][DKR][32]
+    float *Vs = Ks + NBUF * DKR * 32;              // [NBUF][DKR][33]
+    float *Ms = Vs + NBUF * DKR * 33;              // [2][32]   key mask of the tile
+    float *QRs = Ms + 64;                          // [NWV][32][ATT_QRS]   rel-key logits
+    float *Sws = QRs + NWV * 32 * ATT_QRS;         // [NWV][32][ATT_QRS]   in-window raw scores
+    float *RVs = Sws + NWV * 32 * ATT_QRS;         // [ATT_MAXREL][dk] relative value embeddings
+    float *Qw = RVs + ATT_MAXREL * DKR + wave * DKR * 32;   // WIDE: this wave's query tile [DKR][32]
 
     const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
     const float *kb = p.k + (long long)b * p.bs + (long long)h * dk * T;
@@ -70,14 +78,17 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
     // ---- this lane's slice of the query tile, pre-scaled: B operand of S^T = K^T Q is Q[d = 2kk+half][i = l31] ----
     const int qi = i0 + l31;                       // this lane's query
     const int qic = min(qi, T - 1);
-    float qreg[DT * 16];
+    float qreg[WIDE ? 1 : DT * 16];
 #pragma unroll
     for (int kk = 0; kk < DT * 16; ++kk) {
         const int d = 2 * kk + half;
         const float v = qb[(long long)min(d, dk - 1) * T + qic];
-        qreg[kk] = (d < dk && qi < T) ? v * p.scale : 0.f;
+        const float qs = (d < dk && qi < T) ? v * p.scale : 0.f;
+        if constexpr (WIDE) Qw[d * 32 + l31] = qs;
+        else qreg[kk] = qs;
     }
-    for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
+    auto qv = [&](int kk) __attribute__((always_inline)) { return WIDE ? Qw[(2 * kk + half) * 32 + l31] : qreg[WIDE ? 0 : kk]; };
+    for (int e = tid; e < nrel * dk; e += NTHR) RVs[e] = relv[e];
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
     for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
@@ -91,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
             const int d = min(2 * kk + half, dk - 1);      // qreg is 0 beyond dk
 #pragma unroll
             for (int r = 0; r < ATT_MAXREL; ++r)
-                if (r < nrel) qr[r] += qreg[kk] * relk[r * dk + d];
+                if (r < nrel) qr[r] += qv(kk) * relk[r * dk + d];
         }
 #pragma unroll
         for (int r = 0; r < ATT_MAXREL; ++r) {
@@ -101,12 +112,37 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
     }
 
     // ---- K/V tile staging (registers -> LDS), thread t owns elements e = t + 256*i of the [DKR][32] tile ----
-    float kst[KPT], vst[KPT], mst = 1.f;
+    float kst[WIDE ? 1 : KPT], vst[WIDE ? 1 : KPT], mst = 1.f;
+    // WIDE: global -> LDS in batches of 8 elements per thread (no register-resident prefetch: the registers are the accumulators)
+    auto tile_fill = [&](int jt) __attribute__((always_inline)) {
+        const int j0 = jt * 32;
+#pragma unroll 1
+        for (int i0_ = 0; i0_ < KPT; i0_ += 8) {
+            float kq[8], vq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + NTHR * (i0_ + u);
+                const int d = e >> 5, jj = e & 31;
+                const long long off = (long long)min(d, dk - 1) * T + min(j0 + jj, T - 1);
+                kq[u] = kb[off];
+                vq[u] = vb[off];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + NTHR * (i0_ + u);
+                const int d = e >> 5, jj = e & 31;
+                const bool ok = (d < dk) && (j0 + jj < T);
+                Ks[e] = ok ? kq[u] : 0.f;
+                Vs[d * 33 + jj] = ok ? vq[u] : 0.f;
+            }
+        }
+        if (tid < 32) Ms[tid] = (j0 + tid < T) ? (maskb ? maskb[min(j0 + tid, T - 1)] : 1.f) : 1.f;
+    };
     auto tile_load = [&](int jt) __attribute__((always_inline)) {
         const int j0 = jt * 32;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NTHR * i;
             const int d = e >> 5, jj = e & 31;
             const long long off = (long long)min(d, dk - 1) * T + min(j0 + jj, T - 1);
             kst[i] = kb[off];
@@ -119,7 +155,7 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
         float *Kb = Ks + buf * DKR * 32, *Vb = Vs + buf * DKR * 33;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NTHR * i;
             const int d = e >> 5, jj = e & 31;
             const bool ok = (d < dk) && (j0 + jj < T);
             Kb[e] = ok ? kst[i] : 0.f;
@@ -137,14 +173,20 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
     const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
 
     const int ntiles = (T + 31) / 32;
-    tile_load(0);
-    tile_store(0, 0);
+    if constexpr (WIDE) {
+        tile_fill(0);
+    } else {
+        tile_load(0);
+        tile_store(0, 0);
+    }
     __syncthreads();
     for (int jt = 0; jt < ntiles; ++jt) {
         const int j0 = jt * 32;
-        const int buf = jt & 1;
+        const int buf = WIDE ? 0 : (jt & 1);
         const float *Kb = Ks + buf * DKR * 32, *Vb = Vs + buf * DKR * 33, *Mb = Ms + buf * 32;
-        if (jt + 1 < ntiles) tile_load(jt + 1);
+        if constexpr (!WIDE) {
+            if (jt + 1 < ntiles) tile_load(jt + 1);
+        }
 
         // ---- S^T tile: rows = keys, cols (lanes) = queries ----
         f32x16 s;
@@ -153,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
 #pragma unroll
         for (int kk = 0; kk < DT * 16; ++kk) {
             const float a = Kb[(2 * kk + half) * 32 + l31];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[kk], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qv(kk), s, 0, 0, 0);
         }
         const bool near_diag = nrel && (j0 + 31 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
         float tmax = -INFINITY;
@@ -202,8 +244,14 @@ __global__ void __launch_bounds__(256, 2) relattn_kernel(const AttnParams p) {
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[ks], o[t], 0, 0, 0);
             }
         }
-        if (jt + 1 < ntiles) tile_store(jt + 1, buf ^ 1);
-        __syncthreads();
+        if constexpr (WIDE) {
+            __syncthreads();                         // every wave is done with the (single) K/V buffer
+            if (jt + 1 < ntiles) tile_fill(jt + 1);
+            __syncthreads();
+        } else {
+            if (jt + 1 < ntiles) tile_store(jt + 1, buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- finish: normalise, add the relative-value term, store ----
@@ -303,19 +351,20 @@ __global__ void __launch_bounds__(64 * G) layernorm_c_kernel(const LnParams p) {
 
 using namespace vs;
 
-template <int DT>
+template <int DT, int NWV, bool WIDE>
 static int launch_attn(const AttnParams &p, hipStream_t s) {
-    const size_t lds = sizeof(float) * ((size_t)2 * DT * 32 * 32 + (size_t)2 * DT * 32 * 33 + 64 + 2 * 4 * 32 * ATT_QRS +
-                                        (size_t)ATT_MAXREL * p.dk);
-    auto kern = relattn_kernel<DT>;
+    constexpr int NBUF = WIDE ? 1 : 2;
+    const size_t lds = sizeof(float) * ((size_t)NBUF * DT * 32 * 32 + (size_t)NBUF * DT * 32 * 33 + 64 + 2 * NWV * 32 * ATT_QRS +
+                                        (size_t)ATT_MAXREL * DT * 32 + (WIDE ? (size_t)NWV * DT * 32 * 32 : 0));
+    auto kern = relattn_kernel<DT, NWV, WIDE>;
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (lds > 160 * 1024) { set_error("vs_relattn_fwd: head dim %d needs %zu B of LDS", p.dk, lds); return VS_EUNSUPPORTED; }
-    dim3 grid((unsigned)ceil_div(p.T, 128), (unsigned)p.nh, (unsigned)p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    dim3 grid((unsigned)ceil_div(p.T, 32 * NWV), (unsigned)p.nh, (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -342,11 +391,15 @@ int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_b
     hipStream_t s = as_stream(stream);
     const int DT = (int)ceil_div(k_channels, 32);
     switch (DT) {
-        case 1: return launch_attn<1>(p, s);
-        case 2: return launch_attn<2>(p, s);
-        case 3: return launch_attn<3>(p, s);
-        case 4: return launch_attn<4>(p, s);
-        default: set_error("vs_relattn_fwd: k_channels %d > 128 not supported yet", k_channels); return VS_EUNSUPPORTED;
+        case 1: return launch_attn<1, 4, false>(p, s);
+        case 2: return launch_attn<2, 4, false>(p, s);
+        case 3: return launch_attn<3, 4, false>(p, s);
+        case 4: return launch_attn<4, 4, false>(p, s);
+        case 5: return launch_attn<5, 2, true>(p, s);
+        case 6: return launch_attn<6, 2, true>(p, s);
+        case 7: return launch_attn<7, 2, true>(p, s);
+        case 8: return launch_attn<8, 2, true>(p, s);
+        default: set_error("vs_relattn_fwd: k_channels %d > 256 not supported", k_channels); return VS_EUNSUPPORTED;
     }
 }
 

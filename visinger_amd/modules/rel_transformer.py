@@ -138,10 +138,10 @@ class MultiHeadAttention(nn.Module):
             return autograd.attention(self, x * frame_mask.reshape(B, 1, T) if (in_mask and frame_mask is not None) else x,
                                       None if frame_mask is None else frame_mask.reshape(B, T).float())
         _forward_only_guard(self)
-        if self.k_channels > 128:
-            # BASELINE config 5 (hidden 512, 2 heads -> 256 channels per head): the streaming kernel keeps the query tile in
-            # registers and covers k_channels <= 128; wider heads run the q/k/v/o convs on the HIP engine and the [T, T]
-            # core as PyTorch-ROCm ops (same index arithmetic, same -1e4 mask fill) until the kernel streams Q through LDS.
+        if self.k_channels > 256:
+            # the streaming kernel covers heads of up to 256 channels (BASELINE config 5: hidden 512, 2 heads; the query tile
+            # moves to LDS above 128); anything wider runs the q/k/v/o convs on the HIP engine and the [T, T] core as
+            # PyTorch-ROCm ops (same index arithmetic, same -1e4 mask fill).
             assert c is x, "wide-head path implements self-attention"
             with torch.no_grad():
                 fm = None if frame_mask is None else frame_mask.reshape(B, T).float()
