@@ -33,7 +33,7 @@ SR = 22050
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 
 
-def synthetic_batch(B, T, Tph, ph_dict, seed, device, ragged=False):
+def synthetic_batch(B, T, Tph, ph_dict, seed, device, ragged=False, hidden=192):
     """SURVEY.md 8d synthetic inputs: mel2ph = repeat_interleave(arange(1, Tph+1), T/Tph); tokens uniform."""
     g = torch.Generator().manual_seed(seed)
     text = torch.randint(4, ph_dict, (B, Tph), generator=g)
@@ -43,15 +43,17 @@ def synthetic_batch(B, T, Tph, ph_dict, seed, device, ragged=False):
     if ragged:
         lens = torch.randint(T // 2, T + 1, (B,), generator=g)
         mel2ph = mel2ph * (torch.arange(T)[None] < lens[:, None])
-    noise = torch.randn(B, 192, T, generator=g)
+    noise = torch.randn(B, hidden, T, generator=g)
     spk = torch.zeros(B, dtype=torch.long)
     return [t.to(device) for t in (text, pitch, dur, mel2ph, spk, noise)]
 
 
-def build_model(seed=1234, hop=256):
+def build_model(seed=1234, hop=256, hidden=192):
     from visinger_amd.models.visinger import REFERENCE_HPARAMS, VISinger, hop256_hparams
     torch.manual_seed(seed)
     hp = hop256_hparams() if hop == 256 else dict(REFERENCE_HPARAMS)      # 300: the reference's own 24 kHz configuration
+    if hidden != 192:      # BASELINE config 5 width: hidden 512 (2 heads -> 256 channels per head), FFN 2048
+        hp.update(hidden_size=hidden, ffn_filter_channels=4 * hidden)
     model = VISinger(64, 117, 131, hp)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():    # non-trivial flow (post convs are zero-initialised in the reference)
@@ -170,6 +172,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1024, help="T_mel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hidden", type=int, default=192, help="hidden_size (512 = the BASELINE config-5 width; fp32)")
     ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
                     help="256: the BASELINE.json benchmark variant (default); 300: the reference's own generator configuration")
     args = ap.parse_args()
@@ -198,11 +201,11 @@ def main():
     from visinger_amd.dp import shard_batch, max_over_ranks
     global HOP, SR
     HOP, SR = args.hop, (22050 if args.hop == 256 else 24000)
-    model, hp = build_model(hop=args.hop)
+    model, hp = build_model(hop=args.hop, hidden=args.hidden)
     model = model.to(dev)
     B, T = args.batch, args.frames
     # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
-    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu")
+    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", hidden=args.hidden)
     text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
 
     def step():
