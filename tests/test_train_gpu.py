@@ -167,3 +167,12 @@ def test_wavenet_odd_split_two_pass_epilogue_stays_in_bounds():
             y = m(x, mask)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
+
+
+def test_backward_random_sweep(monkeypatch):
+    """tools/backward_fuzz.py: 120 random conv / transposed / strided-dense / grouped cases, gradients vs aten"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import backward_fuzz
+    monkeypatch.setattr(sys, "argv", ["backward_fuzz.py", "120", "9"])
+    backward_fuzz.main()

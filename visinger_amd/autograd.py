@@ -179,7 +179,7 @@ class StridedConv1dFn(torch.autograd.Function):
             short = pad + T - gxp.shape[2]
             gx = (F.pad(gxp, (0, short)) if short > 0 else gxp)[:, :, pad:pad + T].contiguous()
         if ctx.needs_input_grad[1]:
-            if Cout * stride * C >= 256 * 256:
+            if Cout * stride * C >= 256 * 256 or Q > 16:       # (vs_conv_wgrad covers up to 16 taps)
                 # wide layers (512 / 1024 channels): per tap a plain [Cout x P] x [P x s*C] GEMM over the folded sequence --
                 # library GEMM territory (rocBLAS); vs_conv_wgrad's 32 x 32 tiles re-read both operands once per tile pair
                 Lf = N * Hq
