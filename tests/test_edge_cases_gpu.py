@@ -109,7 +109,7 @@ def test_long_form_T4096(oracle):
 
 def test_config5_width_hidden512_heads2(oracle):
     """BASELINE config-5 width in fp32: hidden 512, 2 heads (256 channels per head: the WIDE variant of the streaming attention
-    kernel, query tile in LDS), FFN 2048 with k=9 (F(2,3) conv path), on a ragged batch, against the fp64 oracle."""
+    kernel: one workgroup per CU, 512 registers per wave), FFN 2048 with k=9 (F(2,3) conv path), on a ragged batch, against the fp64 oracle."""
     from visinger_amd.modules.rel_transformer import RelativeEncoder
     T, C = 333, 512
     enc = RelativeEncoder(C, 2048, 2, 1, kernel_size=9)

@@ -41,10 +41,9 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // buffer after them (one barrier per tile).  The pre-scaled query tile lives in registers (it is the B operand of every
 // S^T MFMA), which keeps the LDS footprint at 74 KB for dk = 96 -> two workgroups per CU.
 //
-// WIDE (heads of 129..256 channels, BASELINE config 5: hidden 512, 2 heads): the query tile moves from registers to LDS (32 KB
-// per wave) and the 128 registers it held go to the output accumulators; two waves per workgroup, K/V single-buffered and
-// filled through small register batches (155 KB of LDS, one workgroup per CU) -- a functional path for the stress shape, not a
-// tuned one.
+// WIDE (heads of 129..256 channels, BASELINE config 5: hidden 512, 2 heads): one workgroup per CU, so that a wave may use the
+// whole 512-register budget (128 for the query tile, 128 for the output accumulators, 64 for the K/V tile in flight); the K/V
+// tile is single-buffered in LDS (double-buffered it would need 167 KB) with the next tile prefetched in registers.
 template <int DT, int NWV, bool WIDE>
 __global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const AttnParams p) {
     constexpr int DKR = DT * 32;                   // padded head dim (rows of the K / V tiles in LDS)
@@ -66,7 +65,7 @@ __global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const A
     float *QRs = Ms + 64;                          // [NWV][32][ATT_QRS]   rel-key logits
     float *Sws = QRs + NWV * 32 * ATT_QRS;         // [NWV][32][ATT_QRS]   in-window raw scores
     float *RVs = Sws + NWV * 32 * ATT_QRS;         // [ATT_MAXREL][dk] relative value embeddings
-    float *Qw = RVs + ATT_MAXREL * DKR + wave * DKR * 32;   // WIDE: this wave's query tile [DKR][32]
+
 
     const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
     const float *kb = p.k + (long long)b * p.bs + (long long)h * dk * T;
@@ -78,16 +77,14 @@ __global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const A
     // ---- this lane's slice of the query tile, pre-scaled: B operand of S^T = K^T Q is Q[d = 2kk+half][i = l31] ----
     const int qi = i0 + l31;                       // this lane's query
     const int qic = min(qi, T - 1);
-    float qreg[WIDE ? 1 : DT * 16];
+    float qreg[DT * 16];
 #pragma unroll
     for (int kk = 0; kk < DT * 16; ++kk) {
         const int d = 2 * kk + half;
         const float v = qb[(long long)min(d, dk - 1) * T + qic];
-        const float qs = (d < dk && qi < T) ? v * p.scale : 0.f;
-        if constexpr (WIDE) Qw[d * 32 + l31] = qs;
-        else qreg[kk] = qs;
+        qreg[kk] = (d < dk && qi < T) ? v * p.scale : 0.f;
     }
-    auto qv = [&](int kk) __attribute__((always_inline)) { return WIDE ? Qw[(2 * kk + half) * 32 + l31] : qreg[WIDE ? 0 : kk]; };
+    auto qv = [&](int kk) __attribute__((always_inline)) { return qreg[kk]; };
     for (int e = tid; e < nrel * dk; e += NTHR) RVs[e] = relv[e];
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
@@ -112,32 +109,7 @@ __global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const A
     }
 
     // ---- K/V tile staging (registers -> LDS), thread t owns elements e = t + 256*i of the [DKR][32] tile ----
-    float kst[WIDE ? 1 : KPT], vst[WIDE ? 1 : KPT], mst = 1.f;
-    // WIDE: global -> LDS in batches of 8 elements per thread (no register-resident prefetch: the registers are the accumulators)
-    auto tile_fill = [&](int jt) __attribute__((always_inline)) {
-        const int j0 = jt * 32;
-#pragma unroll 1
-        for (int i0_ = 0; i0_ < KPT; i0_ += 8) {
-            float kq[8], vq[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + NTHR * (i0_ + u);
-                const int d = e >> 5, jj = e & 31;
-                const long long off = (long long)min(d, dk - 1) * T + min(j0 + jj, T - 1);
-                kq[u] = kb[off];
-                vq[u] = vb[off];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + NTHR * (i0_ + u);
-                const int d = e >> 5, jj = e & 31;
-                const bool ok = (d < dk) && (j0 + jj < T);
-                Ks[e] = ok ? kq[u] : 0.f;
-                Vs[d * 33 + jj] = ok ? vq[u] : 0.f;
-            }
-        }
-        if (tid < 32) Ms[tid] = (j0 + tid < T) ? (maskb ? maskb[min(j0 + tid, T - 1)] : 1.f) : 1.f;
-    };
+    float kst[KPT], vst[KPT], mst = 1.f;
     auto tile_load = [&](int jt) __attribute__((always_inline)) {
         const int j0 = jt * 32;
 #pragma unroll
@@ -173,20 +145,14 @@ __global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const A
     const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
 
     const int ntiles = (T + 31) / 32;
-    if constexpr (WIDE) {
-        tile_fill(0);
-    } else {
-        tile_load(0);
-        tile_store(0, 0);
-    }
+    tile_load(0);
+    tile_store(0, 0);
     __syncthreads();
     for (int jt = 0; jt < ntiles; ++jt) {
         const int j0 = jt * 32;
         const int buf = WIDE ? 0 : (jt & 1);
         const float *Kb = Ks + buf * DKR * 32, *Vb = Vs + buf * DKR * 33, *Mb = Ms + buf * 32;
-        if constexpr (!WIDE) {
-            if (jt + 1 < ntiles) tile_load(jt + 1);
-        }
+        if (jt + 1 < ntiles) tile_load(jt + 1);
 
         // ---- S^T tile: rows = keys, cols (lanes) = queries ----
         f32x16 s;
@@ -246,7 +212,7 @@ __global__ void __launch_bounds__(64 * NWV, WIDE ? 1 : 2) relattn_kernel(const A
         }
         if constexpr (WIDE) {
             __syncthreads();                         // every wave is done with the (single) K/V buffer
-            if (jt + 1 < ntiles) tile_fill(jt + 1);
+            if (jt + 1 < ntiles) tile_store(jt + 1, 0);
             __syncthreads();
         } else {
             if (jt + 1 < ntiles) tile_store(jt + 1, buf ^ 1);
@@ -355,7 +321,7 @@ template <int DT, int NWV, bool WIDE>
 static int launch_attn(const AttnParams &p, hipStream_t s) {
     constexpr int NBUF = WIDE ? 1 : 2;
     const size_t lds = sizeof(float) * ((size_t)NBUF * DT * 32 * 32 + (size_t)NBUF * DT * 32 * 33 + 64 + 2 * NWV * 32 * ATT_QRS +
-                                        (size_t)ATT_MAXREL * DT * 32 + (WIDE ? (size_t)NWV * DT * 32 * 32 : 0));
+                                        (size_t)ATT_MAXREL * DT * 32);
     auto kern = relattn_kernel<DT, NWV, WIDE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -395,10 +361,10 @@ int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_b
         case 2: return launch_attn<2, 4, false>(p, s);
         case 3: return launch_attn<3, 4, false>(p, s);
         case 4: return launch_attn<4, 4, false>(p, s);
-        case 5: return launch_attn<5, 2, true>(p, s);
-        case 6: return launch_attn<6, 2, true>(p, s);
-        case 7: return launch_attn<7, 2, true>(p, s);
-        case 8: return launch_attn<8, 2, true>(p, s);
+        case 5: return launch_attn<5, 4, true>(p, s);
+        case 6: return launch_attn<6, 4, true>(p, s);
+        case 7: return launch_attn<7, 4, true>(p, s);
+        case 8: return launch_attn<8, 4, true>(p, s);
         default: set_error("vs_relattn_fwd: k_channels %d > 256 not supported", k_channels); return VS_EUNSUPPORTED;
     }
 }
