@@ -224,3 +224,36 @@ def test_synthesis_is_run_to_run_deterministic(tiny):
     with torch.no_grad():
         runs = [model(*args, spk_id=spk, infer=True, noise=noise)["wav_out"].clone() for _ in range(3)]
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+
+
+@pytest.mark.parametrize("hop", [256, 300])
+def test_full_size_model_end_to_end_vs_oracle(oracle, hop):
+    """The whole synthesis graph at the production width (hidden 192, 6 + 4 transformer layers, 4 couplings, 512-channel
+    generator; hop-256 benchmark variant and the reference's hop 300), ragged batch of two short clips, against the fp64 oracle
+    end to end: prior statistics, latent after the flow inverse, waveform."""
+    from visinger_amd.models.visinger import REFERENCE_HPARAMS, VISinger, hop256_hparams
+    hp = dict(hop256_hparams() if hop == 256 else REFERENCE_HPARAMS, use_pitch_embed=False)      # the oracle's runnable configuration
+    torch.manual_seed(11)
+    m = VISinger(40, 50, 60, hp)
+    g = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for name, p_ in m.named_parameters():
+            if name.endswith("weight_g"):
+                p_.copy_(0.5 + torch.rand(p_.shape, generator=g))
+            elif ".post." in name:                       # zero-initialised in the reference: make the flow non-trivial
+                p_.copy_(0.05 * torch.randn(p_.shape, generator=g))
+    sd = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    B, Tph, T = 2, 5, 14
+    text = torch.randint(4, 40, (B, Tph), generator=g)
+    pitch = torch.randint(1, 50, (B, Tph), generator=g)
+    dur = torch.randint(4, 60, (B, Tph), generator=g)
+    mel2ph = torch.tensor([[1, 1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5], [1, 1, 2, 2, 2, 3, 4, 4, 5, 0, 0, 0, 0, 0]])
+    spk = torch.zeros(B, dtype=torch.long)
+    noise = torch.randn(B, 192, T, generator=g)
+    ref = oracle.visinger_infer(sd, hp, text.numpy(), pitch.numpy(), dur.numpy(), mel2ph.numpy(), spk.numpy(), noise.numpy(),
+                                return_all=True)
+    with torch.no_grad():
+        wav = m(text.cuda(), pitch.cuda(), dur.cuda(), mel2ph.cuda(), spk_id=spk.cuda(), infer=True, noise=noise.cuda())["wav_out"]
+    assert wav.shape == (B, T * hop)
+    assert maxerr(wav, ref["wav_out"]) <= 1e-4
