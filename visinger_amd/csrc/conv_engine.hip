@@ -556,47 +556,64 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
 // first MFMA (a VALU result consumed by the very next MFMA costs wait states).  xa/xb: LDS addresses of (x0, x2) and (x1, x3)
 // of the wave's two pair tiles -- with dilation 1 the even and odd columns of the window are staged in separate halves of
 // each LDS row, so both are unit-stride across lanes (a stride-2 read is a 2-way bank conflict); otherwise xb = xa + DIL.
-// (A partial last tap group could run as F(2,2) / direct form into the same accumulators -- k=7: 10 instead of 12 MFMAs --
-// but any control flow with MFMAs on the accumulators in both arms makes hipcc spill them; the taps are zero-padded.)
-template <int DIL>
+// (A partial last tap group can run as F(2,2) / direct form into the same accumulators -- k=7: 10 instead of 12 MFMAs -- but
+// any RUNTIME control flow with MFMAs on the accumulators in both arms makes hipcc spill them: the generic kernel zero-pads
+// the taps, and the k = 7 instances (TG = 3) unroll the six half-steps of a chunk as straight-line code.)
+template <int DIL, int TAPS>
 __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float (&a)[16], const float *xa0, const float *xb0,
                                                const float *xa1, const float *xb1, int RP) {
+    // TAPS == 3: F(2,3), four products.  TAPS == 1 (the last group of k = 7 in the k-specialised instances, where the step
+    // sequence of a chunk is straight-line code -- no branch carries the accumulators): the direct form, y[t] += w x0 into M0
+    // and y[t+d] += w x1 into M3 (U3 is packed negated): two products instead of the zero-padded four.
     constexpr int S2 = (DIL == 1) ? 1 : 2 * DIL;      // distance x0 -> x2 (and x1 -> x3) in LDS words
     const float *xa[2] = {xa0, xa1}, *xb[2] = {xb0, xb1};
     float xc[2][4], xn[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        xc[j][0] = xa[j][0]; xc[j][2] = xa[j][S2];
-        xc[j][1] = xb[j][0]; xc[j][3] = xb[j][S2];
+        xc[j][0] = xa[j][0];
+        xc[j][1] = xb[j][0];
+        if constexpr (TAPS == 3) { xc[j][2] = xa[j][S2]; xc[j][3] = xb[j][S2]; }
     }
 #pragma unroll
     for (int cp = 0; cp < 4; ++cp) {
         if (cp + 1 < 4) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                xn[j][0] = xa[j][(cp + 1) * 2 * RP]; xn[j][2] = xa[j][(cp + 1) * 2 * RP + S2];
-                xn[j][1] = xb[j][(cp + 1) * 2 * RP]; xn[j][3] = xb[j][(cp + 1) * 2 * RP + S2];
+                xn[j][0] = xa[j][(cp + 1) * 2 * RP];
+                xn[j][1] = xb[j][(cp + 1) * 2 * RP];
+                if constexpr (TAPS == 3) { xn[j][2] = xa[j][(cp + 1) * 2 * RP + S2]; xn[j][3] = xb[j][(cp + 1) * 2 * RP + S2]; }
             }
         }
         float v[4][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            v[0][j] = xc[j][0] - xc[j][2];
-            v[1][j] = xc[j][1] + xc[j][2];
-            v[2][j] = xc[j][2] - xc[j][1];
-            v[3][j] = xc[j][1] - xc[j][3];
+            if constexpr (TAPS == 3) {
+                v[0][j] = xc[j][0] - xc[j][2];
+                v[1][j] = xc[j][1] + xc[j][2];
+                v[2][j] = xc[j][2] - xc[j][1];
+                v[3][j] = xc[j][1] - xc[j][3];
+            } else {
+                v[0][j] = xc[j][0];
+                v[1][j] = 0.f;
+                v[2][j] = 0.f;
+                v[3][j] = xc[j][1];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
+        for (int xi = 0; xi < 4; ++xi) {
+            if constexpr (TAPS == 1) {
+                if (xi == 1 || xi == 2) continue;          // (compile-time after unrolling)
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[xi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp * 4 + xi], v[xi][j], acc[xi][j], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xc[j][q] = xn[j][q];
+            for (int q = 0; q < (TAPS == 3 ? 4 : 2); ++q) xc[j][q] = xn[j][q];
     }
 }
 
@@ -614,7 +631,7 @@ __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float 
 // wave from four shifted LDS reads: 1 ds_read + 1 VALU per MFMA), weights as fragments from L2 through a 3-deep
 // register ring, LDS-transposed vector epilogue.  A wave owns 32 rows x PW "pair columns" (c -> outputs t(c), t(c)+d
 // with t(c) = (c / d) * 2d + c % d, a contiguous run of 2*PW outputs when d divides PW) x 4 xi = 8 accumulator tiles.
-template <int DIL, int WAVES_M, int WAVES_N>
+template <int DIL, int WAVES_M, int WAVES_N, int TG, int TT>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(const ConvParams p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int PW = (64 / DIL) * DIL;         // valid pair columns per wave (of 64)
@@ -765,7 +782,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     stamp(p, 1);
 
     int chunk = 0, g = 0, half = 0, s = 0;
-    auto step = [&](float (&acur)[16], float (&apre)[16]) __attribute__((always_inline)) {
+    auto step = [&](auto taps_tag, float (&acur)[16], float (&apre)[16]) __attribute__((always_inline)) {
+        constexpr int TAPS = decltype(taps_tag)::value;
         const float *cur = (chunk & 1) ? buf1 : buf0;
         if (s + (RING - 1) < nsteps && !((p.dbg & 1) && s > 3)) load_a(apre, s + (RING - 1));
         if (g == 0 && half == 0) {
@@ -793,7 +811,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
                 }
             }
         }
-        wino_half_step<DIL>(acc, acur, xq[0], xq[1], xq[2], xq[3], RP);
+        wino_half_step<DIL, TAPS>(acc, acur, xq[0], xq[1], xq[2], xq[3], RP);
         ++s;
         if (++half == 2) {
             half = 0;
@@ -804,16 +822,26 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
             }
         }
     };
-    if constexpr (RING == 3) {
+    constexpr std::integral_constant<int, 3> F3{};
+    if constexpr (TG == 3) {
+        // three tap groups -> six half-steps per chunk, a multiple of the ring period: straight-line code.  k = 7 (TT = 1): the
+        // last two half-steps in the direct form on M0 / M3; k = 9 (TT = 3): all six F(2,3).
+        static_assert(RING == 3, "the k-specialised instances use the 3-slot ring");
+        constexpr std::integral_constant<int, TT> TL{};
+        for (int c = 0; c < p.nchunks; ++c) {
+            step(F3, a0, a2); step(F3, a1, a0); step(F3, a2, a1); step(F3, a0, a2);
+            step(TL, a1, a0); step(TL, a2, a1);
+        }
+    } else if constexpr (RING == 3) {
         while (s < nsteps) {
-            step(a0, a2);
-            if (s < nsteps) step(a1, a0);
-            if (s < nsteps) step(a2, a1);
+            step(F3, a0, a2);
+            if (s < nsteps) step(F3, a1, a0);
+            if (s < nsteps) step(F3, a2, a1);
         }
     } else {
         while (s < nsteps) {       // nsteps is even
-            step(a0, a1);
-            step(a1, a0);
+            step(F3, a0, a1);
+            step(F3, a1, a0);
         }
     }
 
@@ -994,6 +1022,7 @@ struct PackParams {
     float *biasp;
     int kind, c_in, c_out, k, up, pad, dmin, KT, CP, MT_alloc, Hh;
     unsigned flags;
+    int wino_tail1;      // pack_wino_kernel: the single tap of the last group in the direct form (k = 7 specialised instances)
 };
 
 __global__ void pack_conv_kernel(const PackParams q) {
@@ -1089,7 +1118,8 @@ __global__ void pack_wino_kernel(const PackParams q, int G, int nchunks) {
         const float w0 = (k0 < q.k) ? wr[k0] * sc : 0.f;
         const float w1 = (k0 + 1 < q.k) ? wr[k0 + 1] * sc : 0.f;
         const float w2 = (k0 + 2 < q.k) ? wr[k0 + 2] * sc : 0.f;
-        val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
+        if (q.wino_tail1 && k0 + 1 == q.k) val = (xi == 0) ? w0 : (xi == 3) ? -w0 : 0.f;       // single last tap: direct form
+        else val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
     }
     q.wp[e] = val;
 }
@@ -1238,6 +1268,7 @@ struct vs_conv {
     vs::DevBuf wp, biasp, scale, weff, beff;   // weff/beff: unpacked effective weights (c_out <= 4 VALU path)
     vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), when wino_groups > 0
     int wino_groups = 0;                       // ceil(k / 3) if the conv is eligible for the F(2,3) path, else 0
+    bool wino_k7 = false;                      // k = 7 on an even tile count: the TG = 3 instances (direct-form last tap)
     bool has_bias = false;
 };
 
@@ -1260,11 +1291,11 @@ static int launch_cfg(const ConvParams &p, hipStream_t s) {
     return VS_OK;
 }
 
-template <int DIL, int WAVES_M, int WAVES_N>
+template <int DIL, int WAVES_M, int WAVES_N, int TG = 0, int TT = 3>
 static int launch_wino(const ConvParams &p, hipStream_t s) {
     constexpr int NBW = 2 * ((64 / DIL) * DIL);
     constexpr int BN = NBW * WAVES_N;
-    auto kern = conv_wino_kernel<DIL, WAVES_M, WAVES_N>;
+    auto kern = conv_wino_kernel<DIL, WAVES_M, WAVES_N, TG, TT>;
     const int Wh = (p.W + 1) >> 1, H = ((Wh + 15) & ~31) + 16;
     const int RP = (DIL == 1) ? H + Wh : p.W;      // LDS row pitch, as computed by the kernel
     const size_t lds = sizeof(float) * std::max<size_t>((size_t)2 * CK * RP, (size_t)WAVES_M * WAVES_N * 8 * (NBW + 8));
@@ -1280,10 +1311,19 @@ static int launch_wino(const ConvParams &p, hipStream_t s) {
 }
 
 template <int DIL>
-static int launch_wino_dil(ConvParams &p, int MT, int span_w, hipStream_t s) {
+static int launch_wino_dil(ConvParams &p, int MT, int span_w, int spec, hipStream_t s) {      // spec: 0 generic, 7: k = 7 instances
+    // (k = 9 through the same straight-line structure, TT = 3, measured +1 %: not instantiated)
     constexpr int NBW = 2 * ((64 / DIL) * DIL);
-    if (MT % 4 == 0) { p.W = NBW + span_w; return launch_wino<DIL, 4, 1>(p, s); }
-    if (MT % 2 == 0) { p.W = 2 * NBW + span_w; return launch_wino<DIL, 2, 2>(p, s); }
+    if (MT % 4 == 0) {
+        p.W = NBW + span_w;
+        if (spec == 7) return launch_wino<DIL, 4, 1, 3, 1>(p, s);
+        return launch_wino<DIL, 4, 1>(p, s);
+    }
+    if (MT % 2 == 0) {
+        p.W = 2 * NBW + span_w;
+        if (spec == 7) return launch_wino<DIL, 2, 2, 3, 1>(p, s);
+        return launch_wino<DIL, 2, 2>(p, s);
+    }
     p.W = 4 * NBW + span_w;
     return launch_wino<DIL, 1, 4>(p, s);
 }
@@ -1366,6 +1406,7 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     if (kind == VS_CONV1D && k >= 3 && (k & 1) && (dil == 1 || dil == 3 || dil == 5) && pad == dil * (k - 1) / 2 &&
         c_out % 32 == 0 && 3 * (int)ceil_div(k, 3) * dil <= MAX_SPAN)
         h->wino_groups = (int)ceil_div(k, 3);
+    h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     *out = h;
     return VS_OK;
 }
@@ -1397,7 +1438,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     PackParams q;
     q.w = w; q.scale = scale; q.bias = bias; q.wp = h->wp.as<float>(); q.biasp = h->biasp.as<float>();
     q.kind = h->kind; q.c_in = h->c_in; q.c_out = h->c_out; q.k = h->k; q.up = h->dil; q.pad = h->pad; q.dmin = h->dmin;
-    q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags;
+    q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags; q.wino_tail1 = 0;
     const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
     if (h->wino_groups) {
@@ -1405,6 +1446,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         VS_TRY(h->wpw.reserve(nw * sizeof(float)));
         PackParams qw = q;
         qw.wp = h->wpw.as<float>();
+        qw.wino_tail1 = h->wino_k7 ? 1 : 0;
         hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)ceil_div((long long)nw, 256)), dim3(256), 0, s, qw, h->wino_groups,
                            h->nchunks);
     }
@@ -1548,7 +1590,8 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // fragment ring) only k >= 9 at dilation 1 (+10 %).  The dilated k=3 / k=7 convs lose 2..25 % (idle pair columns, 8-byte
     // epilogue runs, fewer MFMAs to hide the same staging behind) and stay on the direct engine.
     // VS_WINO_FORCE=1 / VS_NO_WINO=1: test / A-B switches.
-    const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9);
+    // k = 7 through the straight-line instances (direct-form last tap, 10/14 of the direct MFMAs): +11..22 % at every dilation.
+    const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9 || h->wino_k7);
     if (h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
         ConvParams q = p;
         q.wp = h->wpw.as<float>();
@@ -1558,9 +1601,10 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         // the vector epilogue stores float4 (dilation 1) / float2 runs: same alignment preconditions as the direct engine's
         // (Tout % 4 == 0 checked above covers both)
         const int span_w = 3 * h->wino_groups * h->dil;
-        if (h->dil == 1) return launch_wino_dil<1>(q, h->MT, span_w, s);
-        if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, s);
-        return launch_wino_dil<5>(q, h->MT, span_w, s);
+        const int spec = h->wino_k7 ? 7 : 0;
+        if (h->dil == 1) return launch_wino_dil<1>(q, h->MT, span_w, spec, s);
+        if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, spec, s);
+        return launch_wino_dil<5>(q, h->MT, span_w, spec, s);
     }
     // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,
     // coupling `pre` and last res/skip convs) AND the launch is short (T_mel-sized): there 64 x 256 blocks waste no MFMA

@@ -75,7 +75,7 @@ class ConvOp:
         if self.kind == L.CONV1D and self.c_out <= 4 and self.c_in * self.k <= 2048:
             return "conv_small_kernel"
         odd = (self.c_out // 32) % 2 == 1
-        pays = (self.k >= 9 and self.dil == 1) if odd else (self.dil == 1 or self.k >= 9)
+        pays = (self.k >= 9 and self.dil == 1) if odd else (self.dil == 1 or self.k >= 7)
         pays = pays or os.environ.get("VS_WINO_FORCE")
         if self.wino_eligible() and pays and not os.environ.get("VS_NO_WINO"):
             mt = self.c_out // 32
