@@ -572,7 +572,8 @@ __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float 
     for (int j = 0; j < 2; ++j) {
         xc[j][0] = xa[j][0];
         xc[j][1] = xb[j][0];
-        if constexpr (TAPS == 3) { xc[j][2] = xa[j][S2]; xc[j][3] = xb[j][S2]; }
+        if constexpr (TAPS >= 2) xc[j][2] = xa[j][S2];
+        if constexpr (TAPS == 3) xc[j][3] = xb[j][S2];
     }
 #pragma unroll
     for (int cp = 0; cp < 4; ++cp) {
@@ -581,7 +582,8 @@ __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float 
             for (int j = 0; j < 2; ++j) {
                 xn[j][0] = xa[j][(cp + 1) * 2 * RP];
                 xn[j][1] = xb[j][(cp + 1) * 2 * RP];
-                if constexpr (TAPS == 3) { xn[j][2] = xa[j][(cp + 1) * 2 * RP + S2]; xn[j][3] = xb[j][(cp + 1) * 2 * RP + S2]; }
+                if constexpr (TAPS >= 2) xn[j][2] = xa[j][(cp + 1) * 2 * RP + S2];
+                if constexpr (TAPS == 3) xn[j][3] = xb[j][(cp + 1) * 2 * RP + S2];
             }
         }
         float v[4][2];
@@ -592,6 +594,11 @@ __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float 
                 v[1][j] = xc[j][1] + xc[j][2];
                 v[2][j] = xc[j][2] - xc[j][1];
                 v[3][j] = xc[j][1] - xc[j][3];
+            } else if constexpr (TAPS == 2) {      // F(2,2): (x0 - x1) w0 -> M0, x1 (w0 + w1) -> M1, (x1 - x2) w1 -> M3
+                v[0][j] = xc[j][0] - xc[j][1];
+                v[1][j] = xc[j][1];
+                v[2][j] = 0.f;
+                v[3][j] = xc[j][1] - xc[j][2];
             } else {
                 v[0][j] = xc[j][0];
                 v[1][j] = 0.f;
@@ -605,6 +612,9 @@ __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float 
             if constexpr (TAPS == 1) {
                 if (xi == 1 || xi == 2) continue;          // (compile-time after unrolling)
             }
+            if constexpr (TAPS == 2) {
+                if (xi == 2) continue;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[xi][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp * 4 + xi], v[xi][j], acc[xi][j], 0, 0, 0);
@@ -613,7 +623,7 @@ __device__ __forceinline__ void wino_half_step(f32x16 (&acc)[4][2], const float 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < (TAPS == 3 ? 4 : 2); ++q) xc[j][q] = xn[j][q];
+            for (int q = 0; q < TAPS + 1; ++q) xc[j][q] = xn[j][q];
     }
 }
 
@@ -770,7 +780,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     };
     // ring depth: 3 slots (fragments requested two half-steps ahead), 2 for the widest workgroup shape (its 36 staging
     // registers do not leave room for the third slot)
-    constexpr int RING = (WAVES_N == 4) ? 2 : 3;
+    constexpr int RING = (WAVES_N == 4 || TG == 4) ? 2 : 3;
     if (nsteps > 0) load_a(a0, 0);
     if (RING == 3 && nsteps > 1) load_a(a1, 1);
 
@@ -831,6 +841,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
         for (int c = 0; c < p.nchunks; ++c) {
             step(F3, a0, a2); step(F3, a1, a0); step(F3, a2, a1); step(F3, a0, a2);
             step(TL, a1, a0); step(TL, a2, a1);
+        }
+    } else if constexpr (TG == 4) {
+        // k = 11: groups (3, 3, 3, 2 taps) -> eight half-steps per chunk on the 2-slot ring, the last two as F(2,2)
+        constexpr std::integral_constant<int, TT> TL{};
+        for (int c = 0; c < p.nchunks; ++c) {
+            step(F3, a0, a1); step(F3, a1, a0); step(F3, a0, a1); step(F3, a1, a0); step(F3, a0, a1); step(F3, a1, a0);
+            step(TL, a0, a1); step(TL, a1, a0);
         }
     } else if constexpr (RING == 3) {
         while (s < nsteps) {
@@ -1119,6 +1136,7 @@ __global__ void pack_wino_kernel(const PackParams q, int G, int nchunks) {
         const float w1 = (k0 + 1 < q.k) ? wr[k0 + 1] * sc : 0.f;
         const float w2 = (k0 + 2 < q.k) ? wr[k0 + 2] * sc : 0.f;
         if (q.wino_tail1 && k0 + 1 == q.k) val = (xi == 0) ? w0 : (xi == 3) ? -w0 : 0.f;       // single last tap: direct form
+        else if (q.wino_tail1 && k0 + 2 == q.k) val = (xi == 0) ? w0 : (xi == 1) ? (w0 + w1) : (xi == 3) ? w1 : 0.f;   // two: F(2,2)
         else val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
     }
     q.wp[e] = val;
@@ -1269,6 +1287,7 @@ struct vs_conv {
     vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), when wino_groups > 0
     int wino_groups = 0;                       // ceil(k / 3) if the conv is eligible for the F(2,3) path, else 0
     bool wino_k7 = false;                      // k = 7 on an even tile count: the TG = 3 instances (direct-form last tap)
+    bool wino_k11 = false;                     // k = 11: the TG = 4 instances (F(2,2) last group, 2-slot ring)
     bool has_bias = false;
 };
 
@@ -1311,20 +1330,24 @@ static int launch_wino(const ConvParams &p, hipStream_t s) {
 }
 
 template <int DIL>
-static int launch_wino_dil(ConvParams &p, int MT, int span_w, int spec, hipStream_t s) {      // spec: 0 generic, 7: k = 7 instances
-    // (k = 9 through the same straight-line structure, TT = 3, measured +1 %: not instantiated)
+static int launch_wino_dil(ConvParams &p, int MT, int span_w, int spec, hipStream_t s) {
+    // spec: 0 generic (zero-padded last group), 7 / 11: the k-specialised straight-line instances
+    // (k = 9 through the same structure, TG = 3 / TT = 3, measured +1 %: not instantiated)
     constexpr int NBW = 2 * ((64 / DIL) * DIL);
     if (MT % 4 == 0) {
         p.W = NBW + span_w;
         if (spec == 7) return launch_wino<DIL, 4, 1, 3, 1>(p, s);
+        if (spec == 11) return launch_wino<DIL, 4, 1, 4, 2>(p, s);
         return launch_wino<DIL, 4, 1>(p, s);
     }
     if (MT % 2 == 0) {
         p.W = 2 * NBW + span_w;
         if (spec == 7) return launch_wino<DIL, 2, 2, 3, 1>(p, s);
+        if (spec == 11) return launch_wino<DIL, 2, 2, 4, 2>(p, s);
         return launch_wino<DIL, 2, 2>(p, s);
     }
     p.W = 4 * NBW + span_w;
+    if (spec == 11 && DIL == 1) return launch_wino<1, 1, 4, 4, 2>(p, s);
     return launch_wino<DIL, 1, 4>(p, s);
 }
 
@@ -1407,6 +1430,7 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
         c_out % 32 == 0 && 3 * (int)ceil_div(k, 3) * dil <= MAX_SPAN)
         h->wino_groups = (int)ceil_div(k, 3);
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
+    h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
     *out = h;
     return VS_OK;
 }
@@ -1446,7 +1470,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         VS_TRY(h->wpw.reserve(nw * sizeof(float)));
         PackParams qw = q;
         qw.wp = h->wpw.as<float>();
-        qw.wino_tail1 = h->wino_k7 ? 1 : 0;
+        qw.wino_tail1 = (h->wino_k7 || h->wino_k11) ? 1 : 0;
         hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)ceil_div((long long)nw, 256)), dim3(256), 0, s, qw, h->wino_groups,
                            h->nchunks);
     }
@@ -1590,7 +1614,8 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // fragment ring) only k >= 9 at dilation 1 (+10 %).  The dilated k=3 / k=7 convs lose 2..25 % (idle pair columns, 8-byte
     // epilogue runs, fewer MFMAs to hide the same staging behind) and stay on the direct engine.
     // VS_WINO_FORCE=1 / VS_NO_WINO=1: test / A-B switches.
-    // k = 7 through the straight-line instances (direct-form last tap, 10/14 of the direct MFMAs): +11..22 % at every dilation.
+    // k = 7 through the straight-line instances (direct-form last tap, 10/14 of the direct MFMAs): +11..22 % at every dilation;
+    // k = 11 likewise with an F(2,2) last group (15/22): another 6 %.
     const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9 || h->wino_k7);
     if (h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
         ConvParams q = p;
@@ -1601,7 +1626,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         // the vector epilogue stores float4 (dilation 1) / float2 runs: same alignment preconditions as the direct engine's
         // (Tout % 4 == 0 checked above covers both)
         const int span_w = 3 * h->wino_groups * h->dil;
-        const int spec = h->wino_k7 ? 7 : 0;
+        const int spec = h->wino_k7 ? 7 : (h->wino_k11 ? 11 : 0);
         if (h->dil == 1) return launch_wino_dil<1>(q, h->MT, span_w, spec, s);
         if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, spec, s);
         return launch_wino_dil<5>(q, h->MT, span_w, spec, s);
