@@ -109,6 +109,14 @@ typedef struct vs_conv_io {
 
 VS_API int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream);
 
+/* One launch for a residual pair of the MRF blocks on the 32- / 64-channel stages (decoder.py:92-101):
+ *     y = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + res [+ acc] [* scale]
+ * conv1 / conv2 are existing handles (weights set): same channel count C in {32, 64}, same odd k <= 13, "same" padding, conv2
+ * undilated.  io: x, B, T, in_act = VS_IN_LRELU, out[0] = {y, res, acc, strides, scale}; no mask / bias_b / split / activation.
+ * vs_respair_supported() tells whether a pair qualifies (callers fall back to two vs_conv_forward launches otherwise).       */
+VS_API int vs_respair_supported(const vs_conv_t *conv1, const vs_conv_t *conv2);
+VS_API int vs_respair_forward(vs_conv_t *conv1, vs_conv_t *conv2, const vs_conv_io_t *io, void *stream);
+
 /* Weight gradient of a stride-1 (dilated) conv, the backward of nn.Conv1d under the training step (trainer.py:306-384 ->
  * autograd of encoder.py / flow.py / decoder.py convs):  gw[co, ci, k] = sum_{b,t} gy[b, co, t] * x[b, ci, t + k*dil - pad],
  * x read as 0 outside [0, T_in).  gy: [B, c_out, T_out], x: [B, c_in, T_in].  The reduction over (b, t) is cut into slices

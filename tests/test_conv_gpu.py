@@ -322,3 +322,31 @@ def test_conv_engine_random_sweep(seed, monkeypatch):
         conv_fuzz.main()
     finally:
         os.environ.pop("VS_WINO_FORCE", None)
+
+
+@pytest.mark.parametrize("C,k,d,T,B", [(32, 3, 1, 2048, 2), (32, 7, 3, 1500, 1), (32, 11, 5, 1024, 2), (64, 3, 5, 1000, 1),
+                                        (64, 7, 1, 700, 2), (64, 11, 3, 516, 1), (32, 5, 1, 37, 1), (32, 3, 3, 4, 2), (64, 9, 1, 250, 1)])
+def test_resblock_pair_fused_launch(oracle, C, k, d, T, B):
+    """csrc/resblock_pair.hip: y = conv2(lrelu(conv1(lrelu(x)))) + x [+ acc] [* scale] in one launch vs the fp64 oracle; tiles
+    in the interior (vector epilogue), at both sequence ends, lengths below one tile and not a multiple of 4 (element-wise
+    epilogue), every (k, dilation) of the MRF blocks."""
+    from visinger_amd.ops import ConvOp, respair_forward, respair_supported
+    r = rng(C * 31 + k * 7 + d + T)
+    x = r.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    w2 = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    b1, b2 = r.standard_normal(C).astype(np.float32), r.standard_normal(C).astype(np.float32)
+    accb = r.standard_normal((B, C, T)).astype(np.float32)
+    op1 = ConvOp(L.CONV1D, C, C, k, d, d * (k - 1) // 2)
+    op2 = ConvOp(L.CONV1D, C, C, k, 1, (k - 1) // 2)
+    op1.set_weights(dev(w1), None, dev(b1))
+    op2.set_weights(dev(w2), None, dev(b2))
+    assert respair_supported(op1, op2)
+    t = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w1, b1, dilation=d, padding=d * (k - 1) // 2)
+    ref = oracle.conv1d(oracle.leaky_relu(t), w2, b2, padding=(k - 1) // 2) + x
+    xd = dev(x)
+    y = respair_forward(op1, op2, xd, torch.empty_like(xd), res=xd)
+    close(y, ref)
+    acc_t = dev(accb)
+    respair_forward(op1, op2, xd, acc_t, res=xd, acc=acc_t, scale=1.0 / 3.0)       # in-place accumulate, MRF average
+    close(acc_t, (ref + accb) / 3.0)

@@ -77,6 +77,8 @@ def lib():
     L.vs_make_positions.argtypes = [_f32p, vp, i64, i64, i64, vp]
     L.vs_slice_segments.argtypes = [_f32p, vp, _f32p, i64, i64, i64, i64, vp]
     L.vs_mel2token_to_dur.argtypes = [vp, vp, i64, i64, i64, i64, vp]
+    L.vs_respair_supported.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.vs_respair_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ConvIO), ctypes.c_void_p]
     L.vs_conv_wgrad.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, i64, ci, ci, ci, vp]
     L.vs_conv_wgrad_planes.argtypes = [i64, i64, i64, i64, ci]
     L.vs_gconv1d_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]

@@ -1278,19 +1278,6 @@ static inline int ceil_div_i(int a, int b) { return -floor_div(-a, b); }
 
 static unsigned long long *g_stamp_buf = nullptr;   // debug hook, see vs_debug_set_stamp_buffer
 
-struct vs_conv {
-    int kind, c_in, c_out, k, dil, pad;   // dil = stride for transposed
-    unsigned flags;
-    int M, MT, MT_alloc, KT, CP, nchunks, off0, tstep, lo, span, dmin, Hh;
-    bool weights_set = false;
-    vs::DevBuf wp, biasp, scale, weff, beff;   // weff/beff: unpacked effective weights (c_out <= 4 VALU path)
-    vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), when wino_groups > 0
-    int wino_groups = 0;                       // ceil(k / 3) if the conv is eligible for the F(2,3) path, else 0
-    bool wino_k7 = false;                      // k = 7 on an even tile count: the TG = 3 instances (direct-form last tap)
-    bool wino_k11 = false;                     // k = 11: the TG = 4 instances (F(2,2) last group, 2-slot ring)
-    bool has_bias = false;
-};
-
 using namespace vs;
 
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N>

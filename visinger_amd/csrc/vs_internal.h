@@ -67,3 +67,19 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace vs
+
+// The conv handle of the C ABI (vs_conv_t), shared by conv_engine.hip (which owns it) and resblock_pair.hip (which runs two
+// of them in one launch).
+struct vs_conv {
+    int kind, c_in, c_out, k, dil, pad;   // dil = stride for transposed
+    unsigned flags;
+    int M, MT, MT_alloc, KT, CP, nchunks, off0, tstep, lo, span, dmin, Hh;
+    bool weights_set = false;
+    vs::DevBuf wp, biasp, scale, weff, beff;   // weff/beff: unpacked effective weights (c_out <= 4 VALU path)
+    vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), when wino_groups > 0
+    int wino_groups = 0;                       // ceil(k / 3) if the conv is eligible for the F(2,3) path, else 0
+    bool wino_k7 = false;                      // k = 7 on an even tile count: the TG = 3 instances (direct-form last tap)
+    bool wino_k11 = false;                     // k = 11: the TG = 4 instances (F(2,2) last group, 2-slot ring)
+    bool has_bias = false;
+};
+

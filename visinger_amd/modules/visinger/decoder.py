@@ -16,6 +16,7 @@ from torch.nn.utils import weight_norm, remove_weight_norm
 
 from ... import _lib as L
 from ... import autograd
+from ...ops import respair_forward, respair_supported
 from ..commons.utils import init_weights, get_padding
 from ..hipconv import HipConv1d, HipConvTranspose1d, mask2d, _forward_only_guard
 
@@ -102,11 +103,20 @@ class ResBlock1(torch.nn.Module):
         tmp = torch.empty_like(x)
         pp = [torch.empty_like(x) if n > 1 else None, torch.empty_like(x) if n > 2 else None]
         for i, (c1, c2) in enumerate(zip(self.convs1, self.convs2)):
+            last = i == n - 1
+            dst = out if last else pp[i % 2]
+            if mask is None:
+                # narrow stages (32 / 64 channels): the whole pair in one launch, the intermediate never leaves the CU
+                op1, op2 = c1._op(), c2._op()
+                if respair_supported(op1, op2, profitable_only=True):
+                    respair_forward(op1, op2, cur, dst, res=cur, acc=None if (first or not last) else out,
+                                    scale=scale if last else 1.0)
+                    cur = dst
+                    continue
             c1.run(cur, in_act=act, mask=mask, y=tmp)
-            if i < n - 1:
-                nxt = pp[i % 2]
-                c2.run(tmp, in_act=act, mask=mask, res=cur, y=nxt)
-                cur = nxt
+            if not last:
+                c2.run(tmp, in_act=act, mask=mask, res=cur, y=dst)
+                cur = dst
             else:
                 c2.run(tmp, in_act=act, mask=mask, res=cur, acc=None if first else out, y=out, scale=scale,
                        out_mask=mask is not None)

@@ -305,3 +305,37 @@ def gconv1d_bwd_weight(gy, x, k, stride, pad, groups):
     planes = torch.empty((B, Cout, Cin // groups, k), device=x.device, dtype=torch.float32)
     L.check(lib.vs_gconv1d_bwd_weight(L.ptr(gy), L.ptr(x), L.ptr(planes), B, Cin, Cout, T, k, stride, pad, groups, L.stream_ptr()))
     return planes.sum(0)
+
+
+def respair_supported(op1, op2, profitable_only=False):
+    """a11: can the (conv1, conv2) pair of a resblock run as one fused launch -- and, with profitable_only, did it measure
+    faster than the two launches (tools/pair_bench.py, B=32 production shapes): at 32 channels x1.32-1.47 for k=3, x1.14 for
+    k=7, a tie for k=11 (the F(2,3) kernel wins at dilation 1); at 64 channels only the dilated k=3 pairs (x1.06): from k=7 on
+    the separate F(2,3) launches do 30 % less matrix work than the fused direct form."""
+    if os.environ.get("VS_NO_RESPAIR") or not op1.lib.vs_respair_supported(op1.h, op2.h):
+        return False
+    if not profitable_only or os.environ.get("VS_RESPAIR_FORCE"):
+        return True
+    C, k, d = op1.c_in, op1.k, op1.dil
+    return (C == 32 and (k <= 7 or d > 1)) or (C == 64 and k == 3 and d > 1)
+
+
+def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
+    """a11: y = conv2(lrelu(conv1(lrelu(x)))) + res [+ acc] [* scale] in one launch (csrc/resblock_pair.hip)."""
+    B, C, T = x.shape
+    io = L.ConvIO()
+    io.x = L.ptr(x)
+    io.x_bs, io.B, io.T = 0, B, T
+    io.in_act = L.IN_LRELU
+    o = io.out[0]
+    o.y, o.res, o.acc = L.ptr(y), L.ptr(res), L.ptr(acc)
+    o.scale = scale
+    if PROFILER.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
+        e1.record()
+        PROFILER.records.append(("respair_kernel", op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), e0, e1))
+    else:
+        L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
+    return y
