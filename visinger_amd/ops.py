@@ -80,7 +80,13 @@ class ConvOp:
         if self.wino_eligible() and pays and not os.environ.get("VS_NO_WINO"):
             mt = self.c_out // 32
             cfg = "4,1" if mt % 4 == 0 else ("2,2" if mt % 2 == 0 else "1,4")
-            return f"conv_wino_kernel<{self.dil},{cfg}>"
+            spec = "0,3"                                    # generic; k = 7 / 11 have straight-line instances (TG, TT)
+            if not os.environ.get("VS_NO_WINO_K7"):
+                if self.k == 7 and mt % 2 == 0:
+                    spec = "3,1"
+                elif self.k == 11 and (mt % 2 == 0 or self.dil == 1):
+                    spec = "4,2"
+            return f"conv_wino_kernel<{self.dil},{cfg},{spec}>"
         rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
         mt = -(-rows // 32)
         if mt >= 3:
@@ -335,7 +341,7 @@ def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
         e0.record()
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
         e1.record()
-        PROFILER.records.append(("respair_kernel", op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), e0, e1))
+        PROFILER.records.append((f"respair_kernel<{'1,4' if C == 32 else '2,2'}>", op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), e0, e1))
     else:
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
     return y
