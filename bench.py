@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1024, help="T_mel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ragged", action="store_true", help="SURVEY 8d ragged variant: item lengths ~ U{T/2..T}, tails masked (mel2ph = 0)")
     ap.add_argument("--hidden", type=int, default=192, help="hidden_size (512 = the BASELINE config-5 width; fp32)")
     ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
                     help="256: the BASELINE.json benchmark variant (default); 300: the reference's own generator configuration")
@@ -217,7 +218,7 @@ def main():
     model = model.to(dev)
     B, T = args.batch, args.frames
     # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
-    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", hidden=args.hidden)
+    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", ragged=args.ragged, hidden=args.hidden)
     text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
 
     def step():
