@@ -436,8 +436,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
             constexpr int RPI = 64 / LPR;          // rows per wave-instruction
             constexpr int NIT = 8 / RPI;           // instructions per 8-row pass
             float *const Lw = smem + wave * 8 * CW;
-            const int lrow = lane / LPR;
-            const int c4 = (lane % LPR) * 4;
+            int lane_e = lane;                     // opaque copy: keeps the epilogue's address arithmetic out of the prologue
+            asm volatile("" : "+v"(lane_e));       // (see conv_wino_kernel)
+            const int lrow = lane_e / LPR;
+            const int c4 = (lane_e % LPR) * 4;
             const int colg = n0 + wn * CW + c4;
             float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f);
             if (use_mask) m4 = *reinterpret_cast<const float4 *>(maskb + colg);
@@ -694,15 +696,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     }
 
     // pair column -> first output of the pair, relative to the wave's first output
-    int posr[2], posw[2];
-    bool cvalid[2];
+    int posr[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = j * 32 + l31;
-        cvalid[j] = c < PW;
         const int t = (c / DIL) * (2 * DIL) + (c % DIL);
-        posr[j] = cvalid[j] ? t : 0;         // idle columns read a valid LDS address
-        posw[j] = cvalid[j] ? t : NBW;       // and write to the dump columns of the transposition buffer
+        posr[j] = (c < PW) ? t : 0;          // idle columns read a valid LDS address
     }
 
     float st[RPW][CIT];
@@ -882,6 +881,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
     const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
     const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
     const int nw = n0 + wn * NBW;                // first output of this wave
+    // pair column -> output position, recomputed from an opaque copy of the lane id (see below: keeps it out of the prologue)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    int posw[2], pose[2];
+    bool cvalid[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = j * 32 + (lane_e & 31);
+        const int t = (c / DIL) * (2 * DIL) + (c % DIL);
+        cvalid[j] = c < PW;
+        posw[j] = cvalid[j] ? t : NBW;       // idle columns write to the dump columns of the transposition buffer
+        pose[j] = cvalid[j] ? t : 0;
+    }
 
     if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M)) {
         constexpr int VEC = (DIL == 1) ? 4 : 2;
@@ -890,9 +902,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
         constexpr int NIT = 8 / RPI;
         typedef float vecf __attribute__((ext_vector_type(VEC)));
         float *const Lw = smem + wave * 8 * CWP;
-        const int lrow = lane / LPR;
-        const int cv = (lane % LPR) * VEC;
-        const bool active = lane < LPR * RPI;
+        // Everything below depends only on the lane and the launch parameters, so hipcc computes the 64-bit row addresses of
+        // the epilogue BEFORE the main loop and spills them across it (17-48 dwords per lane = 1 KB of scratch traffic per
+        // dword and workgroup, written and read back: +15..50 % of a workgroup's HBM traffic).  An opaque copy of the lane id
+        // taken after the loop keeps that arithmetic here.
+        const int lrow = lane_e / LPR;
+        const int cv = (lane_e % LPR) * VEC;
+        const bool active = lane_e < LPR * RPI;
         const int colg = nw + cv;
         vecf mv;
 #pragma unroll
@@ -967,8 +983,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
         };
         const bool simple = !has_acc && o.scale == 1.f && o.out_act == VS_OUT_NONE && !use_mask;
         if (simple) {
-            if (has_res) run(std::integral_constant<int, 4>{}, std::true_type{}, std::true_type{});
-            else run(std::integral_constant<int, 4>{}, std::true_type{}, std::false_type{});
+            if (has_res) run(std::integral_constant<int, 2>{}, std::true_type{}, std::true_type{});
+            else run(std::integral_constant<int, 2>{}, std::true_type{}, std::false_type{});
         } else if (has_res) {
             run(std::integral_constant<int, 2>{}, std::false_type{}, std::true_type{});
         } else {
@@ -980,13 +996,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_wino_kernel(co
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const int col = nw + posr[j] + hh * DIL;
+                const int col = nw + pose[j] + hh * DIL;
                 const bool okc = cvalid[j] && (col < p.N);
                 const int colc = min(col, p.Tout - 1);
                 const float mval = use_mask ? maskb[colc] : 1.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane_e >> 5);
                     const int rowc = min(row, p.M - 1);
                     const long long off = (long long)rowc * p.Tout + colc;
                     float v = (hh == 0 ? acc[0][j][r] : acc[3][j][r]);
