@@ -18,6 +18,8 @@ OUT_NONE, OUT_TANH, OUT_RELU = 0, 1, 2
 PAIR_GATE, PAIR_COUPLING_FWD, PAIR_COUPLING_INV = 0, 1, 2
 MODE_LINEAR, MODE_COUPLING_MEAN_FWD, MODE_COUPLING_MEAN_INV = 0, 1, 2
 FLIP_IN, FLIP_OUT = 1, 2
+# enum vs_conv_math
+MATH_F32, MATH_BF16, MATH_SPLIT6 = 0, 1, 6
 
 _f32p = ctypes.c_void_p
 
@@ -66,6 +68,8 @@ def lib():
     L.vs_conv_destroy.argtypes = [ctypes.c_void_p]
     L.vs_conv_destroy.restype = None
     L.vs_conv_set_weights.argtypes = [ctypes.c_void_p, _f32p, _f32p, _f32p, ctypes.c_void_p]
+    L.vs_conv_set_math.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.vs_conv_get_math.argtypes = [ctypes.c_void_p]
     L.vs_conv_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(ConvIO), ctypes.c_void_p]
     L.vs_conv_out_len.argtypes = [ctypes.c_void_p, ctypes.c_int64]
     L.vs_conv_out_len.restype = ctypes.c_int64

@@ -1,0 +1,84 @@
+// conv_common.h -- launch parameters and device helpers shared by the conv kernels of libvisinger_hip.so
+// (conv_engine.hip: fp32 MFMA + Winograd F(2,3); conv_split.hip: split-bf16 MFMA).
+#pragma once
+#include "vs_internal.h"
+
+namespace vs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CK = 16;        // input channels staged per LDS chunk
+constexpr int MAX_SPAN = 64;  // max (taps-1)*dilation supported by the LDS window
+constexpr int MT_ALLOC = 8;   // packed weights are zero-padded to a multiple of this many M tiles
+
+struct OutSpec {
+    float *y;
+    const float *res;
+    const float *acc;
+    long long y_bs, res_bs, acc_bs;
+    float scale;
+    int out_act, out_mask, mode;
+    int rows;    // rows addressable through res/acc (bounds of the buffer descriptors)
+};
+
+struct ConvParams {
+    const float *x;
+    long long x_bs;
+    const float *wp;      // packed weights
+    const float *biasp;   // packed bias over virtual rows (always present, zeros if no bias)
+    const float *bias_b;  // optional per-item bias over ORIGINAL rows
+    long long bias_b_bs;
+    const float *mask;    // [B, Tin]
+    float *logdet;
+    OutSpec out[2];
+    int split_row;
+    int kind, pair_mode, in_act;
+    int B, Cin, Tin;
+    int M;        // valid virtual rows
+    int MT;       // virtual M tiles
+    int N;        // virtual columns (time positions computed)
+    int Tout;     // true output length (row stride of y)
+    int c_out;    // original output rows
+    int Hh;       // PAIRED: half rows
+    int KT, CP, nchunks;
+    int off0, tstep, lo, W;
+    int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
+    int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
+    int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
+    int dbg;                    // perturbation experiments (VS_WINO_DBG: 1 = no weight-fragment loads, 2 = no staging), 0 in production
+    unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
+};
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// tanh via one exp: t = e^{-2|x|} in (0,1], tanh|x| = (1-t)/(1+t).  Branch-free; absolute error <= ~1e-7 (the
+// subtraction is exact, the error is t's rounding), which is what a tanh-bounded output needs.  The device
+// library's tanhf is branchy and would be inlined once per accumulator register.
+__device__ __forceinline__ float tanh_fast(float v) {
+    const float t = expf(-2.0f * fabsf(v));
+    return copysignf((1.0f - t) / (1.0f + t), v);
+}
+
+
+__device__ __forceinline__ void stamp(const ConvParams &p, int slot) {
+    if (p.stamps && threadIdx.x == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        p.stamps[(size_t)lin * 64 + slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 1 || slot == 2) p.stamps[(size_t)lin * 64 + 3 + slot] = __builtin_amdgcn_s_memtime();   // [4], [5]: shader clock
+        if (slot == 0) p.stamps[(size_t)lin * 64 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+    }
+}
+
+// conv_split.hip
+struct vs_split_pack {            // re-pack of the fp32 fragment-order weights into bf16 planes
+    const float *wp;              // Wp[m_tile][tap][chunk][quad(2)][64][4] (pack_conv_kernel)
+    void *ws;                     // Ws[m_tile][tap][chunk][plane][64 lanes][8 bf16]
+    int MT_alloc, KT, nchunks, terms;
+};
+int split_planes(int terms);
+int pack_split(const vs_split_pack &q, hipStream_t s);
+// cfg: tile shape as chosen by vs_conv_forward for the direct engine (0: 128 rows, 1/3: 64, 2: 32; 4/5: paired); span = receptive span
+int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);
+
+}  // namespace vs

@@ -21,7 +21,7 @@
 //
 // Tile: 4 waves (256 threads), each wave owns MT_W x NT_W accumulator tiles of 32x32 (16 VGPRs each); two
 // workgroups per CU (2 waves/SIMD) hide the staging of one behind the MFMAs of the other.
-#include "vs_internal.h"
+#include "conv_common.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -39,70 +39,6 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int CK = 16;        // input channels staged per LDS chunk
-constexpr int MAX_SPAN = 64;  // max (taps-1)*dilation supported by the LDS window
-constexpr int MT_ALLOC = 8;   // packed weights are zero-padded to a multiple of this many M tiles
-
-struct OutSpec {
-    float *y;
-    const float *res;
-    const float *acc;
-    long long y_bs, res_bs, acc_bs;
-    float scale;
-    int out_act, out_mask, mode;
-    int rows;    // rows addressable through res/acc (bounds of the buffer descriptors)
-};
-
-struct ConvParams {
-    const float *x;
-    long long x_bs;
-    const float *wp;      // packed weights
-    const float *biasp;   // packed bias over virtual rows (always present, zeros if no bias)
-    const float *bias_b;  // optional per-item bias over ORIGINAL rows
-    long long bias_b_bs;
-    const float *mask;    // [B, Tin]
-    float *logdet;
-    OutSpec out[2];
-    int split_row;
-    int kind, pair_mode, in_act;
-    int B, Cin, Tin;
-    int M;        // valid virtual rows
-    int MT;       // virtual M tiles
-    int N;        // virtual columns (time positions computed)
-    int Tout;     // true output length (row stride of y)
-    int c_out;    // original output rows
-    int Hh;       // PAIRED: half rows
-    int KT, CP, nchunks;
-    int off0, tstep, lo, W;
-    int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
-    int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
-    int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
-    int dbg;                    // perturbation experiments (VS_WINO_DBG: 1 = no weight-fragment loads, 2 = no staging), 0 in production
-    unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
-};
-
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.1f * v; }
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
-// tanh via one exp: t = e^{-2|x|} in (0,1], tanh|x| = (1-t)/(1+t).  Branch-free; absolute error <= ~1e-7 (the
-// subtraction is exact, the error is t's rounding), which is what a tanh-bounded output needs.  The device
-// library's tanhf is branchy and would be inlined once per accumulator register.
-__device__ __forceinline__ float tanh_fast(float v) {
-    const float t = expf(-2.0f * fabsf(v));
-    return copysignf((1.0f - t) / (1.0f + t), v);
-}
-
-
-__device__ __forceinline__ void stamp(const ConvParams &p, int slot) {
-    if (p.stamps && threadIdx.x == 0) {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        p.stamps[(size_t)lin * 64 + slot] = __builtin_amdgcn_s_memrealtime();
-        if (slot == 1 || slot == 2) p.stamps[(size_t)lin * 64 + 3 + slot] = __builtin_amdgcn_s_memtime();   // [4], [5]: shader clock
-        if (slot == 0) p.stamps[(size_t)lin * 64 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
-                                                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
-    }
-}
 
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(const ConvParams p) {
@@ -340,213 +276,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(co
     }
 
     stamp(p, 2);
-    // ------------------------------------------------------------------ epilogue
-    // All loops have constant trip counts and no early exits (acc[][][] must stay in registers); every global
-    // LOAD is unconditional on a clamped address and issued NT_W at a time ahead of its uses, only the STORES are
-    // predicated -- a predicated load would cost a branch and a full vmcnt(0) drain per element.
-    int ncol[NT_W];
-#pragma unroll
-    for (int j = 0; j < NT_W; ++j) ncol[j] = n0 + (wn * NT_W + j) * 32 + l31;
-
-    // (the host dispatches PAIRED convs to the MT_W == 2 instances only, and every other kind to MT_W == 1)
-    if constexpr (MT_W == 2) {
-        {
-            // tiles (2i, 2i+1) of this wave hold rows c (first half) and Hh + c (second half)
-            const OutSpec o = p.out[0];
-            const int pair = mt0 >> 1;
-            const int pmode = p.pair_mode;
-            float ld_sum = 0.f;
-            float mval[NT_W];
-#pragma unroll
-            for (int j = 0; j < NT_W; ++j) mval[j] = maskb ? maskb[min(ncol[j], p.Tin - 1)] : 1.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rt = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                const int c = pair * 32 + rt;
-                const bool okc = c < p.Hh;
-                const int cc = min(c, p.Hh - 1);
-                float x1[NT_W];
-                if (pmode != VS_PAIR_GATE) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j)
-                        x1[j] = o.res[(long long)b * o.res_bs + (long long)cc * p.Tout + min(ncol[j], p.Tout - 1)];
-                }
-#pragma unroll
-                for (int j = 0; j < NT_W; ++j) {
-                    const float v0 = acc[0][j][r], v1 = acc[1][j][r];
-                    const bool ok = okc && ncol[j] < p.N;
-                    float outv;
-                    if (pmode == VS_PAIR_GATE) {
-                        outv = tanh_fast(v0) * sigmoidf_(v1);
-                    } else {
-                        const float m = v0 * mval[j], logs = v1 * mval[j];
-                        if (pmode == VS_PAIR_COUPLING_FWD) {
-                            outv = m + x1[j] * expf(logs) * mval[j];
-                            ld_sum += ok ? logs : 0.f;
-                        } else {
-                            outv = (x1[j] - m) * expf(-logs) * mval[j];
-                        }
-                    }
-                    if (ok) o.y[(long long)b * o.y_bs + (long long)c * p.Tout + ncol[j]] = outv;
-                }
-            }
-            if (pmode == VS_PAIR_COUPLING_FWD && p.logdet) {
-#pragma unroll
-                for (int s = 32; s > 0; s >>= 1) ld_sum += __shfl_xor(ld_sum, s);
-                if (lane == 0) atomicAdd(p.logdet + b, ld_sum);
-            }
-        }
-        return;
-    }
-
-    if constexpr (MT_W == 1) {
-    // Every 32-row tile goes to exactly one output spec (the host guarantees split_row % 32 == 0 or launches the
-    // two specs separately with a row window), so the spec, its null-checks and its mode are wave-uniform.
-    //
-    // Residual / accumulate reads are issued RB rows (RB * NT_W loads per lane) at a time before the first use: each
-    // batch exposes one HBM round trip (2-4 us with the whole chip in its epilogue), so a one-row batch (16 round
-    // trips per tile) cost ~0.9 ms of a 2.3 ms launch at C=128, k=3.  RB*NT_W = 32 loads in flight per lane when only
-    // `res` is read, 2 x 16 when `acc` is read as well (more spills: 128 accumulators + per-row metadata).
-    const bool transposed = (p.kind == VS_CONV_TRANSPOSE1D);
-#pragma unroll
-    for (int i = 0; i < MT_W; ++i) {
-        const int tile_row0 = (mt0 + i) * 32;
-        const bool s1 = (p.split_row > 0) && (tile_row0 >= p.split_row);
-        const OutSpec o = s1 ? p.out[1] : p.out[0];
-        const int row_sub = s1 ? p.split_row : 0;
-        const bool has_res = o.res != nullptr, has_acc = o.acc != nullptr;
-        const bool use_mask = (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
-        float *const yb = o.y + (long long)b * o.y_bs;
-        const int spec_bytes = (int)((long long)o.rows * p.Tout * 4);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(has_res ? o.res + (long long)b * o.res_bs : yb), 0, spec_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(has_acc ? o.acc + (long long)b * o.acc_bs : yb), 0, spec_bytes, 0x00020000);
-        // ---- fast path: interior tile of a plain conv.  The accumulator tile (row = register, column = lane) is
-        // transposed through the now-idle staging LDS, 8 rows at a time, so that every global access of the epilogue
-        // is one 16-B-per-lane instruction over a contiguous run of a row (1 KiB per wave-instruction at NT_W = 8)
-        // instead of 4-B stores split over two rows, and the per-element predicate / address arithmetic disappears.
-        // (Measured on the element-wise path: 44 us of a 138 us workgroup at C=128, k=3 WITHOUT any store or
-        // residual load -- instruction-issue-bound, not memory-bound.)
-        // (a last tile with 8, 16 or 24 valid rows -- the 16-channel stage of the reference's hop-300 generator -- runs the
-        // same path with fewer 8-row passes)
-        if (p.fast_epi && (n0 + BN <= p.N) && (tile_row0 + 32 <= p.M || (p.M % 8 == 0 && tile_row0 < p.M))) {
-            constexpr int CW = 32 * NT_W;          // columns of this wave's tile
-            constexpr int LPR = CW / 4;            // lanes per row (float4 each)
-            constexpr int RPI = 64 / LPR;          // rows per wave-instruction
-            constexpr int NIT = 8 / RPI;           // instructions per 8-row pass
-            float *const Lw = smem + wave * 8 * CW;
-            int lane_e = lane;                     // opaque copy: keeps the epilogue's address arithmetic out of the prologue
-            asm volatile("" : "+v"(lane_e));       // (see conv_wino_kernel)
-            const int lrow = lane_e / LPR;
-            const int c4 = (lane_e % LPR) * 4;
-            const int colg = n0 + wn * CW + c4;
-            float4 m4 = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (use_mask) m4 = *reinterpret_cast<const float4 *>(maskb + colg);
-            const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
-            const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                if (tile_row0 + 8 * ps >= p.M) break;      // wave-uniform: rows beyond M do not exist
-                float4 r4[NIT], a4[NIT];
-                long long goff[NIT];
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    goff[it] = (long long)(tile_row0 - row_sub + 8 * ps + it * RPI + lrow) * p.Tout + colg;
-                    if (has_res) r4[it] = *reinterpret_cast<const float4 *>(resp + goff[it]);
-                    if (has_acc) a4[it] = *reinterpret_cast<const float4 *>(accp + goff[it]);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j)
-                        Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = acc[i][j][4 * ps + q];
-                }
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    float4 v = *reinterpret_cast<const float4 *>(Lw + (it * RPI + lrow) * CW + c4);
-                    if (has_res) { v.x += r4[it].x; v.y += r4[it].y; v.z += r4[it].z; v.w += r4[it].w; }
-                    if (has_acc) { v.x += a4[it].x; v.y += a4[it].y; v.z += a4[it].z; v.w += a4[it].w; }
-                    if (o.scale != 1.f) { v.x *= o.scale; v.y *= o.scale; v.z *= o.scale; v.w *= o.scale; }
-                    if (o.out_act == VS_OUT_TANH) {
-                        v.x = tanh_fast(v.x); v.y = tanh_fast(v.y); v.z = tanh_fast(v.z); v.w = tanh_fast(v.w);
-                    } else if (o.out_act == VS_OUT_RELU) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    if (use_mask) { v.x *= m4.x; v.y *= m4.y; v.z *= m4.z; v.w *= m4.w; }
-                    *reinterpret_cast<float4 *>(yb + goff[it]) = v;
-                }
-            }
-        } else {
-
-        float mv[NT_W];
-#pragma unroll
-        for (int j = 0; j < NT_W; ++j) mv[j] = 1.f;
-        if (use_mask) {
-#pragma unroll
-            for (int j = 0; j < NT_W; ++j) mv[j] = maskb[min(ncol[j], p.Tout - 1)];   // (never with a transposed conv)
-        }
-
-        auto run = [&](auto rb_tag, auto acc_tag) __attribute__((always_inline)) {
-            constexpr int RB = decltype(rb_tag)::value;
-            constexpr bool WITH_ACC = decltype(acc_tag)::value;
-#pragma unroll
-            for (int nb = 0; nb < 16 / RB; ++nb) {
-                float rv[RB][NT_W], av[WITH_ACC ? RB : 1][NT_W];
-                int roff[RB], phase_[RB];
-                bool okm[RB];
-#pragma unroll
-                for (int q = 0; q < RB; ++q) {
-                    const int r = nb * RB + q;
-                    const int m = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                    const int mc = min(m, p.M - 1);
-                    int row = mc, phase = 0;
-                    if (transposed) { phase = mc / p.c_out; row = mc - phase * p.c_out; }
-                    okm[q] = (m < p.M) && (row >= p.row_lo) && (row < p.row_hi);
-                    phase_[q] = phase;
-                    // (rows below row_lo belong to the other pass of a two-pass split launch: they are not stored, and their
-                    // loads must not reach below the destination, whose pointer was moved back by split_row rows)
-                    roff[q] = (max(row, p.row_lo) - row_sub) * p.Tout;       // < 2^31: one item's rows * T_out
-                    // (res / acc are never combined with a transposed conv: host-checked)
-                    const int voff = (roff[q] + ncol[0]) * 4;
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j) {
-                        rv[q][j] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + j * 128, 0, 0)) : 0.f;
-                        if constexpr (WITH_ACC)
-                            av[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(asrc, voff + j * 128, 0, 0));
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < RB; ++q) {
-                    const int r = nb * RB + q;
-                    float *const y = yb + roff[q];
-#pragma unroll
-                    for (int j = 0; j < NT_W; ++j) {
-                        const int col = transposed ? ncol[j] * p.up + phase_[q] : ncol[j];
-                        const float v = acc[i][j][r];
-                        float outv;
-                        if (o.mode == VS_OUT_LINEAR) {
-                            outv = v + rv[q][j];
-                            if constexpr (WITH_ACC) outv += av[q][j];
-                            outv *= o.scale;
-                            if (o.out_act == VS_OUT_TANH) outv = tanh_fast(outv);
-                            else if (o.out_act == VS_OUT_RELU) outv = fmaxf(outv, 0.f);
-                            outv *= mv[j];
-                        } else if (o.mode == VS_OUT_COUPLING_MEAN_FWD) {
-                            outv = v * mv[j] + rv[q][j] * mv[j];
-                        } else {
-                            outv = (rv[q][j] - v * mv[j]) * mv[j];
-                        }
-                        if (okm[q] && ncol[j] < p.N && col < p.Tout) y[col] = outv;
-                    }
-                }
-            }
-        };
-        if (has_acc) run(std::integral_constant<int, (NT_W >= 8 ? 2 : 4)>{}, std::true_type{});
-        else run(std::integral_constant<int, (NT_W >= 8 ? 4 : 8)>{}, std::false_type{});
-        }   // element-wise path
-    }
-    }   // MT_W == 1
+#include "conv_epilogue.inc"
     if (p.stamps) {
         __builtin_amdgcn_s_waitcnt(0);   // all stores acknowledged
         stamp(p, 3);
@@ -1434,9 +1164,32 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
         h->wino_groups = (int)ceil_div(k, 3);
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
+    if (const char *e = getenv("VS_CONV_MATH")) {       // A/B switch: default arithmetic of every conv created from here on
+        const int m = atoi(e);
+        if (m == 1 || m == 6) h->math = m;
+    }
     *out = h;
     return VS_OK;
 }
+
+static int pack_split_planes(vs_conv *h, hipStream_t s) {
+    const int npl = split_planes(h->math);
+    VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * npl * 64 * 16));
+    vs_split_pack q;
+    q.wp = h->wp.as<float>(); q.ws = h->ws.p; q.MT_alloc = h->MT_alloc; q.KT = h->KT; q.nchunks = h->nchunks; q.terms = h->math;
+    return pack_split(q, s);
+}
+
+int vs_conv_set_math(vs_conv_t *h, int math, void *stream) {
+    VS_REQUIRE(h, "vs_conv_set_math: NULL handle");
+    VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6, "vs_conv_set_math: unknown arithmetic %d", math);
+    if (h->math == math) return VS_OK;
+    h->math = math;
+    if (math && h->weights_set) VS_TRY(pack_split_planes(h, as_stream(stream)));
+    return VS_OK;
+}
+
+int vs_conv_get_math(const vs_conv_t *h) { return h ? h->math : -1; }
 
 void vs_conv_destroy(vs_conv_t *h) { delete h; }
 
@@ -1489,6 +1242,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         }
     }
     VS_CHECK_HIP(hipGetLastError());
+    if (h->math) VS_TRY(pack_split_planes(h, s));
     h->weights_set = true;
     return VS_OK;
 }
@@ -1596,6 +1350,10 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     if (h->kind == VS_CONV1D_PAIRED) {
         p.row_lo = 0;
         p.row_hi = h->c_out;
+        if (h->math) {
+            p.wp = h->ws.as<float>();
+            return launch_split(p, (h->MT >= 4) ? 4 : 5, h->math, h->span, s);
+        }
         if (h->MT >= 4) { p.W = 128 + h->span; return launch_cfg<2, 2, 2, 2>(p, s); }
         p.W = 256 + h->span;
         return launch_cfg<2, 2, 1, 4>(p, s);
@@ -1620,7 +1378,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // k = 7 through the straight-line instances (direct-form last tap, 10/14 of the direct MFMAs): +11..22 % at every dilation;
     // k = 11 likewise with an F(2,2) last group (15/22): another 6 %.
     const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9 || h->wino_k7);
-    if (h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
+    if (!h->math && h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
         ConvParams q = p;
         q.wp = h->wpw.as<float>();
         q.KT = h->wino_groups;
@@ -1642,7 +1400,9 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     if (h->MT >= 3) cfg = ((h->MT % 4) == 2) ? (((long long)p.N * p.B <= 65536) ? 3 : 1) : 0;
     else cfg = (h->MT == 2) ? 1 : 2;
     if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
+    if (h->math) p.wp = h->ws.as<float>();
     auto launch = [&](const ConvParams &q) -> int {
+        if (h->math) return launch_split(q, cfg, h->math, h->span, s);
         switch (cfg) {
             case 0: return launch_cfg<1, 8, 4, 1>(q, s);
             case 1: return launch_cfg<1, 8, 2, 2>(q, s);

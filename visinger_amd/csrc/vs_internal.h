@@ -81,5 +81,7 @@ struct vs_conv {
     bool wino_k7 = false;                      // k = 7 on an even tile count: the TG = 3 instances (direct-form last tap)
     bool wino_k11 = false;                     // k = 11: the TG = 4 instances (F(2,2) last group, 2-slot ring)
     bool has_bias = false;
+    int math = 0;                              // 0: fp32 MFMA / F(2,3); 6: split-bf16 x6 (fp32 class); 1: bf16 (conv_split.hip)
+    vs::DevBuf ws;                             // bf16 plane fragments of the split engine, when math != 0
 };
 

@@ -55,6 +55,15 @@ class ConvOp:
         self.h = h
         self._wkey = None
 
+    @property
+    def math(self):
+        """arithmetic of the contraction (L.MATH_F32 / MATH_SPLIT6 / MATH_BF16, include/visinger_hip.h vs_conv_math)"""
+        return int(self.lib.vs_conv_get_math(self.h))
+
+    def set_math(self, math):
+        L.check(self.lib.vs_conv_set_math(self.h, int(math), L.stream_ptr()))
+        return self
+
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
         if h:
@@ -69,11 +78,22 @@ class ConvOp:
     def kernel_instance(self):
         """Name of the conv_mfma_kernel<MT_W,NT_W,WAVES_M,WAVES_N> instance vs_conv_forward dispatches to
         (mirrors the selection in csrc/conv_engine.hip)."""
+        math = self.math
         if self.kind == L.CONV1D_PAIRED:
             mt = 2 * -(-(self.c_out // 2) // 32)
+            if math:
+                return f"conv_split_kernel<2,2,2,2,{math}>" if mt >= 4 else f"conv_split_kernel<2,2,1,4,{math}>"
             return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
         if self.kind == L.CONV1D and self.c_out <= 4 and self.c_in * self.k <= 2048:
             return "conv_small_kernel"
+        if math:
+            rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
+            mt = -(-rows // 32)
+            if mt >= 3:
+                cfg = "1,4,2,2" if mt % 4 == 2 else "1,8,4,1"
+            else:
+                cfg = "1,4,2,2" if mt == 2 else "1,2,1,4"
+            return f"conv_split_kernel<{cfg},{math}>"
         odd = (self.c_out // 32) % 2 == 1
         pays = (self.k >= 9 and self.dil == 1) if odd else (self.dil == 1 or self.k >= 7)
         pays = pays or os.environ.get("VS_WINO_FORCE")
