@@ -12,9 +12,9 @@ Inputs (tokens, mel2ph, noise) are resident in HBM before the timed region; weig
 reference architecture (no checkpoints offline).  Multi-GPU = one process per GPU, utterances sharded by the
 reference's strided rule (batch[rank::world], tasks/base.py:130-133), no data-path collective -> weak scaling.
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (the fp32-MFMA
-implicit-GEMM conv instance with the largest share of the step), from HIP events recorded around each of its
-launches inside the timed steps; `cpu_baseline` is the CPU oracle ("port") timed on a bounded sample.
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (the implicit-GEMM conv
+instance with the largest share of the step: a split-bf16 MFMA instance by default), from HIP events recorded around
+each of its launches inside the timed steps; `cpu_baseline` is the CPU oracle ("port") timed on a bounded sample.
 """
 import argparse
 import json
@@ -31,6 +31,10 @@ sys.path.insert(0, ROOT)
 HOP = 256
 SR = 22050
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense bf16 (no sparsity)
+MATH = {"split6": 6, "f32": 0, "bf16": 1}
+DTYPE = {"split6": "f32 (operands split exactly into 3 bf16 planes, 6 cross products on the bf16 MFMA, fp32 accumulate)",
+         "f32": "f32", "bf16": "bf16 operands, f32 accumulate (f32 tensors in HBM)"}
 
 
 def synthetic_batch(B, T, Tph, ph_dict, seed, device, ragged=False, hidden=192):
@@ -158,10 +162,16 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected
     from inside the timed run: they need rocprofv3 and one pass per counter); None when not recorded."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch_corrected"]
+        for tag in ("r01_e", "r01_c"):
+            path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+            if os.path.exists(path):
+                with open(path) as f:
+                    ks = json.load(f)["kernels"]
+                if kernel in ks:
+                    return ks[kernel]["hbm_bytes_per_launch_corrected"]
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
 def pmc_mfma_executed(kernel):
@@ -188,7 +198,11 @@ def main():
     ap.add_argument("--hidden", type=int, default=192, help="hidden_size (512 = the BASELINE config-5 width; fp32)")
     ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
                     help="256: the BASELINE.json benchmark variant (default); 300: the reference's own generator configuration")
+    ap.add_argument("--math", default="split6", choices=tuple(MATH),
+                    help="arithmetic of the conv engine (include/visinger_hip.h vs_conv_math): split6 = fp32-class split-bf16 "
+                         "(default, the headline), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 operands (BASELINE config 5)")
     args = ap.parse_args()
+    os.environ["VS_CONV_MATH"] = str(MATH[args.math])      # read by vs_conv_create: before any conv handle exists
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -251,6 +265,22 @@ def main():
         name, d = dom
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for v in prof.values())
+        if name.startswith("conv_split_kernel"):
+            terms = int(name.rstrip(">").split(",")[-1])
+            executed = achieved * terms
+            roof = {"bound": "mfma", "kernel": name, "achieved": executed, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": executed / BF16_MFMA_PEAK_TFLOPS,
+                    "algorithmic_tflops": achieved, "algorithmic_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "note": f"achieved = bf16-MFMA FLOPs the algorithm needs = {terms} x the conv's 2*MAC count (each fp32 product is "
+                            f"{terms} bf16 cross products; nothing else is executed on the pipe) / measured time, against the dense "
+                            "bf16 MFMA peak; algorithmic_tflops counts the conv's own 2*MAC only.  Under this load the chip clocks "
+                            "at ~1.55-1.6 GHz (power), i.e. ~0.65 of the 2.4 GHz the peak is quoted at (tools/conv_stamps.py)"}
+        else:
+            roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "note": "achieved = ALGORITHMIC (direct-form) FLOPs / time; the F(2,3) minimal-filtering instances execute "
+                            "4/6 (k=3, 9), 10/14 (k=7), 15/22 (k=11) of them on the matrix pipe, so achieved can exceed the MFMA "
+                            "peak: mfma_executed is what the pipe really did"}
         out = {
             "metric": "audio samples/sec (22.05 kHz) + flow log-det rel-err, B=32 T_mel=1024",
             "value": samples / dt,
@@ -262,20 +292,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE[args.math],
             "data": "synthetic",
             "config": {"workload": f"VISinger synthesis (text-enc + pitch-pred + frame-prior + flow-inverse + HiFi-GAN), "
                                    f"B={B}/GPU T_mel={T} hop={HOP} fp32, random-init weights",
                        "per_gpu_batch": B, "global_batch": B * world, "t_mel": T, "hop": HOP,
                        "parallelism": f"dp{world} (utterance shard, no collective)",
                        "realtime_factor": samples / dt / SR},
-            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(name),
+            "roofline": dict(roof, **{"traffic": pmc_traffic(name),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
-                                         "recorded run: profiles/r01_c_pmc_traffic.json)",
-                         "note": "achieved = ALGORITHMIC (direct-form) FLOPs / time; the F(2,3) minimal-filtering instances execute "
-                                 "4/6 (k=3, 9), 10/14 (k=7), 15/22 (k=11) of them on the matrix pipe, so achieved can exceed the MFMA peak: "
-                                 "mfma_executed is what the pipe really did",
+                                         "recorded run: profiles/r01_*_pmc_traffic.json)",
                          "mfma_executed": pmc_mfma_executed(name),
                          "launches_per_step": d["launches"] / args.steps,
                          "avg_launch_ms": d["ms"] / d["launches"],
@@ -284,7 +310,7 @@ def main():
                          "all_conv_instances": {k: {"ms_per_step": v["ms"] / args.steps,
                                                     "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
                                                 for k, v in prof.items()},
-                         "conv_engine_share_of_step": conv_ms / (dt * 1e3)},
+                         "conv_engine_share_of_step": conv_ms / (dt * 1e3)}),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, hp)

@@ -80,9 +80,9 @@ VS_API void vs_conv_destroy(vs_conv_t *h);
 VS_API int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const float *bias, void *stream);
 
 /* Arithmetic of the matrix contraction of one conv handle (inputs, outputs and accumulation are fp32 in every mode):
- *   VS_MATH_F32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), Winograd F(2,3) instances where they measured faster (default)
+ *   VS_MATH_F32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), Winograd F(2,3) instances where they measured faster
  *   VS_MATH_SPLIT6 operands split exactly into three bf16 planes, the six leading cross products on v_mfma_f32_32x32x16_bf16:
- *                  fp32-class result (dropped terms <= 2^-23 relative per product) at 16/6 of the fp32 matrix rate
+ *                  fp32-class result (dropped terms <= 2^-23 relative per product) at 16/6 of the fp32 matrix rate (default)
  *   VS_MATH_BF16   operands rounded to bf16 (RNE), fp32 accumulate: BASELINE.json's long-form bf16 configuration
  * May be called before or after vs_conv_set_weights (the bf16 planes are re-packed from the fp32 fragments).
  * No reference counterpart: its arithmetic is whatever torch picks (config/models/base_config.yaml:5 `amp: false` = fp32).   */

@@ -277,7 +277,7 @@ def test_conv1d_winograd_path(oracle, monkeypatch, B, Cin, Cout, T, k, dil):
     mask[-1, (2 * T) // 3:] = 0
     w = oracle.weight_norm(v, g)
     pad = (k * dil - dil) // 2
-    op = ConvOp(L.CONV1D, Cin, Cout, k, dil, pad)
+    op = ConvOp(L.CONV1D, Cin, Cout, k, dil, pad).set_math(L.MATH_F32)
     assert op.kernel_instance().startswith("conv_wino_kernel"), op.kernel_instance()
     op.set_weights(dev(v), dev(g), dev(bias))
     conv = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w, bias, dilation=dil, padding=pad)
@@ -298,7 +298,7 @@ def test_winograd_matches_direct_engine_at_size(monkeypatch):
     x = torch.randn(B, C, T, device="cuda")
     w = torch.randn(C, C, k, device="cuda") / (C * k) ** 0.5
     bias = torch.randn(C, device="cuda")
-    op = ConvOp(L.CONV1D, C, C, k, dil, (k * dil - dil) // 2)
+    op = ConvOp(L.CONV1D, C, C, k, dil, (k * dil - dil) // 2).set_math(L.MATH_F32)
     op.set_weights(w, None, bias)
     monkeypatch.setenv("VS_WINO_FORCE", "1")
     y_w = op.forward(x, in_act=L.IN_LRELU, res=x)

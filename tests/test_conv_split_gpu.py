@@ -1,0 +1,108 @@
+"""The split-bf16 conv engine (csrc/conv_split.hip, vs_conv_set_math) through the C ABI: parity with the fp64 oracle for every
+conv kind and fused epilogue, error no larger than the fp32 MFMA engine's, bf16 mode within a bf16 tolerance, and re-packing
+when the arithmetic of a live handle changes.  (Reference sites: the nn.Conv1d / ConvTranspose1d calls listed in
+include/visinger_hip.h; the oracle restates torch's conv arithmetic in fp64.)"""
+import numpy as np
+import pytest
+import torch
+
+from visinger_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rel_rms(y, ref):
+    e = y.detach().cpu().double().numpy() - ref
+    return float(np.sqrt((e ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), 1e-30))
+
+
+@pytest.mark.parametrize("C,k,d,T", [(128, 3, 1, 2048), (128, 7, 3, 1500), (256, 11, 1, 777), (64, 11, 5, 4096), (32, 7, 1, 3000),
+                                      (192, 5, 1, 1000), (96, 1, 1, 513)])
+def test_split6_error_not_above_fp32_mfma(oracle, monkeypatch, C, k, d, T):
+    """the six-product split keeps the fp32 class: its RMS error against fp64 is not above the exact-fp32 MFMA engine's
+    direct form (both are dominated by fp32 accumulation rounding; tools/conv_accuracy.py prints the table)"""
+    from visinger_amd.ops import ConvOp
+    monkeypatch.setenv("VS_NO_WINO", "1")        # MATH_F32 = the direct fp32 MFMA kernel, not its F(2,3) variant
+    r = np.random.default_rng(C * 31 + k * 7 + d + T)
+    x = r.standard_normal((2, C, T)).astype(np.float32)
+    w = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    bias = r.standard_normal(C).astype(np.float32)
+    pad = d * (k - 1) // 2
+    ref = oracle.conv1d(x.astype(np.float64), w, bias, dilation=d, padding=pad)
+    errs = {}
+    for math in (L.MATH_F32, L.MATH_SPLIT6, L.MATH_BF16):
+        op = ConvOp(L.CONV1D, C, C, k, d, pad).set_math(math)
+        assert op.math == math
+        op.set_weights(dev(w), None, dev(bias))
+        errs[math] = rel_rms(op.forward(dev(x)), ref)
+    assert errs[L.MATH_SPLIT6] <= 1.25 * errs[L.MATH_F32] + 1e-8, errs
+    assert errs[L.MATH_SPLIT6] <= 3e-6, errs
+    assert 1e-4 < errs[L.MATH_BF16] <= 6e-3, errs          # bf16 operands: ~2^-9 per product, fp32 accumulate
+
+
+def test_split_kernel_instances_and_repack(oracle):
+    """vs_conv_set_math on a handle whose weights are already packed re-packs the bf16 planes; the three arithmetics of one
+    handle agree with the oracle in turn"""
+    from visinger_amd.ops import ConvOp
+    r = np.random.default_rng(5)
+    B, Cin, Cout, T, k = 2, 48, 160, 700, 5
+    x = r.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (r.standard_normal((Cout, Cin, k)) / np.sqrt(Cin * k)).astype(np.float32)
+    ref = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w, None, padding=2)
+    op = ConvOp(L.CONV1D, Cin, Cout, k, 1, 2)
+    assert op.math == L.MATH_SPLIT6 and op.kernel_instance().startswith("conv_split_kernel")
+    op.set_weights(dev(w), None, None)
+    for math, tol in ((L.MATH_SPLIT6, 2e-6), (L.MATH_F32, 2e-6), (L.MATH_BF16, 6e-3), (L.MATH_SPLIT6, 2e-6)):
+        op.set_math(math)
+        assert rel_rms(op.forward(dev(x), in_act=L.IN_LRELU), ref) <= tol, math
+    with pytest.raises(L.VisingerHipError):
+        op.set_math(3)
+
+
+@pytest.mark.parametrize("math,tol", [(L.MATH_SPLIT6, 3e-6), (L.MATH_BF16, 8e-3)])
+def test_split_transposed_and_paired(oracle, math, tol):
+    """polyphase transposed conv, WaveNet gate and affine-coupling epilogues on the split engine"""
+    from visinger_amd.ops import ConvOp
+    r = np.random.default_rng(17)
+    # transposed 64 -> 32, k = 16, stride 8 (decoder.py:26-31)
+    x = r.standard_normal((2, 64, 300)).astype(np.float32)
+    w = (r.standard_normal((64, 32, 16)) / np.sqrt(64 * 2)).astype(np.float32)
+    bias = r.standard_normal(32).astype(np.float32)
+    ref = oracle.conv_transpose1d(oracle.leaky_relu(x.astype(np.float64)), w, bias, stride=8, padding=4)
+    op = ConvOp(L.CONV_TRANSPOSE1D, 64, 32, 16, 8, 4).set_math(math)
+    op.set_weights(dev(w), None, dev(bias))
+    assert rel_rms(op.forward(dev(x), in_act=L.IN_LRELU), ref) <= tol
+    # gate: tanh(a) * sigmoid(b) over the two halves of a 192 -> 384 k5 conv (wavenet.py:54-64)
+    H, T = 192, 500
+    x = r.standard_normal((2, H, T)).astype(np.float32)
+    w = (r.standard_normal((2 * H, H, 5)) / np.sqrt(H * 5)).astype(np.float32)
+    bias = r.standard_normal(2 * H).astype(np.float32)
+    z = oracle.conv1d(x.astype(np.float64), w, bias, padding=2)
+    ref = np.tanh(z[:, :H]) * (1.0 / (1.0 + np.exp(-z[:, H:])))
+    op = ConvOp(L.CONV1D_PAIRED, H, 2 * H, 5, 1, 2).set_math(math)
+    op.set_weights(dev(w), None, dev(bias))
+    y = op.forward(dev(x), pair_mode=L.PAIR_GATE)
+    assert rel_rms(y, ref) <= 2 * tol
+
+
+def test_set_conv_math_on_modules(oracle):
+    """modules.hipconv.set_conv_math: the generator in bf16 arithmetic stays within a bf16 tolerance of the default engine"""
+    from visinger_amd.modules.hipconv import set_conv_math
+    from visinger_amd.modules.visinger.decoder import Generator
+    torch.manual_seed(0)
+    g = Generator(80, "1", [3, 7], [[1, 3, 5], [1, 3, 5]], [4, 4], 64, [8, 8], gin_channels=0).cuda().eval()
+    g.remove_weight_norm()
+    x = torch.randn(2, 80, 50, device="cuda")
+    with torch.no_grad():
+        y6 = g(x)
+        set_conv_math(g, L.MATH_F32)
+        y0 = g(x)
+        set_conv_math(g, L.MATH_BF16)
+        y1 = g(x)
+        set_conv_math(g, None)
+    assert float((y6 - y0).abs().max()) <= 2e-5
+    assert 1e-6 < float((y1 - y0).abs().max()) <= 5e-2

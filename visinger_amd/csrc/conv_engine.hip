@@ -1164,9 +1164,13 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
         h->wino_groups = (int)ceil_div(k, 3);
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
-    if (const char *e = getenv("VS_CONV_MATH")) {       // A/B switch: default arithmetic of every conv created from here on
+    // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
+    // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
+    // VS_CONV_MATH=0 / 1 / 6: process-wide A/B switch for handles created from here on.
+    h->math = VS_MATH_SPLIT6;
+    if (const char *e = getenv("VS_CONV_MATH")) {
         const int m = atoi(e);
-        if (m == 1 || m == 6) h->math = m;
+        if (m == VS_MATH_F32 || m == VS_MATH_BF16 || m == VS_MATH_SPLIT6) h->math = m;
     }
     *out = h;
     return VS_OK;

@@ -47,6 +47,9 @@ class _HipConvMixin:
                 ops[key] = ConvOp(kind, self.in_channels, self.out_channels, self.kernel_size[0],
                                   self.dilation[0], self.padding[0], flags)
         op = ops[key]
+        math = self.__dict__.get("_hip_math")
+        if math is not None and op.math != math:
+            op.set_math(math)
         if bind:
             w, g = self._weights()
             op.set_weights(w, g, self.bias)
@@ -75,6 +78,19 @@ class HipConv1d(_HipConvMixin, nn.Conv1d):
 
 class HipConvTranspose1d(_HipConvMixin, nn.ConvTranspose1d):
     _kind = L.CONV_TRANSPOSE1D
+
+
+def set_conv_math(module, math):
+    """Select the arithmetic of every HIP conv under `module` (L.MATH_SPLIT6: fp32-class split-bf16, the default;
+    L.MATH_F32: fp32 MFMA / Winograd F(2,3); L.MATH_BF16: bf16 operands, fp32 accumulate -- BASELINE.json's long-form bf16
+    configuration).  None restores the library default for handles created afterwards."""
+    for m in module.modules():
+        if isinstance(m, _HipConvMixin):
+            if math is None:
+                m.__dict__.pop("_hip_math", None)
+            else:
+                m.__dict__["_hip_math"] = int(math)
+    return module
 
 
 def mask2d(x_mask, B, T):

@@ -343,6 +343,10 @@ def respair_supported(op1, op2, profitable_only=False):
     if not profitable_only or os.environ.get("VS_RESPAIR_FORCE"):
         return True
     C, k, d = op1.c_in, op1.k, op1.dil
+    if op1.math != L.MATH_F32:
+        # the fused pair is an fp32-MFMA kernel; against two launches of the split-bf16 engine (tools/conv_bench.py) it still
+        # wins at 32 channels, k = 3 (~1.1 vs 1.37 ms per pair) and loses from k = 7 on (2.1 vs 1.9 ms) and at 64 channels
+        return C == 32 and k == 3
     return (C == 32 and (k <= 7 or d > 1)) or (C == 64 and k == 3 and d > 1)
 
 
