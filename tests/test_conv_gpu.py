@@ -326,8 +326,9 @@ def test_conv_engine_random_sweep(seed, monkeypatch):
 
 @pytest.mark.parametrize("C,k,d,T,B", [(32, 3, 1, 2048, 2), (32, 7, 3, 1500, 1), (32, 11, 5, 1024, 2), (64, 3, 5, 1000, 1),
                                         (64, 7, 1, 700, 2), (64, 11, 3, 516, 1), (32, 5, 1, 37, 1), (32, 3, 3, 4, 2), (64, 9, 1, 250, 1)])
-def test_resblock_pair_fused_launch(oracle, C, k, d, T, B):
-    """csrc/resblock_pair.hip: y = conv2(lrelu(conv1(lrelu(x)))) + x [+ acc] [* scale] in one launch vs the fp64 oracle; tiles
+@pytest.mark.parametrize("math", [L.MATH_SPLIT6, L.MATH_F32])
+def test_resblock_pair_fused_launch(oracle, C, k, d, T, B, math):
+    """csrc/resblock_pair_split.hip (split-bf16 x6, the default) and csrc/resblock_pair.hip (fp32 MFMA): y = conv2(lrelu(conv1(lrelu(x)))) + x [+ acc] [* scale] in one launch vs the fp64 oracle; tiles
     in the interior (vector epilogue), at both sequence ends, lengths below one tile and not a multiple of 4 (element-wise
     epilogue), every (k, dilation) of the MRF blocks."""
     from visinger_amd.ops import ConvOp, respair_forward, respair_supported
@@ -337,8 +338,8 @@ def test_resblock_pair_fused_launch(oracle, C, k, d, T, B):
     w2 = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
     b1, b2 = r.standard_normal(C).astype(np.float32), r.standard_normal(C).astype(np.float32)
     accb = r.standard_normal((B, C, T)).astype(np.float32)
-    op1 = ConvOp(L.CONV1D, C, C, k, d, d * (k - 1) // 2)
-    op2 = ConvOp(L.CONV1D, C, C, k, 1, (k - 1) // 2)
+    op1 = ConvOp(L.CONV1D, C, C, k, d, d * (k - 1) // 2).set_math(math)
+    op2 = ConvOp(L.CONV1D, C, C, k, 1, (k - 1) // 2).set_math(math)
     op1.set_weights(dev(w1), None, dev(b1))
     op2.set_weights(dev(w2), None, dev(b2))
     assert respair_supported(op1, op2)

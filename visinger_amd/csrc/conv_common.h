@@ -70,6 +70,38 @@ __device__ __forceinline__ void stamp(const ConvParams &p, int slot) {
     }
 }
 
+// ---- split-bf16 helpers (conv_split.hip, resblock_pair_split.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned f2u(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float u2f(unsigned v) { return __builtin_bit_cast(float, v); }
+// (hi16(b) << 16) | hi16(a)
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+__device__ __forceinline__ unsigned rne_bf16(float v) {       // bf16 bits in the HIGH half (finite inputs)
+    const unsigned u = f2u(v);
+    return u + 0x7fffu + ((u >> 16) & 1u);
+}
+// planes of a pair of values -> one packed dword per plane
+template <int NPL>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NPL]) {
+    if constexpr (NPL == 1) {
+        out[0] = pack_hi(rne_bf16(a), rne_bf16(b));
+    } else {
+        unsigned ab = f2u(a), bb = f2u(b);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            out[pl] = pack_hi(ab, bb);
+            if (pl + 1 < NPL) {
+                a -= u2f(ab & 0xffff0000u);
+                b -= u2f(bb & 0xffff0000u);
+                ab = f2u(a);
+                bb = f2u(b);
+            }
+        }
+    }
+}
+
 // conv_split.hip
 struct vs_split_pack {            // re-pack of the fp32 fragment-order weights into bf16 planes
     const float *wp;              // Wp[m_tile][tap][chunk][quad(2)][64][4] (pack_conv_kernel)

@@ -26,38 +26,7 @@
 
 namespace vs {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 int split_planes(int terms) { return terms == 1 ? 1 : (terms == 3 ? 2 : 3); }
-
-__device__ __forceinline__ unsigned f2u(float v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ float u2f(unsigned v) { return __builtin_bit_cast(float, v); }
-// (hi16(b) << 16) | hi16(a)
-__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-__device__ __forceinline__ unsigned rne_bf16(float v) {       // bf16 bits in the HIGH half (finite inputs)
-    const unsigned u = f2u(v);
-    return u + 0x7fffu + ((u >> 16) & 1u);
-}
-// planes of a pair of values -> one packed dword per plane
-template <int NPL>
-__device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NPL]) {
-    if constexpr (NPL == 1) {
-        out[0] = pack_hi(rne_bf16(a), rne_bf16(b));
-    } else {
-        unsigned ab = f2u(a), bb = f2u(b);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-            out[pl] = pack_hi(ab, bb);
-            if (pl + 1 < NPL) {
-                a -= u2f(ab & 0xffff0000u);
-                b -= u2f(bb & 0xffff0000u);
-                ab = f2u(a);
-                bb = f2u(b);
-            }
-        }
-    }
-}
 
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams p) {

@@ -85,3 +85,6 @@ struct vs_conv {
     vs::DevBuf ws;                             // bf16 plane fragments of the split engine, when math != 0
 };
 
+
+// resblock_pair_split.hip: the fused residual pair on the split-bf16 x6 arithmetic (both handles in VS_MATH_SPLIT6)
+int vs_respair_split_launch(const vs_conv *c1, const vs_conv *c2, const vs_conv_io_t *io, int fast_epi, hipStream_t s);

@@ -335,18 +335,21 @@ def gconv1d_bwd_weight(gy, x, k, stride, pad, groups):
 
 def respair_supported(op1, op2, profitable_only=False):
     """a11: can the (conv1, conv2) pair of a resblock run as one fused launch -- and, with profitable_only, did it measure
-    faster than the two launches (tools/pair_bench.py, B=32 production shapes): at 32 channels x1.32-1.47 for k=3, x1.14 for
+    faster than the two launches.  fp32 MFMA arithmetic (tools/pair_bench.py with VS_CONV_MATH=0): at 32 channels x1.32-1.47 for k=3, x1.14 for
     k=7, a tie for k=11 (the F(2,3) kernel wins at dilation 1); at 64 channels only the dilated k=3 pairs (x1.06): from k=7 on
     the separate F(2,3) launches do 30 % less matrix work than the fused direct form."""
     if os.environ.get("VS_NO_RESPAIR") or not op1.lib.vs_respair_supported(op1.h, op2.h):
         return False
+    if op1.math != op2.math or op1.math == L.MATH_BF16:
+        return False
     if not profitable_only or os.environ.get("VS_RESPAIR_FORCE"):
         return True
     C, k, d = op1.c_in, op1.k, op1.dil
-    if op1.math != L.MATH_F32:
-        # the fused pair is an fp32-MFMA kernel; against two launches of the split-bf16 engine (tools/conv_bench.py) it still
-        # wins at 32 channels, k = 3 (~1.1 vs 1.37 ms per pair) and loses from k = 7 on (2.1 vs 1.9 ms) and at 64 channels
-        return C == 32 and k == 3
+    if op1.math == L.MATH_SPLIT6:
+        # csrc/resblock_pair_split.hip against two launches of the split engine (tools/pair_bench.py, B=32 production shapes):
+        # 32 channels x1.46-1.61 (k=3), x1.25 (k=7), x1.13 (k=11); 64 channels x1.22 (k=3), a tie at k=7, x0.91 at k=11 (its
+        # 64 x 128 tile spends 9 % of both convs on halo columns)
+        return C == 32 or k == 3
     return (C == 32 and (k <= 7 or d > 1)) or (C == 64 and k == 3 and d > 1)
 
 
@@ -365,7 +368,9 @@ def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
         e0.record()
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
         e1.record()
-        PROFILER.records.append((f"respair_kernel<{'1,4' if C == 32 else '2,2'}>", op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), e0, e1))
+        name = (f"respair_split_kernel<2,{'1,4' if C == 32 else '2,2'}>" if op1.math == L.MATH_SPLIT6
+                else f"respair_kernel<{'1,4' if C == 32 else '2,2'}>")
+        PROFILER.records.append((name, op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), e0, e1))
     else:
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
     return y
