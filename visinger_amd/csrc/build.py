@@ -11,6 +11,28 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvi
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
+# conv_split_kernel issues its weight-fragment loads as inline asm and waits for them with hand-counted `s_waitcnt vmcnt(n)`:
+# a register spill inside its main loop would be a vector-memory instruction hipcc adds behind the count's back.  The build
+# fails instead of shipping such a kernel.
+NO_SCRATCH = {"conv_split.hip": "conv_split_kernel"}
+
+
+def check_no_scratch(src, remarks):
+    name, bad = None, []
+    for line in remarks.splitlines():
+        if "remark:" not in line:
+            if "warning" in line or "error" in line:
+                sys.stderr.write(line + "\n")
+            continue
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize [bytes/lane]:" in line and name and NO_SCRATCH[os.path.basename(src)] in name:
+            if int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) != 0:
+                bad.append(name)
+    if bad:
+        raise RuntimeError(f"{src}: kernels with hand-counted vmcnt waits must not use scratch: {bad}")
+
+
 def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip")))
 
@@ -32,12 +54,20 @@ def build(force=False, verbose=True):
         obj = src[:-4] + ".o"
         objs.append(obj)
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        guarded = os.path.basename(src) in NO_SCRATCH
+        if guarded:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, pr in procs:
+        procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE if guarded else None, text=True), guarded))
+    for src, pr, guarded in procs:
+        err = pr.communicate()[1] if guarded else None
         if pr.wait() != 0:
+            if err:
+                sys.stderr.write(err)
             raise RuntimeError(f"hipcc failed on {src}")
+        if guarded:
+            check_no_scratch(src, err)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

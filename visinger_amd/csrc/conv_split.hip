@@ -31,7 +31,6 @@ int split_planes(int terms) { return terms == 1 ? 1 : (terms == 3 ? 2 : 3); }
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves: a wave stages four consecutive channels of a 16-channel chunk");
-    constexpr int NW = 4;
     constexpr int NPL = (TERMS == 1) ? 1 : (TERMS == 3 ? 2 : 3);
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int MAXW = BN + MAX_SPAN;
@@ -180,6 +179,8 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams p) 
     // loads in issue order, so "fragments of THIS step have landed" is vmcnt(n) with n = everything issued after them: the
     // activation loads of the previous step (if it staged), this step's A prefetch, this step's activation loads (if it
     // stages).  (hipcc's own waits for its buffer loads do not know about the asm loads and are therefore merely stricter.)
+    // The count assumes no other vector-memory instruction in the loop: csrc/build.py fails the build if an instance of this
+    // kernel uses scratch (a spill would be one).
     const int ntaps = tap_e - tap_b;
     const int nsteps = p.nchunks * ntaps;
     const u32x4 *wbase[MT_W];
