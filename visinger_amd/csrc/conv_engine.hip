@@ -1022,7 +1022,7 @@ static inline int ceil_div_i(int a, int b) { return -floor_div(-a, b); }
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 
-static unsigned long long *g_stamp_buf = nullptr;   // debug hook, see vs_debug_set_stamp_buffer
+unsigned long long *g_stamp_buf = nullptr;   // debug hook, see vs_debug_set_stamp_buffer (also read by resblock_pair_split.hip)
 
 using namespace vs;
 

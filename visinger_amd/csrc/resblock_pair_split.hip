@@ -16,6 +16,12 @@
 //   phase 2  conv2 straight from that tile: no staging, no barrier; NOUT = BN - halo columns are final outputs;
 //   epilogue + x [+ acc] [* scale] through the LDS transpose, all residual loads in flight at once.
 //
+// Measured and of no use here (tools/pair_bench.py): weight fragments requested three steps ahead through a 4-slot ring with
+// counted vmcnt waits, and the next step's first B planes read under the current step's last MFMAs -- both within 1 %: with two
+// or three workgroups per CU those latencies are already covered.  What the phase stamps show instead (tools/pair_stamps.py,
+// C=32, k=11): phase 2 runs at the rate of the (power-throttled) matrix pipe, phase 1 takes 1.45x as long for the same MFMAs
+// (chunk barriers), and prologue + transform + epilogue are 8 us of a 45 us workgroup.
+//
 // Tiles: 32 channels: 32 x 256 (four waves side by side), 64 channels: 64 x 128 (2 x 2 waves); both keep LDS at ~54-61 KB
 // (two workgroups per CU) and 32 accumulator registers per wave.
 #include "conv_common.h"
@@ -40,7 +46,13 @@ struct PairSplitParams {
     int W1;          // staged x columns: BN + (K - 1) * d1
     int PH;          // intermediate columns that are not final outputs: (K - 1) rounded up to 4
     int fast_epi;
+    unsigned long long *stamps;   // debug: per-workgroup phase time stamps (NULL in production; tools/pair_stamps.py)
 };
+
+__device__ __forceinline__ void pstamp(const PairSplitParams &p, int slot) {
+    if (p.stamps && threadIdx.x == 0)
+        p.stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 64 + slot] = __builtin_amdgcn_s_memrealtime();
+}
 
 template <int NT_W, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitParams p) {
@@ -135,10 +147,12 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; ++pc; } };
     load_a(a0, pc, pt); advance();
 
+    pstamp(p, 0);
     stage_load(0);
     stage_store(lbuf0);
     if (p.nchunks > 1) stage_load(1);
     __syncthreads();
+    pstamp(p, 1);
 
     // one (chunk, tap) step: NT_W column tiles x 6 cross products; xs = LDS address (dwords) of this lane's 16-byte cell of the
     // first tile in plane 0, plsz = plane pitch; the planes of tile j+1 are read under the MFMAs of tile j
@@ -185,6 +199,7 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
         if (s < nsteps) step1(a1, a0);
     }
     // (the barrier after the last tap of the last chunk: every wave is done with the staging buffers)
+    pstamp(p, 2);
 
     // ------------------------------------------------------------------ intermediate tile -> LDS, as conv2's B operand
     const int KG = p.C / 8;                                     // channel groups of the intermediate
@@ -218,6 +233,7 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     }
     __syncthreads();
 
+    pstamp(p, 8);
     // ------------------------------------------------------------------------------------------- phase 2: conv2 from LDS
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -239,6 +255,7 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
         if (s < nsteps) step2(a1, a0);
     }
     __syncthreads();                                            // the tile in LDS is consumed: its space becomes the epilogue's
+    pstamp(p, 9);
 
     // ------------------------------------------------------------------------------------------- epilogue: + x [+ acc] [* scale]
     const int tile_row0 = wm * 32;
@@ -297,6 +314,10 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
             }
         }
     }
+    if (p.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        pstamp(p, 3);
+    }
 }
 
 template <int NT_W, int WAVES_M, int WAVES_N>
@@ -321,6 +342,8 @@ static int launch_pair_split_cfg(PairSplitParams p, hipStream_t s) {
 
 using namespace vs;
 
+extern unsigned long long *g_stamp_buf;   // conv_engine.hip (vs_debug_set_stamp_buffer)
+
 // called by vs_respair_forward (resblock_pair.hip) when both convs run the split-bf16 x6 arithmetic
 int vs_respair_split_launch(const vs_conv *c1, const vs_conv *c2, const vs_conv_io_t *io, int fast_epi, hipStream_t s) {
     PairSplitParams p;
@@ -337,6 +360,7 @@ int vs_respair_split_launch(const vs_conv *c1, const vs_conv *c2, const vs_conv_
     p.B = (int)io->B; p.C = C; p.T = (int)io->T; p.K = c1->k; p.d1 = c1->dil; p.nchunks = c1->nchunks;
     p.PH = ((c1->k - 1) + 3) & ~3;
     p.fast_epi = fast_epi;
+    p.stamps = g_stamp_buf;
     if (C == 32) return launch_pair_split_cfg<2, 1, 4>(p, s);
     return launch_pair_split_cfg<2, 2, 2>(p, s);
 }
