@@ -162,7 +162,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected
     from inside the timed run: they need rocprofv3 and one pass per counter); None when not recorded."""
     try:
-        for tag in ("r01_e", "r01_c"):
+        for tag in ("r01_f", "r01_e", "r01_c"):
             path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if os.path.exists(path):
                 with open(path) as f:
@@ -175,15 +175,23 @@ def pmc_traffic(kernel):
 
 
 def pmc_mfma_executed(kernel):
-    """FLOP/s the matrix pipe really executed in `kernel` (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / kernel time, recorded PMC pass);
-    None when not recorded."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_pmc_mfma_busy.json")) as f:
-            k = json.load(f)["kernels"][kernel]
-        return {"tflops": k["mfma_tflops_executed"], "frac_of_peak": k["mfma_pipe_util"],
-                "source": "profiles/r01_c_pmc_mfma_busy.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32, its own pass)"}
-    except (OSError, KeyError, ValueError):
-        return None
+    """FLOP/s the matrix pipe really executed in `kernel` (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, recorded PMC pass of its
+    own: tools/pmc_mfma_summarize.py); None when not recorded."""
+    for tag in ("r01_f", "r01_e", "r01_c"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_busy.json")
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"][kernel]
+        except (OSError, KeyError, ValueError):
+            continue
+        if "mfma_tflops_executed" not in k:
+            continue
+        out = {"tflops": k["mfma_tflops_executed"], "pipe_busy": k["mfma_pipe_util"],
+               "source": f"profiles/{tag}_pmc_mfma_busy.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_*, its own pass)"}
+        if "gfx_clock_ghz" in k:
+            out["gfx_clock_ghz"] = k["gfx_clock_ghz"]
+        return out
+    return None
 
 
 def main():

@@ -5,7 +5,8 @@
 // On the narrow stages of the generator (32 / 64 channels, 2-4 input chunks) a conv on the bf16 matrix pipe is HBM-bound
 // as its own launch (k = 3 at 32 channels: 3.2 GB in 0.70 ms = 4.6 TB/s; tools/conv_stamps.py: the main loop is 36-56 % of a
 // workgroup, the rest is the exposed latency of the first stage-in and of the residual read / store).  Fused, a pair moves
-// 2 tensor passes instead of 6: x is staged once (it is also the residual), the intermediate never leaves the CU.
+// 3 tensor passes instead of 6: x staged once, x again as the residual (what sits in LDS is leaky-relu(x) in bf16 planes), y
+// out; the intermediate never leaves the CU.
 //
 //   phase 1  conv1 over a tile of BN intermediate columns, exactly the main loop of conv_split_kernel (x split into three
 //            bf16 planes while it is staged, six cross products per 16 input channels);
