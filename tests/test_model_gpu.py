@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, load_golden
+from visinger_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
@@ -134,6 +135,36 @@ def test_full_size_generator_reference_config_hop300(oracle):
         wav = gen(cu(z), g=cu(g))
     assert wav.shape == (B, 1, T * 300)
     assert maxerr(wav, wav_ref) <= 1e-4
+
+
+def test_full_size_generator_error_by_arithmetic(oracle, capsys):
+    """Whole hop-256 generator (72 convs deep) at full width vs the fp64 oracle under each arithmetic of the conv engine: the
+    split-bf16 x6 default stays within the error of the fp32 MFMA / F(2,3) kernels, bf16 operands do not (what `dtype` in the bench
+    line stands for)."""
+    from visinger_amd.modules.hipconv import set_conv_math
+    from visinger_amd.modules.visinger.decoder import Generator
+    B, T = 1, 24
+    gen = Generator(192, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 2, 2], 512, [16, 16, 4, 4], gin_channels=256)
+    sdg = _rand_sd(gen, 21)
+    gen = gen.cuda().eval()
+    r = np.random.default_rng(256)
+    z = r.standard_normal((B, 192, T)).astype(np.float32)
+    g = r.standard_normal((B, 256, 1)).astype(np.float32)
+    wav_ref = oracle.generator(sdg, z, g, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+                               upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4])
+    err = {}
+    for name, math in (("split6", L.MATH_SPLIT6), ("f32", L.MATH_F32), ("bf16", L.MATH_BF16)):
+        set_conv_math(gen, math)
+        with torch.no_grad():
+            wav = gen(cu(z), g=cu(g))
+        e = wav.double().cpu().numpy() - wav_ref
+        err[name] = (float(np.sqrt((e ** 2).mean())), float(np.abs(e).max()))
+    set_conv_math(gen, None)
+    with capsys.disabled():
+        print("\n   generator waveform error vs fp64 (rms, max): " + "  ".join(f"{k}: {v[0]:.2e}, {v[1]:.2e}" for k, v in err.items()))
+    assert err["split6"][1] <= 1e-4 and err["f32"][1] <= 1e-4
+    assert err["split6"][0] <= 1.5 * err["f32"][0] + 1e-8
+    assert err["bf16"][0] > 10 * err["split6"][0]
 
 
 def test_north_star_shape_properties():
