@@ -320,6 +320,22 @@ def main():
                                                 for k, v in prof.items()},
                          "conv_engine_share_of_step": conv_ms / (dt * 1e3)}),
         }
+        if world == 1 and args.math == "split6" and not args.no_cpu_baseline:
+            # the same workload on the exact-fp32 MFMA / F(2,3) kernels, same process, same weights: the number to hold the
+            # split-bf16 arithmetic against (its error against fp64 is in DESIGN.md 4 and tests/test_conv_split_gpu.py)
+            from visinger_amd.modules.hipconv import set_conv_math
+            set_conv_math(model, MATH["f32"])
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                wav32 = step()
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / 3
+            set_conv_math(model, MATH["split6"])
+            out["fp32_mfma_engine"] = {"value": B * T * HOP / dt32, "unit": "audio samples/s", "ms_per_step": dt32 * 1e3, "steps": 3,
+                                       "max_abs_waveform_diff_vs_value_run": float((wav32 - wav).abs().max()),
+                                       "note": "bench.py --math f32: v_mfma_f32_32x32x2_f32 + Winograd F(2,3) kernels, no bf16 anywhere"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, hp)
             out["cpu_baseline_torch"] = cpu_baseline(model, hp, backend="torch")
