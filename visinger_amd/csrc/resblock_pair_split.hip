@@ -19,7 +19,8 @@
 //
 // Measured and of no use here (tools/pair_bench.py): weight fragments requested three steps ahead through a 4-slot ring with
 // counted vmcnt waits, and the next step's first B planes read under the current step's last MFMAs -- both within 1 %: with two
-// or three workgroups per CU those latencies are already covered.  What the phase stamps show instead (tools/pair_stamps.py,
+// or three workgroups per CU those latencies are already covered; 32 x 128 tiles (four to five workgroups per CU) were 5-15 % SLOWER
+// (more halo columns, twice the weight-fragment traffic per MFMA).  What the phase stamps show instead (tools/pair_stamps.py,
 // C=32, k=11): phase 2 runs at the rate of the (power-throttled) matrix pipe, phase 1 takes 1.45x as long for the same MFMAs
 // (chunk barriers), and prologue + transform + epilogue are 8 us of a 45 us workgroup.
 //
