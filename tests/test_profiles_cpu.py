@@ -1,0 +1,34 @@
+"""The committed rocprofv3 summaries that bench.py cites (profiles/README.md) parse and carry the dominant kernel instance."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOM = "conv_split_kernel<1,8,4,1,6>"
+
+
+def test_bench_reads_committed_pmc_summaries():
+    import bench
+    t = bench.pmc_traffic(DOM)
+    assert t is not None and 0.5e9 < t < 3e9                       # HBM bytes per launch of the dominant instance
+    m = bench.pmc_mfma_executed(DOM)
+    assert m is not None and 800.0 < m["tflops"] < 2500.0 and 0.3 < m["pipe_busy"] <= 1.0
+    assert bench.pmc_traffic("no_such_kernel") is None and bench.pmc_mfma_executed("no_such_kernel") is None
+
+
+def test_committed_bench_line_and_kernel_stats_agree():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench_line_profiled.json")))
+    r = line["roofline"]
+    assert r["kernel"] == DOM and r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    with open(os.path.join(ROOT, "profiles", "r01_f_bench_kernel_stats.csv"), newline="") as f:
+        rows = {row["Name"]: row for row in csv.DictReader(f)}
+    name = "void vs::conv_split_kernel<1, 8, 4, 1, 6>(vs::ConvParams)"
+    avg_ms = float(rows[name]["AverageNs"]) * 1e-6
+    assert abs(avg_ms - r["avg_launch_ms"]) <= 0.02 * avg_ms       # rocprofv3's average launch vs the HIP events of the same run
+    full = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench_line.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in full, key
+    assert full["cpu_baseline"]["kind"] == "port" and full["cpu_baseline"]["cores"] >= 1
+    assert full["flow_logdet_rel_err"] <= 1e-4
