@@ -12,13 +12,24 @@ Inputs (tokens, mel2ph, noise) are resident in HBM before the timed region; weig
 reference architecture (no checkpoints offline).  Multi-GPU = one process per GPU, utterances sharded by the
 reference's strided rule (batch[rank::world], tasks/base.py:130-133), no data-path collective -> weak scaling.
 
+`--gpus N` without a torchrun environment starts its own N ranks (fresh child processes, one per GPU, started before this
+process touches the GPU -- the reference spawns its ranks itself as well, utils/commons/trainer.py:117-138); under
+torch.distributed.run it takes RANK / LOCAL_RANK / WORLD_SIZE from the environment and refuses a WORLD_SIZE != N.
+
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (the implicit-GEMM conv
 instance with the largest share of the step: a split-bf16 MFMA instance by default), from HIP events recorded around
-each of its launches inside the timed steps; `cpu_baseline` is the CPU oracle ("port") timed on a bounded sample.
+each of its launches inside the timed steps: `achieved` = ALGORITHMIC FLOPs (the conv's own 2*MAC) / time, `frac` =
+achieved / the stated peak; what the matrix pipe executes on top of that (6 bf16 cross products per fp32 product) is under
+`frac_executed` / `mfma_executed`.  `cpu_baseline` is the CPU oracle ("port") timed on a bounded sample.
+
+Other BASELINE.json configurations: --config 2 (flow inverse + HiFi-GAN decode, B=8 T_mel=512 fp32), --config 3 (full GAN
+training step, B=16), --config 4 (= the default workload, meant for --gpus 8), --config 5 (T_mel=4096 hidden=512 bf16).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -158,94 +169,174 @@ def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
     return res
 
 
+PROFILE_TAGS = ("r02_c", "r02_b", "r02_a", "r01_f", "r01_e", "r01_c")      # newest first: profiles/<tag>_pmc_*.json
+
+
+def _norm(kernel):
+    return kernel.replace(" ", "")
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected
     from inside the timed run: they need rocprofv3 and one pass per counter); None when not recorded."""
-    try:
-        for tag in ("r01_f", "r01_e", "r01_c"):
-            path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
-            if os.path.exists(path):
-                with open(path) as f:
-                    ks = json.load(f)["kernels"]
-                if kernel in ks:
-                    return ks[kernel]["hbm_bytes_per_launch_corrected"]
-    except (OSError, KeyError, ValueError):
-        pass
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        try:
+            with open(path) as f:
+                ks = {_norm(k): v for k, v in json.load(f)["kernels"].items()}
+            if _norm(kernel) in ks:
+                return {"bytes_per_launch": ks[_norm(kernel)]["hbm_bytes_per_launch_corrected"],
+                        "source": f"recorded: profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"}
+        except (OSError, KeyError, ValueError):
+            continue
     return None
 
 
 def pmc_mfma_executed(kernel):
     """FLOP/s the matrix pipe really executed in `kernel` (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, recorded PMC pass of its
     own: tools/pmc_mfma_summarize.py); None when not recorded."""
-    for tag in ("r01_f", "r01_e", "r01_c"):
+    for tag in PROFILE_TAGS:
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_busy.json")
         try:
             with open(path) as f:
-                k = json.load(f)["kernels"][kernel]
+                k = {_norm(n): v for n, v in json.load(f)["kernels"].items()}[_norm(kernel)]
         except (OSError, KeyError, ValueError):
             continue
         if "mfma_tflops_executed" not in k:
             continue
         out = {"tflops": k["mfma_tflops_executed"], "pipe_busy": k["mfma_pipe_util"],
-               "source": f"profiles/{tag}_pmc_mfma_busy.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_*, its own pass)"}
+               "source": f"recorded: profiles/{tag}_pmc_mfma_busy.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_*, its own pass)"}
         if "gfx_clock_ghz" in k:
             out["gfx_clock_ghz"] = k["gfx_clock_ghz"]
         return out
     return None
 
 
-def main():
+CONFIGS = {     # BASELINE.json `configs` (1-based; config 1 is the CPU plumbing case: tests/, not a bench line)
+    2: dict(batch=8, frames=512, what="flow inverse + HiFi-GAN decode"),
+    3: dict(batch=16, frames=512, what="full GAN training step"),
+    4: dict(batch=32, frames=1024, what="batched inference, 32 utterances per GPU (B=256 over 8 GPUs)"),
+    5: dict(batch=8, frames=4096, hidden=512, math="bf16", what="long-form stress"),
+}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """Start n ranks of this script (one per GPU) as fresh child processes and wait for them.  Nothing in THIS process has
+    touched the GPU (never re-exec or fork a process that initialised HIP); rank 0's JSON line passes through on stdout."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, VS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
-    ap.add_argument("--frames", type=int, default=1024, help="T_mel")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 4, 5),
+                    help="a BASELINE.json configuration (sets batch / frames / hidden / math); 0 = the headline workload")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 32)")
+    ap.add_argument("--frames", type=int, default=None, help="T_mel (default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="SURVEY 8d ragged variant: item lengths ~ U{T/2..T}, tails masked (mel2ph = 0)")
-    ap.add_argument("--hidden", type=int, default=192, help="hidden_size (512 = the BASELINE config-5 width; fp32)")
+    ap.add_argument("--hidden", type=int, default=None, help="hidden_size (512 = the BASELINE config-5 width)")
     ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
                     help="256: the BASELINE.json benchmark variant (default); 300: the reference's own generator configuration")
-    ap.add_argument("--math", default="split6", choices=tuple(MATH),
+    ap.add_argument("--math", default=None, choices=tuple(MATH),
                     help="arithmetic of the conv engine (include/visinger_hip.h vs_conv_math): split6 = fp32-class split-bf16 "
                          "(default, the headline), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 operands (BASELINE config 5)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (no GPU work): every rank joins the process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
-    os.environ["VS_CONV_MATH"] = str(MATH[args.math])      # read by vs_conv_create: before any conv handle exists
+    preset = CONFIGS.get(args.config, {})
+    args.batch = args.batch if args.batch is not None else preset.get("batch", 32)
+    args.frames = args.frames if args.frames is not None else preset.get("frames", 1024)
+    args.hidden = args.hidden if args.hidden is not None else preset.get("hidden", 192)
+    if args.math is None:
+        args.math = "bf16" if preset.get("math") == "bf16" else "split6"
+    return args
 
+
+def init_ranks(args):
+    """-> (rank, local_rank, world, dist-or-None, backend); exits non-zero when the world is not --gpus."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    backend = os.environ.get("VS_BENCH_BACKEND", "nccl")        # "gloo": rehearsal of the N > 1 path on a 1-GPU box
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different world size", file=sys.stderr)
+        raise SystemExit(2)
+    backend = os.environ.get("VS_BENCH_BACKEND", "nccl")        # "gloo": rehearsal of the N > 1 path without N GPUs
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world, dist, backend
+
+
+def dry_run(args):
+    """The N-rank launch path without GPU work: rendezvous, barrier, max-over-ranks of a per-rank value, census of the ranks."""
+    rank, local_rank, world, dist, backend = init_ranks(args)
+    from visinger_amd.dp import max_over_ranks
+    seen, pids = [rank], [os.getpid()]
+    dev = torch.device("cuda", local_rank) if (backend == "nccl" and world > 1) else None
+    if dist is not None:
+        dist.barrier()
+        t = torch.zeros(2, world, dtype=torch.int64, device=dev)
+        t[0, rank], t[1, rank] = rank + 1, os.getpid()
+        dist.all_reduce(t)
+        seen, pids = [int(v) - 1 for v in t[0].tolist()], [int(v) for v in t[1].tolist()]
+    slow = max_over_ranks(float(rank + 1), device=dev)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen, "max_over_ranks": slow, "backend": backend if world > 1 else None,
+                          "processes": len(set(pids)), "launcher_pid_is_a_rank": os.getppid() in pids}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def percentile_stats(ms):
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"median_ms": float(np.median(a)), "min_ms": float(a[0]), "max_ms": float(a[-1])}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))        # this process never touches the GPU
+    os.environ["VS_CONV_MATH"] = str(MATH[args.math])      # read by vs_conv_create: before any conv handle exists
+    if args.dry_run:
+        return dry_run(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    rank, local_rank, world, dist, backend = init_ranks(args)
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from visinger_amd.ops import PROFILER
     from visinger_amd.dp import shard_batch, max_over_ranks
     global HOP, SR
     HOP, SR = args.hop, (22050 if args.hop == 256 else 24000)
-    model, hp = build_model(hop=args.hop, hidden=args.hidden)
-    model = model.to(dev)
     B, T = args.batch, args.frames
-    # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
-    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", ragged=args.ragged, hidden=args.hidden)
-    text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
-
-    def step():
-        with torch.no_grad():
-            return model(text, pitch, dur, mel2ph, spk_id=spk, infer=True, noise=noise)["wav_out"]
 
     def barrier():
         torch.cuda.synchronize()
@@ -253,44 +344,102 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        wav = step()
-    barrier()
-    PROFILER.start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wav = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    PROFILER.stop()
+    if args.config == 3:
+        return train_bench(args, rank, world, dist, dev, barrier)
+
+    model, hp = build_model(hop=args.hop, hidden=args.hidden)
+    model = model.to(dev)
+    # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
+    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", ragged=args.ragged, hidden=args.hidden)
+    text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
+
+    if args.config == 2:      # flow inverse + generator only (BASELINE configs[1]); inputs: a prior sample z_p, the mask, the speaker
+        with torch.no_grad():
+            fmask = (mel2ph > 0).float().unsqueeze(1)
+            g = model.speaker_embedding(None, spk).transpose(1, 2).contiguous()
+            z_p = (noise * fmask).contiguous()
+
+        def step():
+            with torch.no_grad():
+                z_q = model.flow(z_p, fmask, g=g, reverse=True) * fmask
+                return model.decoder(z_q, g=g).squeeze(1)
+    else:
+        def step():
+            with torch.no_grad():
+                return model(text, pitch, dur, mel2ph, spk_id=spk, infer=True, noise=noise)["wav_out"]
+
+    def timed_run(steps, warmup, profile):
+        for _ in range(warmup):
+            wav = step()
+        barrier()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        if profile:
+            PROFILER.start()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            wav = step()
+            marks[i + 1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        if profile:
+            PROFILER.stop()
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        return wav, dt, per_step
+
+    wav, dt, per_step = timed_run(args.steps, args.warmup, True)
     assert wav.shape == (B, T * HOP) and bool(torch.isfinite(wav).all())
     dt = max_over_ranks(dt, device=dev if backend == "nccl" else None)
     samples = B * world * T * HOP * args.steps
 
     if rank == 0:
         prof = PROFILER.summary()
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        conv_ms = sum(v["ms"] for v in prof.values())
-        if name.startswith("conv_split_kernel"):
-            terms = int(name.rstrip(">").split(",")[-1])
-            executed = achieved * terms
-            roof = {"bound": "mfma", "kernel": name, "achieved": executed, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": executed / BF16_MFMA_PEAK_TFLOPS,
-                    "algorithmic_tflops": achieved, "algorithmic_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                    "note": f"achieved = bf16-MFMA FLOPs the algorithm needs = {terms} x the conv's 2*MAC count (each fp32 product is "
-                            f"{terms} bf16 cross products; nothing else is executed on the pipe) / measured time, against the dense "
-                            "bf16 MFMA peak; algorithmic_tflops counts the conv's own 2*MAC only.  Under this load the chip clocks "
-                            "at 1.6-1.85 GHz (power): a bare loop of this MFMA with the same accumulator chains sustains 1.57 PFLOP/s "
-                            "at 1.67 GHz on this box (tools/ubench/mfma_bf16_rate.hip) = frac_of_measured_mfma_ceiling's denominator",
-                    "frac_of_measured_mfma_ceiling": executed / 1570.0}
+        name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12            # ALGORITHMIC: the convs' own 2*MAC / measured kernel time
+        step_flops = sum(v["flops"] for v in prof.values()) / args.steps
+        step_tflops = step_flops / (dt / args.steps) / 1e12
+        kern_ms = sum(v["ms"] for v in prof.values())
+        if name.startswith(("conv_split_kernel", "respair_split_kernel")):
+            terms = int(name.rstrip(">").split(",")[-1]) if name.startswith("conv_split_kernel") else 6
+            peak = BF16_MFMA_PEAK_TFLOPS / terms
+            peak_name = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
+                         f"this arithmetic for fp32-class results" if terms > 1 else "dense bf16 MFMA peak")
+            roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "peak_name": peak_name, "frac_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "executed_tflops": achieved * terms, "frac_executed": achieved * terms / BF16_MFMA_PEAK_TFLOPS,
+                    "frac_executed_of_measured_mfma_ceiling": achieved * terms / 1570.0,
+                    "note": f"achieved = ALGORITHMIC FLOPs (the convs' own 2*MAC, SURVEY 8d) / HIP-event time of the kernel's launches; the "
+                            f"matrix pipe executes {terms} bf16 MFMA FLOPs per algorithmic FLOP (executed_tflops, frac_executed vs the 2500 "
+                            "dense peak; mfma_executed = the same from rocprofv3's MFMA counters).  Under this load the chip clocks at "
+                            "1.6-1.85 GHz: a bare loop of this MFMA sustains 1.57 PFLOP/s at 1.67 GHz on this box "
+                            "(tools/ubench/mfma_bf16_rate.hip) = the denominator of frac_executed_of_measured_mfma_ceiling"}
         else:
             roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                    "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "peak_name": "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
                     "note": "achieved = ALGORITHMIC (direct-form) FLOPs / time; the F(2,3) minimal-filtering instances execute "
                             "4/6 (k=3, 9), 10/14 (k=7), 15/22 (k=11) of them on the matrix pipe, so achieved can exceed the MFMA "
                             "peak: mfma_executed is what the pipe really did"}
+        step_peak = roof["peak"]
+        roof.update({
+            "traffic": (pmc_traffic(name) or {}).get("bytes_per_launch"),
+            "traffic_source": (pmc_traffic(name) or {}).get("source"),
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+            "hbm_gbps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9, "hbm_frac_of_8tbps": d["bytes"] / (d["ms"] * 1e-3) / 8e12,
+            "mfma_executed": pmc_mfma_executed(name),
+            "launches_per_step": d["launches"] / args.steps,
+            "avg_launch_ms": d["ms"] / d["launches"],
+            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+            "share_of_step": d["ms"] / (dt * 1e3),
+            "step": {"algorithmic_tflop_per_step": step_flops / 1e12, "achieved": step_tflops, "peak": step_peak, "unit": "TFLOP/s",
+                     "frac": step_tflops / step_peak, "frac_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+                     "note": "whole step: the conv + attention launches' algorithmic FLOPs (2*MAC) / wall time of the step"},
+            "all_instances": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                  "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                                  "launches_per_step": v["launches"] / args.steps}
+                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+            "timed_kernels_share_of_step": kern_ms / (dt * 1e3)})
+        workload = (f"VISinger synthesis (text-enc + pitch-pred + frame-prior + flow-inverse + HiFi-GAN), "
+                    if args.config != 2 else "VISinger flow inverse + HiFi-GAN decode (BASELINE config 2), ")
         out = {
             "metric": "audio samples/sec (22.05 kHz) + flow log-det rel-err, B=32 T_mel=1024",
             "value": samples / dt,
@@ -299,51 +448,75 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_stats": percentile_stats(per_step),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": DTYPE[args.math],
             "data": "synthetic",
-            "config": {"workload": f"VISinger synthesis (text-enc + pitch-pred + frame-prior + flow-inverse + HiFi-GAN), "
-                                   f"B={B}/GPU T_mel={T} hop={HOP} fp32, random-init weights",
-                       "per_gpu_batch": B, "global_batch": B * world, "t_mel": T, "hop": HOP,
+            "config": {"workload": workload + f"B={B}/GPU T_mel={T} hop={HOP} hidden={args.hidden} fp32 tensors, random-init weights",
+                       "baseline_config": args.config or "headline (north_star: B=32, T_mel=1024, hop 256)",
+                       "per_gpu_batch": B, "global_batch": B * world, "t_mel": T, "hop": HOP, "hidden": args.hidden,
                        "parallelism": f"dp{world} (utterance shard, no collective)",
                        "realtime_factor": samples / dt / SR},
-            "roofline": dict(roof, **{"traffic": pmc_traffic(name),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; "
-                                         "recorded run: profiles/r01_*_pmc_traffic.json)",
-                         "mfma_executed": pmc_mfma_executed(name),
-                         "launches_per_step": d["launches"] / args.steps,
-                         "avg_launch_ms": d["ms"] / d["launches"],
-                         "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                         "share_of_step": d["ms"] / (dt * 1e3),
-                         "all_conv_instances": {k: {"ms_per_step": v["ms"] / args.steps,
-                                                    "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
-                                                for k, v in prof.items()},
-                         "conv_engine_share_of_step": conv_ms / (dt * 1e3)}),
+            "roofline": roof,
         }
         if world == 1 and args.math == "split6" and not args.no_cpu_baseline:
-            # the same workload on the exact-fp32 MFMA / F(2,3) kernels, same process, same weights: the number to hold the
-            # split-bf16 arithmetic against (its error against fp64 is in DESIGN.md 4 and tests/test_conv_split_gpu.py)
+            # the same workload on the exact-fp32 MFMA / F(2,3) kernels, same process, same weights, same --steps / --warmup: the
+            # number to hold the split-bf16 arithmetic against (error against fp64: DESIGN.md 4, tests/test_conv_split_gpu.py)
             from visinger_amd.modules.hipconv import set_conv_math
             set_conv_math(model, MATH["f32"])
-            step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                wav32 = step()
-            torch.cuda.synchronize()
-            dt32 = (time.perf_counter() - t1) / 3
+            wav32, dt32, per32 = timed_run(args.steps, args.warmup, False)
             set_conv_math(model, MATH["split6"])
-            out["fp32_mfma_engine"] = {"value": B * T * HOP / dt32, "unit": "audio samples/s", "ms_per_step": dt32 * 1e3, "steps": 3,
+            out["fp32_mfma_engine"] = {"value": B * T * HOP * args.steps / dt32, "unit": "audio samples/s", "ms_per_step": dt32 / args.steps * 1e3,
+                                       "ms_per_step_stats": percentile_stats(per32), "steps": args.steps, "warmup": args.warmup,
                                        "max_abs_waveform_diff_vs_value_run": float((wav32 - wav).abs().max()),
                                        "note": "bench.py --math f32: v_mfma_f32_32x32x2_f32 + Winograd F(2,3) kernels, no bf16 anywhere"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config in (0, 4):
             out["cpu_baseline"] = cpu_baseline(model, hp)
             out["cpu_baseline_torch"] = cpu_baseline(model, hp, backend="torch")
             out["flow_logdet"] = flow_logdet_check(model, dev)
             out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_bench(args, rank, world, dist, dev, barrier):
+    """BASELINE config 3: one full GAN training step (generator pass + discriminator pass, both optimizers; under N > 1 ranks the
+    stock DistributedDataParallel gradient all-reduce over RCCL) on synthetic B=16, T_mel=512, segment 32 frames, hop 256."""
+    from visinger_amd.dp import max_over_ranks
+    from visinger_amd.models.visinger import hop256_hparams
+    from visinger_amd.train import VISingerTrainer, synthetic_train_batch
+    B, T = args.batch, args.frames
+    hp = hop256_hparams(p_dropout=0.0)
+    torch.manual_seed(1234)
+    tr = VISingerTrainer(64, 117, 131, hp).to(dev).configure().train()
+    runner = tr
+    if dist is not None:
+        runner = torch.nn.parallel.DistributedDataParallel(tr, device_ids=[dev.index], find_unused_parameters=True)
+    batch = synthetic_train_batch(B, T, T // 8, tr.hop, 64, hp["num_linear_bins"], 1234 + rank, dev)
+    for _ in range(args.warmup):
+        tr.training_step(batch, runner=runner)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = tr.training_step(batch, runner=runner)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, device=dev if dist is not None else None)
+    if rank == 0:
+        assert all(np.isfinite(v) for v in logs.values()), logs
+        print(json.dumps({
+            "metric": "GAN training steps/sec (BASELINE config 3: posterior + flow fwd + MRF + MPD/MSD, both optimizer passes)",
+            "value": args.steps * world / dt, "unit": "global steps/s (x n_gpus batches of B)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE[args.math], "data": "synthetic",
+            "config": {"workload": f"VISinger GAN training step, B={B}/GPU T_mel={T} segment={tr.segment_size} hop={tr.hop}, reference-size "
+                                   "generator + MPD/MSD, AdamW x2, random-init weights", "baseline_config": 3, "per_gpu_batch": B,
+                       "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)"},
+            "generated_samples_per_s": B * world * tr.segment_size * tr.hop * args.steps / dt,
+            "losses_last_step": logs}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -33,6 +33,11 @@ extern "C" {
 enum vs_status { VS_OK = 0, VS_EINVAL = 1, VS_EHIP = 2, VS_EUNSUPPORTED = 3, VS_ENOMEM = 4 };
 
 VS_API const char *vs_last_error(void);
+/* Name of the kernel instance the calling thread's last vs_conv_forward / vs_respair_forward / vs_relattn_fwd launched, spelled as
+ * rocprofv3 prints it without the namespace and argument list ("conv_split_kernel<1, 8, 4, 1, 6>"): the dispatch is decided in
+ * this library, so a caller that attributes per-launch timings to kernel instances (bench.py's roofline line) reads it back
+ * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
+VS_API const char *vs_last_kernel_name(void);
 VS_API int vs_abi_version(void);
 /* number of HIP devices visible / name of device 0 written into buf (diagnostics for the loader) */
 VS_API int vs_device_info(char *buf, size_t buf_bytes);

@@ -548,3 +548,47 @@ def discriminator_p(sd, x, period, kernel_size=5, stride=3, dtype=np.float64):
     x = conv2d_k1(x, _get_w(sd, "conv_post", dtype), sd["conv_post.bias"], 1, 1)
     fmap.append(x)
     return x.reshape(b, -1), fmap
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# linear / log-mel spectrogram in fp64, by definition (framed DFT with numpy's rfft in double).
+# PARITY UNPINNED w.r.t. the reference: utils/audio/mel_processing.py:15-38 delegates to torchaudio.transforms
+# (Spectrogram / MelSpectrogram), a third-party dependency that is neither under /root/reference nor installed here
+# (requirements.txt:17 leaves it unpinned; README.md:22 suggests torchaudio==0.11.0).  What follows restates the documented
+# defaults of that version: periodic hann window of win_length centred in n_fft, center=True with reflect padding of n_fft/2,
+# onesided, power 2, no normalisation; melscale_fbanks(mel_scale="htk", norm=None); the reference's own additions are
+# log(x + 1e-3) and dropping the last frame (mel_processing.py:24-38).  It referees visinger_amd/audio.py's torch.stft path.
+def linear_spectrogram_f64(wav, n_fft=2048, win_length=1200, hop_length=300, power=2.0):
+    """wav [B, L] -> [B, T, n_fft/2 + 1] (float64), T = L // hop_length (last of the 1 + L // hop frames dropped)"""
+    wav = np.asarray(wav, np.float64)
+    B, Lw = wav.shape
+    n = np.arange(win_length)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / win_length)                  # torch.hann_window(periodic=True)
+    full = np.zeros(n_fft)
+    left = (n_fft - win_length) // 2
+    full[left:left + win_length] = win
+    x = np.pad(wav, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+    n_frames = 1 + Lw // hop_length
+    idx = np.arange(n_fft)[None, :] + hop_length * np.arange(n_frames)[:, None]
+    spec = np.fft.rfft(x[:, idx] * full, axis=-1)                           # [B, frames, n_fft/2+1]
+    return (np.abs(spec) ** power)[:, :-1]
+
+
+def mel_filterbank_f64(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """HTK mel triangles without area normalisation, [n_freqs, n_mels] (float64)"""
+    hz2mel = lambda f: 2595.0 * np.log10(1.0 + np.asarray(f, np.float64) / 700.0)      # noqa: E731
+    all_freqs = np.linspace(0.0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up))
+
+
+def mel_spectrogram_f64(wav, sample_rate=24000, n_fft=2048, win_length=1200, hop_length=300, n_mels=128, f_min=20.0, f_max=12000.0,
+                        eps=1e-3):
+    """wav [B, L] -> log-mel [B, T, n_mels] (float64)"""
+    lin = linear_spectrogram_f64(wav, n_fft, win_length, hop_length)
+    return np.log(lin @ mel_filterbank_f64(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate) + eps)

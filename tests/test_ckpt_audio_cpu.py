@@ -69,3 +69,45 @@ def test_wav_writer_and_bucketing(tmp_path):
     for b in batches:
         assert max(lengths[i] for i in b) * len(b) <= 2000 or len(b) == 1               # padded-frame budget
         assert [lengths[i] for i in b] == sorted((lengths[i] for i in b), reverse=True)  # longest first
+
+
+def test_spectrogram_against_fp64_dft_oracle(oracle):
+    """visinger_amd/audio.py (torch.stft) against the framed-DFT definition in fp64 (oracle/visinger_oracle.py).  Still PARITY UNPINNED
+    w.r.t. the reference's torchaudio transforms (utils/audio/mel_processing.py:15-38; torchaudio is absent): this pins the
+    restatement against its own definition, on CPU here and on the GPU in tests/test_audio_gpu.py."""
+    from visinger_amd import audio
+    torch.manual_seed(3)
+    for (n_fft, win, hop, n_mels, sr, fmin, fmax, T) in ((2048, 1200, 300, 128, 24000, 20.0, 12000.0, 21), (64, 32, 8, 16, 8000, 0.0, 4000.0, 40),
+                                                         (1024, 1024, 256, 80, 22050, 0.0, 11025.0, 17)):
+        wav = (torch.randn(2, T * hop) * 0.3).clamp(-1, 1)
+        lin_ref = oracle.linear_spectrogram_f64(wav.numpy(), n_fft, win, hop)
+        lin = audio.linear_spectrogram(wav, n_fft, win, hop).double().numpy()
+        assert lin.shape == lin_ref.shape == (2, T, n_fft // 2 + 1)
+        assert np.abs(lin - lin_ref).max() <= 1e-4 * lin_ref.max()
+        fb_ref = oracle.mel_filterbank_f64(n_fft // 2 + 1, fmin, fmax, n_mels, sr)
+        assert np.abs(audio.mel_filterbank(n_fft // 2 + 1, fmin, fmax, n_mels, sr).double().numpy() - fb_ref).max() <= 5e-5   # fp32 triangles (as torchaudio builds them) vs fp64
+        mel_ref = oracle.mel_spectrogram_f64(wav.numpy(), sr, n_fft, win, hop, n_mels, fmin, fmax)
+        mel = audio.mel_spectrogram(wav, sr, n_fft, win, hop, n_mels, fmin, fmax).double().numpy()
+        assert np.abs(mel - mel_ref).max() <= 2e-3                    # log(x + 1e-3): fp32 bins of ~1e-3 relative to eps
+
+
+def test_trainer_learning_rate_follows_the_reference_schedule():
+    """tasks/visinger.py:221-227 with config/models/visinger.yaml:106 (`endless_ds: false`): both optimizers' rates are
+    base * gamma ** EPOCH after every optimizer step -- not gamma ** step (0.999875 ** 100000 = 3.7e-6 would stall training);
+    with `endless_ds: true` the exponent is global_step // accumulate_grad_batches."""
+    from visinger_amd.train import VISingerTrainer
+    hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_hparams.json")))
+    tr = VISingerTrainer(13, 9, 7, hp).configure()
+    tr.global_step = 5000
+    tr.on_after_optimization()
+    assert tr.opt_gen.param_groups[0]["lr"] == 2e-4 and tr.opt_disc.param_groups[0]["lr"] == 2e-4     # still epoch 0
+    for _ in range(3):
+        tr.on_epoch_end()
+    tr.on_after_optimization()
+    for o in (tr.opt_gen, tr.opt_disc):
+        assert abs(o.param_groups[0]["lr"] - 2e-4 * 0.999875 ** 3) < 1e-18
+    assert tr.sched[0].get_last_lr()[0] == tr.opt_gen.param_groups[0]["lr"]
+    tr2 = VISingerTrainer(13, 9, 7, hp, dict(endless_ds=True, accumulate_grad_batches=2)).configure()
+    tr2.global_step = 21
+    tr2.on_after_optimization()
+    assert abs(tr2.opt_disc.param_groups[0]["lr"] - 2e-4 * 0.999875 ** 10) < 1e-18

@@ -278,10 +278,10 @@ def test_conv1d_winograd_path(oracle, monkeypatch, B, Cin, Cout, T, k, dil):
     w = oracle.weight_norm(v, g)
     pad = (k * dil - dil) // 2
     op = ConvOp(L.CONV1D, Cin, Cout, k, dil, pad).set_math(L.MATH_F32)
-    assert op.kernel_instance().startswith("conv_wino_kernel"), op.kernel_instance()
     op.set_weights(dev(v), dev(g), dev(bias))
     conv = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w, bias, dilation=dil, padding=pad)
     y = op.forward(dev(x), in_act=L.IN_LRELU)
+    assert op.kernel_instance().startswith("conv_wino_kernel"), op.kernel_instance()      # as reported by the library
     close(y, conv)
     y = op.forward(dev(x), in_act=L.IN_LRELU, res=dev(res), acc=dev(accb), scale=1.0 / 3.0)
     close(y, (conv + res + accb) / 3.0)

@@ -123,3 +123,24 @@ def test_ddp_gradient_allreduce_matches_global_batch_world2():
     for p in procs:
         p.join(timeout=120)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment starts two rank processes itself (the reference spawns its ranks
+    too: utils/commons/trainer.py:117-138); --dry-run + VS_BENCH_BACKEND=gloo rehearses exactly that launch path on CPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["VS_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks"] == [0, 1] and line["processes"] == 2 and line["max_over_ranks"] == 2.0
+    assert line["launcher_pid_is_a_rank"] is False           # the launcher only spawns: it never joins the group or touches a GPU
+    # a world size that is not --gpus is refused (non-zero exit, no line), e.g. a stale torchrun environment
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1"),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

@@ -123,3 +123,56 @@ def test_config5_width_hidden512_heads2(oracle):
     with torch.no_grad():
         y = enc(cu(x), cu(mask))
     assert maxerr(y, ref) <= 1e-4
+
+
+def test_config5_shape_in_its_arithmetic_hidden512_T4096_bf16(oracle):
+    """BASELINE config 5 AS SPECIFIED: T_mel = 4096, hidden 512 (2 heads of 256 channels, FFN 2048), bf16 arithmetic
+    (VS_MATH_BF16: operands rounded to bf16, fp32 accumulate) -- one prior-transformer layer and one affine coupling layer (with its
+    log-det) at that width, length and arithmetic against the fp64 oracle of the SAME fp32 weights and inputs.
+
+    Stated bf16 tolerance: every operand carries a relative rounding error of <= 2^-9 (8-bit significand), accumulated in fp32; a
+    conv output therefore sits at ~2^-9 = 2e-3 of its own rms and a layer (four to six convs, a LayerNorm, the attention) at a
+    small multiple of that: rms error <= 2 % of the output's rms, no single element off by more than 0.15 of the rms scale; the
+    log-det (a sum of 256 x 4096 independently perturbed terms) <= 1e-2 relative."""
+    from visinger_amd import _lib as L
+    from visinger_amd.modules.hipconv import set_conv_math
+    from visinger_amd.modules.rel_transformer import RelativeEncoder
+    from visinger_amd.modules.visinger.flow import ResidualCouplingLayer
+    T, C = 4096, 512
+    r = np.random.default_rng(5)
+    x = r.standard_normal((1, C, T)).astype(np.float32)
+    mask = np.ones((1, 1, T), np.float32)
+    mask[0, :, 3900:] = 0
+
+    enc = RelativeEncoder(C, 2048, 2, 1, kernel_size=9)
+    sde = _rand_sd(enc, 11)
+    enc = set_conv_math(enc.cuda().eval(), L.MATH_BF16)
+    ref = oracle.rel_encoder(sde, x, mask, None, n_heads=2, n_layers=1, kernel_size=9)
+    with torch.no_grad():
+        y = enc(cu(x), cu(mask)).cpu().double().numpy()
+    assert np.isfinite(y).all()
+    scale = np.sqrt((ref ** 2).mean())
+    rms, worst = np.sqrt(((y - ref) ** 2).mean()) / scale, np.abs(y - ref).max() / scale
+    print(f"config-5 encoder layer, bf16 arithmetic: rms err {rms:.2e} of the output rms, max {worst:.2e}")
+    assert rms <= 2e-2 and worst <= 0.15, (rms, worst)
+
+    lay = ResidualCouplingLayer(C, C, 5, 1, 4, gin_channels=256, mean_only=False)
+    sdl = _rand_sd(lay, 12, 0.5)
+    g = r.standard_normal((1, 256, 1)).astype(np.float32)
+    lay = set_conv_math(lay.cuda().eval(), L.MATH_BF16)
+    ref_y, ref_ld = oracle.coupling_layer(sdl, x, mask, g, channels=C, hidden_channels=C, kernel_size=5, dilation_rate=1, n_layers=4,
+                                          mean_only=False)
+    with torch.no_grad():
+        yl, ld = lay(cu(x), cu(mask), g=cu(g))
+    yl, ld = yl.cpu().double().numpy(), ld.cpu().double().numpy()
+    scale = np.sqrt((ref_y ** 2).mean())
+    rms = np.sqrt(((yl - ref_y) ** 2).mean()) / scale
+    ld_rel = float(np.abs(ld - ref_ld).max() / np.abs(ref_ld).max())
+    print(f"config-5 coupling layer, bf16 arithmetic: rms err {rms:.2e}, log-det {ld[0]:.3f} vs {ref_ld[0]:.3f} (rel {ld_rel:.2e})")
+    assert rms <= 2e-2 and ld_rel <= 1e-2, (rms, ld_rel)
+    # the same layer in the default fp32-class arithmetic meets the fp32 bar at this shape (log-det <= 1e-4 relative)
+    set_conv_math(lay, L.MATH_SPLIT6)
+    with torch.no_grad():
+        yl6, ld6 = lay(cu(x), cu(mask), g=cu(g))
+    assert np.abs(yl6.cpu().double().numpy() - ref_y).max() <= 2e-4 * (1 + np.abs(ref_y).max())
+    assert float(np.abs(ld6.cpu().double().numpy() - ref_ld).max() / np.abs(ref_ld).max()) <= 1e-4

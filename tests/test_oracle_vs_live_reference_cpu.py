@@ -86,3 +86,49 @@ def test_full_width_transformers_and_posterior(ref, oracle):
     _close(muo, mu, 1e-4)
     _close(logso, logs, 1e-4)
     assert float(np.abs(zo - z.numpy()).max() / (1.0 + np.abs(z.numpy()).max())) <= 1e-4
+
+
+def test_reference_ckpt_utils_reads_our_checkpoint(ref, tmp_path):
+    """SURVEY 8f-4 pinned against the reference rather than against ourselves: a file written by visinger_amd.ckpt.save_checkpoint
+    is found and loaded by the reference's own utils/commons/ckpt_utils.py (get_all_ckpts: newest first; load_ckpt(strict=True),
+    ckpt_utils.py:17-63) into the REFERENCE's modules, whose forward then equals the golden output of the weights we saved; and a
+    legacy-serialised file laid out as the reference's Trainer writes it (trainer.py:473-492) loads into ours."""
+    import torch
+    from conftest import load_golden
+    from visinger_amd import ckpt
+    from visinger_amd.modules.visinger.flow import ResidualCouplingBlock as OurFlow
+    spec = importlib.util.spec_from_file_location("ref_ckpt_utils", os.path.join(REF, "utils", "commons", "ckpt_utils.py"))
+    ref_ckpt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_ckpt)
+
+    w, a = load_golden("flow_block")
+    C, H, k, dr, n_layers, n_flows, gin = (int(v) for v in a["cfg"])
+    ctor = (C, H, k, dr, n_layers)
+    ours = OurFlow(*ctor, n_flows=n_flows, gin_channels=gin)
+    ours.load_state_dict({k_: torch.from_numpy(v) for k_, v in w.items()}, strict=True)
+    opt = torch.optim.AdamW(ours.parameters(), lr=2e-4, betas=(0.8, 0.99), eps=1e-9)
+    ckpt.save_checkpoint(tmp_path / "model_ckpt_steps_100.ckpt", {"model": ours}, [opt], epoch=1, global_step=100)
+    ckpt.save_checkpoint(tmp_path / "model_ckpt_steps_2500.ckpt", {"model": ours}, [opt], epoch=9, global_step=2500)
+
+    found = ref_ckpt.get_all_ckpts(str(tmp_path))
+    assert [os.path.basename(p) for p in found] == ["model_ckpt_steps_2500.ckpt", "model_ckpt_steps_100.ckpt"]
+    theirs = ref.ResidualCouplingBlock(*ctor, n_flows=n_flows, gin_channels=gin).eval()
+    ref_ckpt.load_ckpt(theirs, str(tmp_path), model_name="model", strict=True)          # the reference's loader, directory form
+    for (k1, v1), (k2, v2) in zip(theirs.state_dict().items(), ours.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    x, mask, g = torch.from_numpy(a["x"]), torch.from_numpy(a["mask"]), torch.from_numpy(a["g"])
+    np.testing.assert_allclose(theirs(x, mask, g=g).numpy(), a["y"], atol=1e-6)      # the golden output of the weights we saved
+    raw, path = ref_ckpt.get_last_checkpoint(str(tmp_path))
+    assert path.endswith("2500.ckpt") and raw["global_step"] == 2500 and len(raw["optimizer_states"]) == 1
+
+    # the other direction: the layout the reference's Trainer.save_checkpoint writes (legacy pickle of this dict)
+    theirs2 = ref.randomize(ref.ResidualCouplingBlock(*ctor, n_flows=n_flows, gin_channels=gin), 77)
+    their_file = tmp_path / "theirs" / "model_ckpt_steps_40.ckpt"
+    os.makedirs(their_file.parent)
+    torch.save({"epoch": 0, "global_step": 40, "checkpoint_callback_best": 1e9, "optimizer_states": [],
+                "state_dict": {"model": theirs2.state_dict()}}, their_file, _use_new_zipfile_serialization=False)
+    mine = OurFlow(*ctor, n_flows=n_flows, gin_channels=gin)
+    step, _ = ckpt.load_model(mine, str(their_file.parent), child="model", strict=True)
+    assert step == 40
+    for (k1, v1), (k2, v2) in zip(theirs2.state_dict().items(), mine.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)

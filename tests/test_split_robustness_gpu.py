@@ -1,0 +1,107 @@
+"""Robustness of the split-bf16 x6 arithmetic (csrc/conv_split.hip, conv_common.h split_pair) beyond N(0, 1) data: operands spanning
+forty binary orders of magnitude, catastrophic cancellation, and non-finite inputs -- against the fp64 oracle and next to the
+exact-fp32 MFMA engine on the same data.  Reference arithmetic: torch's fp32 conv (config/models/base_config.yaml:5 `amp: false`).
+
+Error measure: |y - y_fp64| against S = sum |x| |w| over the receptive field (the condition-aware scale of a dot product: an fp32
+evaluation in any order is bounded by ~n * 2^-24 * S and typically sits at sqrt(n) * 2^-24 * S; a bound relative to |y| is
+meaningless under cancellation)."""
+import numpy as np
+import pytest
+import torch
+
+from visinger_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def run(oracle, x, w, bias, k, d, maths=(L.MATH_F32, L.MATH_SPLIT6)):
+    from visinger_amd.ops import ConvOp
+    C_out, C_in, _ = w.shape
+    pad = d * (k - 1) // 2
+    ref = oracle.conv1d(x.astype(np.float64), w, bias, dilation=d, padding=pad)
+    S = oracle.conv1d(np.abs(x).astype(np.float64), np.abs(w), None if bias is None else np.abs(bias), dilation=d, padding=pad)
+    out = {}
+    for math in maths:
+        op = ConvOp(L.CONV1D, C_in, C_out, k, d, pad).set_math(math)
+        op.set_weights(dev(w), None, None if bias is None else dev(bias))
+        y = op.forward(dev(x)).cpu().double().numpy()
+        out[math] = (y, float(np.max(np.abs(y - ref) / np.maximum(S, 1e-300))), float(np.sqrt(np.mean(((y - ref) / np.maximum(S, 1e-300)) ** 2))))
+    return ref, S, out
+
+
+@pytest.mark.parametrize("C,k,d,T,span", [(128, 7, 1, 1500, 20), (64, 11, 3, 2048, 20), (256, 3, 1, 700, 12), (32, 7, 5, 3000, 20)])
+def test_wide_dynamic_range(oracle, monkeypatch, C, k, d, T, span):
+    """activations and weights with magnitudes log-uniform over 2^-span .. 2^span and random signs: every plane of the split sees
+    every exponent; the lower planes (x - xh, x - xh - xm) of large and of tiny values are all exercised"""
+    monkeypatch.setenv("VS_NO_WINO", "1")
+    r = np.random.default_rng(C + 13 * k + d)
+    x = (r.choice([-1.0, 1.0], (2, C, T)) * np.exp2(r.uniform(-span, span, (2, C, T))) * r.uniform(1, 2, (2, C, T))).astype(np.float32)
+    w = (r.choice([-1.0, 1.0], (C, C, k)) * np.exp2(r.uniform(-span, span, (C, C, k))) * r.uniform(1, 2, (C, C, k))).astype(np.float32)
+    bias = r.standard_normal(C).astype(np.float32)
+    _, _, out = run(oracle, x, w, bias, k, d)
+    (_, max32, rms32), (_, max6, rms6) = out[L.MATH_F32], out[L.MATH_SPLIT6]
+    n = C * k
+    print(f"wide range C={C} k={k} d={d}: max|err|/S split6 {max6:.3e} fp32-mfma {max32:.3e}; rms split6 {rms6:.3e} fp32-mfma {rms32:.3e}")
+    assert max6 <= 4 * 2.0 ** -24 * np.sqrt(n) + 2.0 ** -22, (max6, max32)      # fp32 class: a few ulp-of-S, like the fp32 engine
+    # sums dominated by a handful of huge products: the split's dropped cross terms (<= 3 * 2^-24 of a product, one-sided because the
+    # planes are truncations) weigh as much as the fp32 engine's own product rounding (<= 2^-24): same class, up to ~3x its rms
+    assert rms6 <= 3.0 * rms32 + 2.0 ** -26, (rms6, rms32)
+
+
+@pytest.mark.parametrize("C,k,T", [(128, 7, 1024), (64, 3, 4096)])
+def test_catastrophic_cancellation(oracle, monkeypatch, C, k, T):
+    """pairs of channels carry +a and -a(1 - 2^-12) under equal weights: each output is the small difference of products 2^12
+    times larger, so any error of the operand split relative to the OPERANDS (not to the result) would surface 4096-fold"""
+    monkeypatch.setenv("VS_NO_WINO", "1")
+    r = np.random.default_rng(7 * C + k)
+    a = (r.standard_normal((2, C // 2, T)) * 100.0).astype(np.float32)
+    x = np.empty((2, C, T), np.float32)
+    x[:, 0::2] = a
+    x[:, 1::2] = -(a * np.float32(1.0 - 2.0 ** -12)).astype(np.float32)
+    w = np.repeat((r.standard_normal((C, C // 2, k)) / np.sqrt(C * k)).astype(np.float32), 2, axis=1)      # equal weights within a pair
+    ref, S, out = run(oracle, x, w, None, k, 1)
+    assert np.median(np.abs(ref) / S) < 2e-4                       # the data really cancels
+    (_, max32, rms32), (_, max6, rms6) = out[L.MATH_F32], out[L.MATH_SPLIT6]
+    print(f"cancellation C={C} k={k}: max|err|/S split6 {max6:.3e} fp32-mfma {max32:.3e}; rms split6 {rms6:.3e} fp32-mfma {rms32:.3e}")
+    assert max6 <= 4 * 2.0 ** -24 * np.sqrt(C * k) + 2.0 ** -22, (max6, max32)
+    assert rms6 <= 1.5 * rms32 + 2.0 ** -26, (rms6, rms32)
+    # alternating signs with exact cancellation: sum_k (+v, -v) * 1 == 0 exactly in every arithmetic (the six cross products of
+    # +v and -v cancel pairwise inside the accumulator: no residue from the split)
+    x2 = np.empty((1, C, T), np.float32)
+    v = (r.standard_normal((1, C // 2, T)) * np.exp2(r.integers(-20, 20, (1, C // 2, T)))).astype(np.float32)
+    x2[:, 0::2], x2[:, 1::2] = v, -v
+    w2 = np.ones((C, C, 1), np.float32)
+    _, _, out2 = run(oracle, x2, w2, None, 1, 1)
+    for math, (y, _, _) in out2.items():
+        assert np.abs(y).max() <= 2.0 ** -24 * np.abs(v).max() * C, math
+
+
+def test_nonfinite_inputs_stay_local_and_nonfinite(oracle):
+    """A +-Inf or NaN activation: the reference (torch fp32 conv) returns +-Inf or NaN in the outputs whose receptive field holds
+    it.  split_pair's lower planes of an Inf are Inf - Inf = NaN, so the split engine returns NaN where the reference may return
+    +-Inf: outputs are non-finite in exactly the same positions, every other output is untouched.  ('non-finite')"""
+    from visinger_amd.ops import ConvOp
+    r = np.random.default_rng(3)
+    C, k, d, T = 64, 7, 3, 1024
+    pad = d * (k - 1) // 2
+    x = r.standard_normal((2, C, T)).astype(np.float32)
+    w = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
+    clean = oracle.conv1d(x.astype(np.float64), w, None, dilation=d, padding=pad)
+    x[0, 5, 100], x[0, 17, 600], x[1, 63, 1023] = np.inf, -np.inf, np.nan
+    hit = np.zeros((2, T), bool)
+    for b, t in ((0, 100), (0, 600), (1, 1023)):
+        for j in range(k):
+            tt = t + pad - j * d
+            if 0 <= tt < T:
+                hit[b, tt] = True
+    for math in (L.MATH_SPLIT6, L.MATH_F32):
+        op = ConvOp(L.CONV1D, C, C, k, d, pad).set_math(math)
+        op.set_weights(dev(w), None, None)
+        y = op.forward(dev(x)).cpu().double().numpy()
+        bad = ~np.isfinite(y)
+        assert (bad == hit[:, None, :]).all(), math                 # non-finite exactly in the receptive fields, for every row
+        assert np.abs(y[~bad] - np.broadcast_to(clean, y.shape)[~bad]).max() <= 2e-5, math

@@ -19,7 +19,8 @@ for C, T in ((32, 262144), (64, 131072)):
             for op in (op1, op2): op.set_weights(torch.randn(C, C, k, device="cuda") * 0.05, None, torch.randn(C, device="cuda"))
             x = torch.randn(B, C, T, device="cuda"); tmp = torch.empty_like(x); y = torch.empty_like(x)
             sep = t(lambda: (op1.forward(x, in_act=L.IN_LRELU, y=tmp), op2.forward(tmp, in_act=L.IN_LRELU, res=x, y=y)))
+            names = f"{op1.kernel_instance()} + {op2.kernel_instance()}"
             fus = t(lambda: respair_forward(op1, op2, x, y, res=x))
             fl = op1.algorithmic_flops(B, T) * 2
-            print(f"C={C} k={k} d={d}: separate {sep:8.1f} us ({op1.kernel_instance()} + {op2.kernel_instance()})   fused {fus:8.1f} us  "
+            print(f"C={C} k={k} d={d}: separate {sep:8.1f} us ({names})   fused {fus:8.1f} us  "
                   f"{fl/fus/1e6:6.1f} TFLOP/s   x{sep/fus:.2f}", flush=True)

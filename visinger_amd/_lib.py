@@ -60,6 +60,7 @@ def lib():
             f"__graft_entry__.build()).  visinger_amd has no CPU fallback.")
     L = ctypes.CDLL(LIB_PATH)
     L.vs_last_error.restype = ctypes.c_char_p
+    L.vs_last_kernel_name.restype = ctypes.c_char_p
     L.vs_abi_version.restype = ctypes.c_int
     L.vs_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.vs_weightnorm_fold.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
@@ -97,12 +98,20 @@ def check(rc):
         raise VisingerHipError(f"libvisinger_hip error {rc}: {lib().vs_last_error().decode()}")
 
 
+_gpu_ok = False
+
+
 def require_gpu():
-    """Fail loudly when the HIP path cannot run (no GPU / library not built)."""
+    """Fail loudly when the HIP path cannot run (no GPU / library not built).  (The positive answer is cached: this sits on
+    every launch.)"""
+    global _gpu_ok
+    if _gpu_ok:
+        return _lib
     import torch
     L = lib()
     if not torch.cuda.is_available():
         raise VisingerHipError("visinger_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU path.")
+    _gpu_ok = True
     return L
 
 

@@ -39,6 +39,14 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+thread_local char g_last_kernel[160] = "";
+void set_last_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+
 
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) conv_mfma_kernel(const ConvParams p) {
@@ -1040,6 +1048,7 @@ static int launch_cfg(const ConvParams &p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, BM_TILES), (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("conv_mfma_kernel<%d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N);
     return VS_OK;
 }
 
@@ -1059,6 +1068,7 @@ static int launch_wino(const ConvParams &p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, WAVES_M), (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("conv_wino_kernel<%d, %d, %d, %d, %d>", DIL, WAVES_M, WAVES_N, TG, TT);
     return VS_OK;
 }
 
@@ -1087,6 +1097,7 @@ static int launch_wino_dil(ConvParams &p, int MT, int span_w, int spec, hipStrea
 extern "C" {
 
 const char *vs_last_error(void) { return g_err; }
+const char *vs_last_kernel_name(void) { return g_last_kernel; }
 int vs_abi_version(void) { return 1; }
 
 int vs_device_info(char *buf, size_t n) {
@@ -1284,6 +1295,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     const int rows_out = (h->kind == VS_CONV1D_PAIRED) ? h->Hh : h->c_out;
     p.split_row = (io->split_row > 0 && io->split_row < rows_out && h->kind != VS_CONV1D_PAIRED) ? io->split_row : 0;
     bool need_mask = (io->in_act >= VS_IN_MASK);
+    bool need_out_mask = false;      // a mask indexed by OUTPUT position: only defined where T_out == T (never for a transposed conv)
     VS_REQUIRE(io->in_act >= VS_IN_NONE && io->in_act <= VS_IN_LRELU_MASK, "vs_conv_forward: bad in_act");
     for (int s = 0; s < 2; ++s) {
         const vs_conv_out_t &o = io->out[s];
@@ -1296,7 +1308,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         d.out_act = o.out_act; d.out_mask = o.out_mask; d.mode = o.mode;
         d.rows = rows;
         if (s == 0 || p.split_row) {
-            need_mask |= (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
+            need_out_mask |= (o.out_mask != 0) || (o.mode != VS_OUT_LINEAR);
             VS_REQUIRE(o.mode == VS_OUT_LINEAR || o.res, "vs_conv_forward: coupling mode needs res (x1)");
         }
     }
@@ -1309,11 +1321,13 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         VS_REQUIRE(io->pair_mode >= VS_PAIR_GATE && io->pair_mode <= VS_PAIR_COUPLING_INV, "bad pair_mode");
         if (io->pair_mode != VS_PAIR_GATE) {
             VS_REQUIRE(io->out[0].res, "vs_conv_forward: coupling pair mode needs out[0].res (x1)");
-            need_mask = true;
+            need_out_mask = true;
         }
     }
+    need_mask |= need_out_mask;
     VS_REQUIRE(!need_mask || io->mask, "vs_conv_forward: mask required but NULL");
-    VS_REQUIRE(Tout == io->T || !need_mask || h->kind != VS_CONV_TRANSPOSE1D, "mask with transposed conv unsupported");
+    // (an INPUT mask -- VS_IN_MASK / VS_IN_LRELU_MASK, indexed by input frame while staging -- is fine with any kind)
+    VS_REQUIRE(Tout == io->T || !need_out_mask, "vs_conv_forward: an output mask needs T_out == T (not with a transposed / unpadded conv)");
     hipStream_t s = as_stream(stream);
     static const bool trace = getenv("VS_TRACE") != nullptr;   // debug: one line per launch on stderr
     if (trace)
@@ -1342,6 +1356,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
             if (k7) hipLaunchKernelGGL((conv_small_kernel<CO, 7, 3>), grid, dim3(256), 0, s, q);           \
             else if (k1) hipLaunchKernelGGL((conv_small_kernel<CO, 1, 0>), grid, dim3(256), 0, s, q);      \
             else hipLaunchKernelGGL((conv_small_kernel<CO, 0, 0>), grid, dim3(256), 0, s, q);              \
+            set_last_kernel("conv_small_kernel<%d, %d, %d>", CO, k7 ? 7 : (k1 ? 1 : 0), k7 ? 3 : 0);       \
         } while (0)
         if (h->c_out == 1) VS_SMALL(1);
         else if (h->c_out == 2) VS_SMALL(2);

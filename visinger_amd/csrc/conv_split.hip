@@ -345,6 +345,7 @@ static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, BM_TILES), (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("conv_split_kernel<%d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS);
     return VS_OK;
 }
 

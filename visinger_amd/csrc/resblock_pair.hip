@@ -286,6 +286,7 @@ static int launch_pair(const PairParams &p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, NOUT), 1, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("respair_kernel<%d, %d>", WAVES_M, WAVES_N);
     return VS_OK;
 }
 

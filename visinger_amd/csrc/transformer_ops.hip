@@ -332,6 +332,7 @@ static int launch_attn(const AttnParams &p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, 32 * NWV), (unsigned)p.nh, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("relattn_kernel<%d, %d, %s>", DT, NWV, WIDE ? "true" : "false");
     return VS_OK;
 }
 

@@ -12,6 +12,9 @@
 namespace vs {
 
 void set_error(const char *fmt, ...);
+// name of the kernel instance the calling thread launched last ("conv_split_kernel<1, 8, 4, 1, 6>": template arguments as
+// rocprofv3 prints them) -- read back through vs_last_kernel_name() by the bench's per-launch attribution
+void set_last_kernel(const char *fmt, ...);
 
 #define VS_CHECK_HIP(expr)                                                                             \
     do {                                                                                               \

@@ -95,19 +95,24 @@ class VISinger(nn.Module):
             z_seg, ret["ids_slice"] = slice_segments(z_q, ids, self.segment_size), ids
         ret["wav_out"] = self.decoder(z_seg, g=spk).squeeze(1)
 
-    def _sample_and_decode(self, frame_mask, spk, mu_p, logs_p, noise, ret):
-        """synthesis side: reparameterised prior sample, flow inverse, full-length decode (visinger.py:105-110)"""
+    def _sample_and_decode(self, frame_mask, spk, mu_p, logs_p, noise, ret, mask_decoder=False):
+        """synthesis side: reparameterised prior sample, flow inverse, full-length decode (visinger.py:105-110).
+        mask_decoder (not in the reference, which synthesises one utterance at a time): decode a padded batch so that every
+        item's samples equal its standalone synthesis (Generator.forward x_mask)."""
         eps = torch.randn_like(mu_p) if noise is None else noise
         z_p = (mu_p + eps * torch.exp(logs_p)) * frame_mask
         z_q = self.flow(z_p, frame_mask, g=spk, reverse=True) * frame_mask
-        ret["wav_out"] = self.decoder(z_q * frame_mask, g=spk).squeeze(1)
+        if mask_decoder:
+            ret["wav_out"] = self.decoder(z_q * frame_mask, g=spk, x_mask=frame_mask).squeeze(1)
+        else:
+            ret["wav_out"] = self.decoder(z_q * frame_mask, g=spk).squeeze(1)
 
     def forward(self, text_tokens, pitch_tokens, dur_tokens, mel2ph, spk_embed=None, spk_id=None, f0=None, uv=None,
-                mel=None, infer=False, noise=None, noise_q=None, u_slice=None, **kwargs):
+                mel=None, infer=False, noise=None, noise_q=None, u_slice=None, mask_decoder=False, **kwargs):
         ret = {}
         frame_mask, spk, mu_p, logs_p = self._prior(text_tokens, pitch_tokens, dur_tokens, mel2ph, spk_embed, spk_id, f0, uv, ret)
         if infer:
-            self._sample_and_decode(frame_mask, spk, mu_p, logs_p, noise, ret)
+            self._sample_and_decode(frame_mask, spk, mu_p, logs_p, noise, ret, mask_decoder=mask_decoder)
         else:
             self._posterior_branch(mel, frame_mask, spk, mu_p, logs_p, noise_q, u_slice, ret)
         return ret

@@ -66,9 +66,10 @@ class _HipConvMixin:
             return conv(self, x)
         return self.run(x.contiguous().float())
 
-    def __getstate__(self):                      # handles are process-local
+    def __getstate__(self):                      # handles are process-local (forward, backward-data and discriminator caches)
         st = self.__dict__.copy()
-        st.pop("_hip_ops", None)
+        for key in ("_hip_ops", "_hip_bwd_ops", "_hip_disc_ops"):
+            st.pop(key, None)
         return st
 
 
@@ -90,6 +91,18 @@ def set_conv_math(module, math):
                 m.__dict__.pop("_hip_math", None)
             else:
                 m.__dict__["_hip_math"] = int(math)
+    return module
+
+
+def repack_weights(module):
+    """Drop every packed-weight cache under `module`: the next forward re-folds and re-packs from the live parameters.  The
+    cache key (data_ptr, in-place version) of visinger_amd.ops.ConvOp.set_weights follows optimizer steps, ``load_state_dict``
+    and ``copy_`` on the parameter itself, but NOT edits made through ``p.data`` (EMA swaps, manual re-initialisation: `.data`
+    carries its own version counter) -- call this after such an edit."""
+    for m in module.modules():
+        for key in ("_hip_ops", "_hip_bwd_ops", "_hip_disc_ops"):
+            for op in m.__dict__.get(key, {}).values():
+                op.invalidate()
     return module
 
 

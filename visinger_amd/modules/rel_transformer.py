@@ -18,18 +18,6 @@ from ..ops import layernorm_c, rel_attention, _off
 from .hipconv import HipConv1d, mask2d, _forward_only_guard
 
 
-def convert_pad_shape(pad_shape):
-    l = pad_shape[::-1]
-    return [item for sublist in l for item in sublist]
-
-
-def sequence_mask(length, max_length=None):
-    if max_length is None:
-        max_length = length.max()
-    x = torch.arange(max_length, dtype=length.dtype, device=length.device)
-    return x.unsqueeze(0) < length.unsqueeze(1)
-
-
 class LayerNorm(nn.Module):
     """rel_transformer.py:24-42: normalises dim 1 of [B, C, T]; biased variance, eps inside rsqrt."""
 

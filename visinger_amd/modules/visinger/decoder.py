@@ -62,23 +62,37 @@ class Generator(nn.Module):
         if gin_channels != 0:
             self.cond = HipConv1d(gin_channels, widths[0], 1)
 
-    def forward(self, x, g=None):
+    def forward(self, x, g=None, x_mask=None):
+        """decoder.py:40-59.  `x_mask` ([B, 1, T] frame mask; not a reference argument) makes a PADDED batch exact: the reference
+        decodes one utterance at a time (tasks/visinger.py:244-263), so an item's last frames see zero padding beyond its own
+        end, whereas in a padded batch the unmasked generator lets conv_pre's bias + speaker condition in the padding leak back
+        through the receptive field.  With the mask every conv reads zeros beyond the item's length at its stage's resolution,
+        i.e. each item's valid samples equal its standalone decode."""
         if autograd.training_path(self):
             return autograd.generator(self, x, g)
         _forward_only_guard(self)
         x = x.contiguous().float()
+        B, _, T = x.shape
+        mask = None
+        if x_mask is not None:
+            mask = mask2d(x_mask, B, T)
+            if bool((mask == 1).all()):
+                mask = None                                     # nothing padded: the fused (unmasked) launches
         cb = None
         if g is not None:
             cb = self.cond.run(g.contiguous().float())          # [B, C0, 1] -> per-item bias of conv_pre
-        x = self.conv_pre.run(x, bias_b=cb)
+        x = self.conv_pre.run(x, bias_b=cb, in_act=L.IN_NONE if mask is None else L.IN_MASK, mask=mask)
         nk = self.num_kernels
+        act = L.IN_LRELU if mask is None else L.IN_LRELU_MASK
         for i in range(self.num_upsamples):
-            x = self.ups[i].run(x, in_act=L.IN_LRELU)
+            x = self.ups[i].run(x, in_act=act, mask=mask)
+            if mask is not None:                                # the frame mask at this stage's resolution
+                mask = mask.repeat_interleave(x.shape[2] // mask.shape[1], dim=1).contiguous()
             xs = torch.empty_like(x)
             for j in range(nk):
-                self.resblocks[i * nk + j]._run_fused(x, xs, first=(j == 0), scale=(1.0 / nk if j == nk - 1 else 1.0))
+                self.resblocks[i * nk + j]._run_fused(x, xs, first=(j == 0), scale=(1.0 / nk if j == nk - 1 else 1.0), mask=mask)
             x = xs
-        return self.conv_post.run(x, in_act=L.IN_LRELU, out_act=L.OUT_TANH)
+        return self.conv_post.run(x, in_act=act, mask=mask, out_act=L.OUT_TANH, out_mask=mask is not None)
 
     def remove_weight_norm(self):
         _strip(self.ups)

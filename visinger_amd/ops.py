@@ -20,7 +20,7 @@ class LaunchProfiler:
 
     def __init__(self):
         self.enabled = False
-        self.records = []          # (kernel instance name, algorithmic flops, start event, end event)
+        self.records = []          # (kernel instance name, algorithmic flops, algorithmic HBM bytes, start event, end event)
 
     def start(self):
         self.records = []
@@ -32,10 +32,11 @@ class LaunchProfiler:
     def summary(self):
         """-> {instance: dict(launches, flops, ms)} ; call after torch.cuda.synchronize()."""
         out = {}
-        for name, fl, e0, e1 in self.records:
-            d = out.setdefault(name, dict(launches=0, flops=0.0, ms=0.0))
+        for name, fl, by, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
             d["launches"] += 1
             d["flops"] += fl
+            d["bytes"] += by
             d["ms"] += e0.elapsed_time(e1)
         return out
 
@@ -47,13 +48,40 @@ class ConvOp:
     """vs_conv_t: one nn.Conv1d / nn.ConvTranspose1d site, weights folded + packed on the device."""
 
     def __init__(self, kind, c_in, c_out, k, dilation_or_stride=1, padding=0, flags=0):
-        self.lib = L.require_gpu()
         self.kind, self.c_in, self.c_out, self.k = kind, c_in, c_out, k
         self.dil, self.pad, self.flags = dilation_or_stride, padding, flags
-        h = ctypes.c_void_p()
-        L.check(self.lib.vs_conv_create(ctypes.byref(h), kind, c_in, c_out, k, dilation_or_stride, padding, flags))
-        self.h = h
+        self._h = None               # vs_conv_t*, created on first use (a handle is process- and device-local)
+        self._pending_math = None    # arithmetic to apply when the handle is created (set_math before first use / after a copy)
         self._wkey = None
+        self._last_kernel = ""
+        if torch.cuda.is_available():
+            _ = self.h               # fail early (bad dims, missing library) where a GPU is present
+
+    @property
+    def lib(self):
+        return L.require_gpu()
+
+    @property
+    def h(self):
+        if self._h is None:
+            h = ctypes.c_void_p()
+            L.check(self.lib.vs_conv_create(ctypes.byref(h), self.kind, self.c_in, self.c_out, self.k, self.dil, self.pad, self.flags))
+            self._h = h
+            if self._pending_math is not None:
+                L.check(self.lib.vs_conv_set_math(h, int(self._pending_math), L.stream_ptr()))
+        return self._h
+
+    def _args(self):
+        return (self.kind, self.c_in, self.c_out, self.k, self.dil, self.pad, self.flags)
+
+    # A handle owns device memory and must be destroyed exactly once: copies (copy.deepcopy of a module for an EMA model,
+    # torch.save(module), pickling for a spawned worker) get a FRESH handle with the same geometry and arithmetic and no
+    # weights -- the owner re-binds its parameters on the next forward (the packed-weight cache key starts empty).
+    def __reduce__(self):
+        return (_rebuild_conv_op, (self._args(), self.math if self._h is not None else self._pending_math))
+
+    def __deepcopy__(self, memo):
+        return _rebuild_conv_op(self._args(), self.math if self._h is not None else self._pending_math)
 
     @property
     def math(self):
@@ -61,57 +89,34 @@ class ConvOp:
         return int(self.lib.vs_conv_get_math(self.h))
 
     def set_math(self, math):
+        self._pending_math = int(math)
         L.check(self.lib.vs_conv_set_math(self.h, int(math), L.stream_ptr()))
         return self
 
+    def invalidate(self):
+        """Forget the packed-weight cache key: the next set_weights re-folds and re-packs.  For in-place edits the key cannot
+        see (`p.data.copy_()` / `p.data.mul_()`: `.data` has its own version counter)."""
+        self._wkey = None
+
     def __del__(self):
-        h, self.h = getattr(self, "h", None), None
+        h, self._h = getattr(self, "_h", None), None
         if h:
             try:
-                self.lib.vs_conv_destroy(h)
+                L.lib().vs_conv_destroy(h)
             except Exception:
                 pass
 
     def out_len(self, T):
         return int(self.lib.vs_conv_out_len(self.h, T))
 
+    def last_kernel(self):
+        """Kernel instance the last launch on this thread went to, as the library reports it (vs_last_kernel_name: the
+        dispatch lives in csrc/conv_engine.hip only)."""
+        return self.lib.vs_last_kernel_name().decode()
+
     def kernel_instance(self):
-        """Name of the conv_mfma_kernel<MT_W,NT_W,WAVES_M,WAVES_N> instance vs_conv_forward dispatches to
-        (mirrors the selection in csrc/conv_engine.hip)."""
-        math = self.math
-        if self.kind == L.CONV1D_PAIRED:
-            mt = 2 * -(-(self.c_out // 2) // 32)
-            if math:
-                return f"conv_split_kernel<2,2,2,2,{math}>" if mt >= 4 else f"conv_split_kernel<2,2,1,4,{math}>"
-            return "conv_mfma_kernel<2,2,2,2>" if mt >= 4 else "conv_mfma_kernel<2,2,1,4>"
-        if self.kind == L.CONV1D and self.c_out <= 4 and self.c_in * self.k <= 2048:
-            return "conv_small_kernel"
-        if math:
-            rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
-            mt = -(-rows // 32)
-            if mt >= 3:
-                cfg = "1,4,2,2" if mt % 4 == 2 else "1,8,4,1"
-            else:
-                cfg = "1,4,2,2" if mt == 2 else "1,2,1,4"
-            return f"conv_split_kernel<{cfg},{math}>"
-        odd = (self.c_out // 32) % 2 == 1
-        pays = (self.k >= 9 and self.dil == 1) if odd else (self.dil == 1 or self.k >= 7)
-        pays = pays or os.environ.get("VS_WINO_FORCE")
-        if self.wino_eligible() and pays and not os.environ.get("VS_NO_WINO"):
-            mt = self.c_out // 32
-            cfg = "4,1" if mt % 4 == 0 else ("2,2" if mt % 2 == 0 else "1,4")
-            spec = "0,3"                                    # generic; k = 7 / 11 have straight-line instances (TG, TT)
-            if not os.environ.get("VS_NO_WINO_K7"):
-                if self.k == 7 and mt % 2 == 0:
-                    spec = "3,1"
-                elif self.k == 11 and (mt % 2 == 0 or self.dil == 1):
-                    spec = "4,2"
-            return f"conv_wino_kernel<{self.dil},{cfg},{spec}>"
-        rows = self.c_out * (self.dil if self.kind == L.CONV_TRANSPOSE1D else 1)
-        mt = -(-rows // 32)
-        if mt >= 3:
-            return "conv_mfma_kernel<1,8,4,1>"      # (or <1,4,2,2> / <1,8,2,2> for 6-tile launches; same family)
-        return "conv_mfma_kernel<1,8,2,2>" if mt == 2 else "conv_mfma_kernel<1,4,1,4>"
+        """Kernel instance this handle's most recent forward() was dispatched to ("" before the first launch)."""
+        return self._last_kernel
 
     def wino_eligible(self):
         """mirrors vs_conv_create: stride-1 'same' conv, odd k >= 3, dilation 1/3/5, whole 32-row tiles -> F(2,3) path
@@ -186,10 +191,21 @@ class ConvOp:
             e0.record()
             L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
             e1.record()
-            PROFILER.records.append((self.kernel_instance(), self.algorithmic_flops(B, T), e0, e1))
+            self._last_kernel = self.last_kernel()
+            passes = 1 + (res is not None or res_ptr is not None) + (acc is not None or acc_ptr is not None)
+            nb = 4.0 * B * (self.c_in * T + passes * self.rows_out * Tout)      # x once, residual / accumulate inputs once, y once
+            PROFILER.records.append((self._last_kernel, self.algorithmic_flops(B, T), nb, e0, e1))
         else:
             L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
+            self._last_kernel = self.last_kernel()
         return y
+
+
+def _rebuild_conv_op(args, math):
+    op = ConvOp.__new__(ConvOp)
+    op.kind, op.c_in, op.c_out, op.k, op.dil, op.pad, op.flags = args
+    op._h, op._pending_math, op._wkey, op._last_kernel = None, math, None, ""
+    return op
 
 
 def weightnorm_fold(v, g):
@@ -210,11 +226,17 @@ def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=N
     if out is None:
         out = torch.empty((B, C, T), device=qkv.device, dtype=torch.float32)
     ws = -1 if window_size is None else int(window_size)
+    if PROFILER.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(lib.vs_relattn_fwd(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
                                L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
                                L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
                                C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
                                L.stream_ptr()))
+    if PROFILER.enabled:
+        e1.record()      # algorithmic work: Q K^T and P V over the full [T, T] score matrix = 4 * T * T * k_channels per head
+        PROFILER.records.append((lib.vs_last_kernel_name().decode(), 4.0 * B * C * T * T, 4.0 * B * 4 * C * T, e0, e1))
     return out
 
 
@@ -368,9 +390,9 @@ def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
         e0.record()
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
         e1.record()
-        name = (f"respair_split_kernel<2,{'1,4' if C == 32 else '2,2'}>" if op1.math == L.MATH_SPLIT6
-                else f"respair_kernel<{'1,4' if C == 32 else '2,2'}>")
-        PROFILER.records.append((name, op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), e0, e1))
+        nb = 4.0 * B * C * T * (2 + (res is not None) + (acc is not None))
+        PROFILER.records.append((op1.last_kernel(), op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), nb, e0, e1))
     else:
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
+    op1._last_kernel = op2._last_kernel = op1.last_kernel()
     return y

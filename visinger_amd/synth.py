@@ -55,7 +55,12 @@ def save_wav(wav, path, sr, norm=False):
 @torch.no_grad()
 def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None):
     """Run VISinger.forward(infer=True) over length-bucketed batches.  Returns a list of float32 waveforms trimmed to
-    each item's own length (frames * hop_size), in the input order."""
+    each item's own length (frames * hop_size), in the input order.
+
+    Every waveform equals the item's one-at-a-time synthesis (the reference's test_step, tasks/visinger.py:244-263) given the same
+    noise: the prior, the flow and the attention are masked per item by the reference itself, and the HiFi-GAN generator -- which
+    the reference runs unmasked, on one utterance -- is run with the frame mask at every stage (Generator.forward x_mask) whenever
+    a batch holds items of different lengths, so that nothing leaks from the padding into an item's last frames."""
     device = next(model.parameters()).device
     lengths = [int((np.asarray(it["mel2ph"]) > 0).sum()) for it in items]
     out = [None] * len(items)
@@ -64,7 +69,8 @@ def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1
         B, T = batch["mel2ph"].shape
         noise = torch.randn((B, model.hidden_size, T), device=device, generator=generator) * noise_scale
         wav = model(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"],
-                    spk_id=batch["spk_id"], infer=True, noise=noise)["wav_out"].float().cpu().numpy()
+                    spk_id=batch["spk_id"], infer=True, noise=noise,
+                    mask_decoder=len({lengths[i] for i in idx}) > 1)["wav_out"].float().cpu().numpy()
         for b, i in enumerate(idx):
             out[i] = wav[b, :lengths[i] * hop_size].copy()
     return out

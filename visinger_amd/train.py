@@ -1,7 +1,9 @@
 """GAN training step of VISinger on the MI355X-native modules, restated from the reference's
 ``tasks/visinger.py:53-170,201-227`` (losses, optimizers, schedulers), ``tasks/base.py:227-238`` (masked mel L1) and
 ``utils/commons/trainer.py:306-384`` (two optimizer passes per batch with the other optimizer's parameters frozen,
-gradient clipping over ALL task parameters, one scheduler step per pass).
+gradient clipping over ALL task parameters, ``optimizer.zero_grad()`` right after every ``optimizer.step()``, and
+``tasks/visinger.py:221-227`` (both learning rates set in closed form after every optimizer step: ``base * gamma ** epoch`` with
+the config's ``endless_ds: false`` (config/models/visinger.yaml:106), ``base * gamma ** (global_step // accumulate)`` otherwise).
 
 Forward: HIP conv engine (visinger_amd.autograd); backward: PyTorch-ROCm autograd; data parallel: stock
 ``DistributedDataParallel(find_unused_parameters=True)`` over RCCL, one process per GPU -- the gradient all-reduce (<= 430 MB
@@ -24,7 +26,7 @@ TRAIN_HPARAMS = dict(lr=2e-4, optimizer_adam_beta1=0.8, optimizer_adam_beta2=0.9
                      clip_grad_norm=1.0, lambda_kl=1.0, kl_min=0.0, kl_start_steps=1, lambda_mel=45.0, lambda_ctc=45.0,
                      lambda_mel_adv=1.0, lambda_fm=2.0, lambda_pitch=10.0, disc_start_steps=0, disc_interval=1,
                      sample_rate=24000, fft_size=2048, win_size=1200, hop_size=300, fmin=20.0, fmax=12000.0,
-                     num_mel_bins=128, use_spectral_norm=False)
+                     num_mel_bins=128, use_spectral_norm=False, endless_ds=False, accumulate_grad_batches=1)
 
 
 def masked_l1(pred, target):
@@ -61,6 +63,7 @@ class VISingerTrainer(nn.Module):
         self.model = VISinger(ph_dict_size, pitch_size, dur_size, hparams)
         self.mel_disc = MultiPeriodDiscriminator(self.hp["use_spectral_norm"])
         self.global_step = 0
+        self.current_epoch = 0        # advanced by on_epoch_end(): the learning rate decays once per EPOCH (endless_ds: false)
         self._cached = None
 
     def configure(self):
@@ -72,6 +75,26 @@ class VISingerTrainer(nn.Module):
                                           **h["discriminator_optimizer_params"])
         self.sched = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=h["scheduler_gamma"]) for o in (self.opt_gen, self.opt_disc)]
         return self
+
+    def lr_exponent(self):
+        """tasks/visinger.py:221-227: the argument the reference passes to ``scheduler.step(...)``"""
+        if self.hp["endless_ds"]:
+            return self.global_step // self.hp["accumulate_grad_batches"]
+        return self.current_epoch
+
+    def on_after_optimization(self):
+        """``ExponentialLR.step(n)`` with an explicit n is the closed form lr = base_lr * gamma ** n (torch's
+        ``_get_closed_form_lr``); the reference calls it for BOTH schedulers after every optimizer step."""
+        n = self.lr_exponent()
+        for sch in self.sched:
+            sch.last_epoch = n
+            for group, base in zip(sch.optimizer.param_groups, sch.base_lrs):
+                group["lr"] = base * sch.gamma ** n
+            sch._last_lr = [g["lr"] for g in sch.optimizer.param_groups]
+
+    def on_epoch_end(self):
+        """trainer.py:300-301: one pass over the training set is over"""
+        self.current_epoch += 1
 
     def mel(self, wav):
         h = self.hp
@@ -126,12 +149,12 @@ class VISingerTrainer(nn.Module):
             for p in own.parameters():
                 p.requires_grad_(True)
             loss, parts = runner(batch, opt_idx)
-            opt.zero_grad(set_to_none=True)
             loss.backward()                      # under DDP: the bucketed gradient all-reduce over RCCL happens here
-            if self.hp["clip_grad_norm"] > 0:
+            if self.hp["clip_grad_norm"] > 0:    # (the other network holds no gradients: zeroed right after ITS step, as below)
                 torch.nn.utils.clip_grad_norm_(self.parameters(), self.hp["clip_grad_norm"])
             opt.step()
-            self.sched[opt_idx].step()
+            opt.zero_grad(set_to_none=True)      # trainer.py:373-374: no stale gradients in the next pass's clip norm
+            self.on_after_optimization()
             logs.update({k: float(v.detach()) for k, v in parts.items()})
         for p in self.parameters():
             p.requires_grad_(True)
