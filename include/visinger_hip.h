@@ -152,10 +152,13 @@ VS_API int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T);
  *     the shared batch stride).  rel_k / rel_v: [n_heads_rel, 2*window+1, k_channels] (emb_rel_k / emb_rel_v);
  *     window_size < 0 disables the relative terms.  mask: [B, T] frame mask m, attention mask = m[i]*m[j]; masked
  *     scores are SET to -1e4 (fully masked rows come out uniform, never NaN).  out: [B, n_heads*k_channels, T].
- *     Streaming softmax: no [T, T] tensor is materialised (the reference's `self.attn` is not produced).        */
+ *     Streaming softmax: no [T, T] tensor is materialised (the reference's `self.attn` is not produced).
+ *     math (enum vs_conv_math, declared below): VS_MATH_BF16 rounds q / sqrt(dk), k, v and the probabilities to bf16 and runs both
+ *     GEMMs on the bf16 matrix instruction with fp32 accumulation (softmax statistics and relative terms stay fp32) -- BASELINE.json's
+ *     long-form bf16 configuration; VS_MATH_F32 / VS_MATH_SPLIT6: the exact-fp32 matrix instruction.                  */
 VS_API int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                           const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B,
-                          int n_heads, int k_channels, int64_t T, int window_size, int n_heads_rel, void *stream);
+                          int n_heads, int k_channels, int64_t T, int window_size, int n_heads_rel, int math, void *stream);
 
 /* a7  channel LayerNorm with its neighbours fused (rel_transformer.py:24-42; call sites 297-299, 305-307, 314-316):
  *     y = ((LayerNorm_C(a + r) * gamma + beta) + g) * mask      r, g, mask optional.

@@ -109,3 +109,40 @@ def test_set_conv_math_on_modules(oracle):
         set_conv_math(g, None)
     assert float((y6 - y0).abs().max()) <= 2e-5
     assert 1e-6 < float((y1 - y0).abs().max()) <= 5e-2
+
+
+@pytest.mark.parametrize("dk,nh,T,ws,share", [(96, 2, 1024, 4, True), (64, 2, 260, 4, False), (128, 1, 516, None, True), (32, 4, 64, 4, True),
+                                              (192, 2, 300, 4, True), (256, 2, 1028, 4, True), (256, 1, 4, 1, True), (160, 1, 132, 7, False)])
+def test_bf16_attention_matches_fp32_kernel(dk, nh, T, ws, share):
+    """vs_relattn_fwd with math = VS_MATH_BF16 (csrc/attention_bf16.hip: q / sqrt(dk), k, v and the probabilities rounded to bf16, both
+    GEMMs on the bf16 MFMA, fp32 softmax statistics and relative terms) against the exact-fp32 kernel of the same entry point --
+    which tests/test_modules_gpu.py pins to the reference's golden vectors and the fuzzers to the fp64 oracle.  Ragged masks with an
+    all-padding item, key tiles cut by T, every head-width instance (DT 2, 3, 4: 64-key tiles; 6, 8: 32-key tiles).
+    Stated bf16 tolerance: operands carry 2^-9 relative error each -> scores off by ~2^-8 |q||k| / sqrt(dk) ~ 4e-3 absolute for N(0,1)
+    data, outputs (convex combinations of v) within ~1e-2 of the value scale."""
+    from visinger_amd.ops import rel_attention
+    g = torch.Generator().manual_seed(dk * 7 + T)
+    B, C = 3, dk * nh
+    qkv = torch.randn(B, 3 * C, T, generator=g).cuda()
+    nrel = 0 if ws is None else 2 * ws + 1
+    rel_k = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5).cuda() if nrel else None
+    rel_v = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5).cuda() if nrel else None
+    lens = torch.tensor([T, max(1, (2 * T) // 3), 0])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().cuda()
+    ref = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_F32)
+    got = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    scale = float(ref.pow(2).mean().sqrt())
+    print(f"bf16 attention dk={dk} T={T}: max err {float(err.max()):.2e}, rms {float(err.pow(2).mean().sqrt()):.2e}, output rms {scale:.2e}")
+    assert float(err.pow(2).mean().sqrt()) <= 1e-2 * scale and float(err.max()) <= 0.1 * max(scale, 1e-3)
+    # the library reports which kernel ran: the bf16 one wherever the shape qualifies (T % 4 == 0 here)
+    from visinger_amd import _lib
+    assert _lib.lib().vs_last_kernel_name().decode().startswith("relattn_bf16_kernel<")
+    # T not a multiple of 4: the bf16 request falls back to the exact-fp32 kernel (bit-identical to math = F32)
+    if T > 8:
+        q3 = qkv[:, :, :T - 1].contiguous()
+        m3 = mask[:, :T - 1].contiguous()
+        a = rel_attention(q3, nh, rel_k, rel_v, m3, ws, math=L.MATH_BF16)
+        assert _lib.lib().vs_last_kernel_name().decode().startswith("relattn_kernel<")
+        assert torch.equal(a, rel_attention(q3, nh, rel_k, rel_v, m3, ws, math=L.MATH_F32))

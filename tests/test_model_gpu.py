@@ -215,24 +215,27 @@ def test_batched_synthesis_driver_matches_single_items(tiny):
         alone = m(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"], spk_id=batch["spk_id"],
                   infer=True, noise=noise)["wav_out"][0].cpu().numpy()
     assert np.abs(alone - both[0]).max() <= 1e-6
-    # the SHORTER item sits in the batch with padded frames: its waveform -- tail included -- must equal its one-at-a-time
-    # synthesis (tasks/visinger.py:244-263) on the same noise; the generator runs with the frame mask at every stage for that
-    T1 = len(items[1]["mel2ph"])
-    assert T1 < T0
+    # A SHORTER item in a batch of padded frames: its waveform -- tail included -- must equal its one-at-a-time synthesis
+    # (tasks/visinger.py:244-263) on the same noise; the generator runs with the frame mask at every stage for that.  (Same token
+    # sequence, fewer frames: the reference's TextEncoder views its positional table by the PADDED token length, encoder.py:52-54,
+    # so only items of equal token count can agree with their standalone run at all -- synth.synthesize(equal_tokens=True).)
+    T1 = T0 - 5
+    short = dict(items[0], mel2ph=items[0]["mel2ph"][:T1])
+    pair = [items[0], short]
     g = torch.Generator(device="cuda").manual_seed(0)
-    noise1 = torch.randn((2, m.hidden_size, T0), device="cuda", generator=g)[1:2, :, :T1].contiguous()
-    batch1 = synth.collate(items[1:2], "cuda")
+    both2 = synth.synthesize(m, pair, hop, generator=g, equal_tokens=True)
+    assert len(both2[1]) == T1 * hop and np.abs(both2[0] - both[0]).max() <= 1e-6
+    g = torch.Generator(device="cuda").manual_seed(0)
+    nz = torch.randn((2, m.hidden_size, T0), device="cuda", generator=g)
+    batch1 = synth.collate([short], "cuda")
     with torch.no_grad():
         alone1 = m(batch1["text_tokens"], batch1["pitch_tokens"], batch1["dur_tokens"], batch1["mel2ph"], spk_id=batch1["spk_id"],
-                   infer=True, noise=noise1)["wav_out"][0].cpu().numpy()
-        # and WITHOUT the mask the padded batch differs in the tail (what the unmasked generator of a padded batch would give)
-        pb = synth.collate(items, "cuda")
-        g = torch.Generator(device="cuda").manual_seed(0)
-        nz = torch.randn((2, m.hidden_size, T0), device="cuda", generator=g)
-        order = sorted(range(2), key=lambda i: -len(items[i]["mel2ph"]))
-        unmasked = m(pb["text_tokens"][order], pb["pitch_tokens"][order], pb["dur_tokens"][order], pb["mel2ph"][order],
-                     spk_id=pb["spk_id"][order], infer=True, noise=nz)["wav_out"][1, :T1 * hop].cpu().numpy()
-    assert alone1.shape == both[1].shape and np.abs(alone1 - both[1]).max() <= 2e-6
+                   infer=True, noise=nz[1:2, :, :T1].contiguous())["wav_out"][0].cpu().numpy()
+        # and WITHOUT the mask the padded batch differs in the tail (what the unmasked generator of a padded batch gives)
+        pb = synth.collate(pair, "cuda")
+        unmasked = m(pb["text_tokens"], pb["pitch_tokens"], pb["dur_tokens"], pb["mel2ph"], spk_id=pb["spk_id"], infer=True,
+                     noise=nz)["wav_out"][1, :T1 * hop].cpu().numpy()
+    assert alone1.shape == both2[1].shape and np.abs(alone1 - both2[1]).max() <= 2e-6
     assert np.abs(unmasked - alone1).max() > 1e-5      # the leak the mask removes (conv_pre's bias + speaker condition in the padding)
     pcm = synth.to_int16(both[0])
     assert pcm.dtype == np.int16 and np.abs(pcm).max() == 32767

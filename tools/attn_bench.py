@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of vs_relattn_fwd at the production shape (B=32, 2 heads x 96, T=1024)."""
+"""Micro-benchmark of vs_relattn_fwd: the production shape (B=32, 2 heads x 96, T=1024) and BASELINE config 5 (B=8, 2 heads x 256,
+T=4096), exact-fp32 kernel vs the bf16 kernel (math = VS_MATH_BF16)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visinger_amd import _lib as L
 from visinger_amd.ops import rel_attention
-B, C, T, nh = 32, 192, int(os.environ.get("T", 1024)), 2
-qkv = torch.randn(B, 3 * C, T, device="cuda")
-rk = torch.randn(1, 9, C // nh, device="cuda") * 0.1
-rv = torch.randn(1, 9, C // nh, device="cuda") * 0.1
-mask = torch.ones(B, T, device="cuda")
-out = torch.empty(B, C, T, device="cuda")
-for _ in range(2):
-    rel_attention(qkv, nh, rk, rv, mask, 4, out=out)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(10):
-    rel_attention(qkv, nh, rk, rv, mask, 4, out=out)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 10
-fl = 4.0 * B * nh * T * T * (C // nh)
-print(f"relattn B={B} T={T}: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s (QK^T + PV only)")
+for B, C, T, nh in ((32, 192, 1024, 2), (8, 512, 4096, 2), (8, 192, 4096, 2)):
+    qkv = torch.randn(B, 3 * C, T, device="cuda")
+    rk = torch.randn(1, 9, C // nh, device="cuda") * 0.1
+    rv = torch.randn(1, 9, C // nh, device="cuda") * 0.1
+    mask = torch.ones(B, T, device="cuda")
+    out = torch.empty(B, C, T, device="cuda")
+    for math, name in ((L.MATH_F32, "fp32"), (L.MATH_BF16, "bf16")):
+        for _ in range(2):
+            rel_attention(qkv, nh, rk, rv, mask, 4, out=out, math=math)
+        kern = L.lib().vs_last_kernel_name().decode()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            rel_attention(qkv, nh, rk, rv, mask, 4, out=out, math=math)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        fl = 4.0 * B * nh * T * T * (C // nh)
+        print(f"relattn {name} B={B} C={C} T={T} [{kern}]: {ms*1e3:.1f} us  {fl/ms/1e9:.1f} TFLOP/s (QK^T + PV only)", flush=True)

@@ -1,0 +1,355 @@
+// attention_bf16.hip -- MultiHeadAttention.attention (reference modules/rel_transformer.py:148-179 + 181-243) on the bf16 matrix
+// instruction v_mfma_f32_32x32x16_bf16, for the VS_MATH_BF16 arithmetic (BASELINE.json's long-form configuration: T_mel 4096,
+// hidden 512 -> 2 heads of 256 channels, "bf16 activations/weights with fp32 accumulate").  Same algorithm as relattn_kernel
+// (transformer_ops.hip: streaming softmax over key tiles, -1e4 mask fill, banded relative-key / relative-value terms by index
+// arithmetic, no [T, T] tensor); what changes is the arithmetic of the two GEMMs and everything that follows from the 16-deep
+// bf16 fragments:
+//   * Q (pre-scaled by 1/sqrt(dk) in fp32), K, V and the probabilities P are rounded to bf16 (RNE); S = K^T Q and O = V P^T
+//     accumulate in fp32; row max / sum, the rescale and the relative terms stay fp32;
+//   * key tiles of 64: two S^T accumulator tiles per wave (keys on the rows, the wave's 32 queries on the lanes);
+//   * K tile in LDS as [d/8][key][8 bf16]: an A fragment (8 consecutive d of one key) is one conflict-free ds_read_b128;
+//   * V tile in LDS as [d][64 keys] with the keys of every 16-group stored in the order (0-3, 8-11 | 4-7, 12-15) and a row
+//     pitch of 144 B: the bf16 pairs of S^T registers 8s .. 8s+7 ARE the B fragment of P^T for k-step s (k index
+//     16s + 8(j>>2) + 4h + (j&3): cdna_hip_programming.md 3, "an accumulator tile as the next MFMA's operand"), and with that key
+//     order the matching A fragment of V is one conflict-free ds_read_b128 per lane -- no LDS round trip for P, no shuffles;
+//   * K / V tiles double-buffered in LDS; the next tile's K float4 loads are issued before the S^T MFMAs and rounded / written
+//     after them, its V loads are issued then and written after the P V MFMAs; one barrier per tile.  Heads of up to 128 channels: two workgroups per CU; 129..256: one (a wave then
+//     holds 128 output accumulators + 64 query registers + 128 staging registers).
+#include "attn_common.h"
+#include "conv_common.h"
+
+namespace vs {
+
+// AKT = keys per tile: 64 for heads of up to 128 channels (two S^T accumulator tiles per wave), 32 for wider heads (the fp32 staging
+// registers of a tile scale with DT * AKT: at 256 channels a 64-key tile does not fit next to 128 output accumulators).
+template <int DT, int AKT>
+__global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(const AttnParams p) {
+    constexpr int DKR = DT * 32;                     // padded head dim
+    constexpr int NKS = DKR / 16;                    // k-steps of S^T = K^T Q
+    constexpr int NKT = AKT / 32;                    // S^T accumulator tiles per key tile
+    constexpr int KQ = AKT / 4;                      // key quads per tile
+    constexpr int AVP = AKT / 2 + 4;                 // V row pitch in dwords (AKT keys x 2 B + 16 B: conflict-free ds_read_b128 down a column)
+    constexpr int KCELLS = (DKR / 8) * KQ;           // (d8, key quad) cells of the K tile, 8 float4 loads each
+    constexpr int KCPT = (KCELLS + 255) / 256;
+    constexpr int VCELLS = DKR * KQ;                 // (d, key quad) cells of the V tile, one float4 each
+    constexpr int VCPT = VCELLS / 256;
+    constexpr int KBUF = (DKR / 8) * AKT * 4;        // dwords per K buffer
+    constexpr int VBUF = DKR * AVP;                  // dwords per V buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int dk = p.dk, T = p.T;
+    const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
+
+    unsigned *Ks = reinterpret_cast<unsigned *>(smem);      // [2][DKR/8][64 keys][4 dwords]
+    unsigned *Vs = Ks + 2 * KBUF;                            // [2][DKR][AVP]
+    float *Ms = reinterpret_cast<float *>(Vs + 2 * VBUF);    // [2][64] key mask of the tile
+    float *QRs = Ms + 2 * AKT;                               // [4][32][ATT_QRS] rel-key logits
+    float *Sws = QRs + 4 * 32 * ATT_QRS;                     // [4][32][ATT_QRS] in-window raw scores
+    float *RVs = smem;                                       // [nrel][dk] relative value embeddings: over the K buffers, after the loop
+
+    const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
+    const float *kb = p.k + (long long)b * p.bs + (long long)h * dk * T;
+    const float *vb = p.v + (long long)b * p.bs + (long long)h * dk * T;
+    const float *maskb = p.mask ? p.mask + (long long)b * T : nullptr;
+    const float *relk = nrel ? p.rel_k + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+    const float *relv = nrel ? p.rel_v + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+
+    // ---- query fragments: B operand of S^T = K^T Q, element j of k-step ks = Q[d = 16 ks + 8 half + j][query l31] ----
+    const int qi = i0 + l31;
+    const int qic = min(qi, T - 1);
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        float qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * ks + 8 * half + j;
+            const float v = qb[(long long)min(d, dk - 1) * T + qic];
+            qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
+        }
+        u32x4 f;
+        f.x = pack_hi(rne_bf16(qv[0]), rne_bf16(qv[1]));
+        f.y = pack_hi(rne_bf16(qv[2]), rne_bf16(qv[3]));
+        f.z = pack_hi(rne_bf16(qv[4]), rne_bf16(qv[5]));
+        f.w = pack_hi(rne_bf16(qv[6]), rne_bf16(qv[7]));
+        qf[ks] = f;
+    }
+    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] from the fp32 query (a rolled loop: prologue code, kept off the
+    // register budget of the main loop); each lane half covers every other group of 8 channels
+    float qr[ATT_MAXREL];
+#pragma unroll
+    for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
+    if (nrel) {
+#pragma unroll 1
+        for (int d8 = half; d8 < (dk + 7) / 8; d8 += 2) {
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * d8 + j;
+                if (d < dk && qi < T) {
+                    const float qs = qb[(long long)d * T + qic] * p.scale;
+#pragma unroll
+                    for (int r = 0; r < ATT_MAXREL; ++r)
+                        if (r < nrel) qr[r] += qs * relk[r * dk + d];
+                }
+            }
+        }
+    }
+    float *QRw = QRs + wave * 32 * ATT_QRS;
+    float *Sww = Sws + wave * 32 * ATT_QRS;
+    for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
+    if (nrel) {
+#pragma unroll
+        for (int r = 0; r < ATT_MAXREL; ++r) {
+            const float tot = qr[r] + __shfl_xor(qr[r], 32);      // the two lane halves hold complementary d's
+            if (half == 0) QRw[l31 * ATT_QRS + r] = tot;
+        }
+    }
+
+    // ---- K / V tile staging ----
+    float4 kst[KCPT][8], vst[VCPT];
+    float mst = 1.f;
+    auto load_k = [&](int jt) __attribute__((always_inline)) {
+        const int j0 = jt * AKT;
+#pragma unroll
+        for (int i = 0; i < KCPT; ++i) {
+            const int c = tid + 256 * i;
+            const int kq = c % KQ, d8 = c / KQ;
+            const int jc = min(j0 + 4 * kq, T - 4);                  // T % 4 == 0: a quad is wholly inside or wholly outside
+#pragma unroll
+            for (int jd = 0; jd < 8; ++jd) {
+                const int d = min(8 * d8 + jd, dk - 1);
+                kst[i][jd] = *reinterpret_cast<const float4 *>(kb + (long long)d * T + jc);
+            }
+        }
+        if (tid < AKT) mst = maskb ? maskb[min(j0 + tid, T - 1)] : 1.f;
+    };
+    auto load_v = [&](int jt) __attribute__((always_inline)) {
+        const int j0 = jt * AKT;
+#pragma unroll
+        for (int i = 0; i < VCPT; ++i) {
+            const int c = tid + 256 * i;
+            const int kq = c % KQ, d = min(c / KQ, dk - 1);
+            const int jc = min(j0 + 4 * kq, T - 4);
+            vst[i] = *reinterpret_cast<const float4 *>(vb + (long long)d * T + jc);
+        }
+    };
+    auto store_k = [&](int jt, int buf) __attribute__((always_inline)) {
+        const int j0 = jt * AKT;
+        unsigned *Kb = Ks + buf * KBUF;
+#pragma unroll
+        for (int i = 0; i < KCPT; ++i) {
+            const int c = tid + 256 * i;
+            const int kq = c % KQ, d8 = c / KQ;
+            if (KCELLS % 256 == 0 || c < KCELLS) {
+                const bool okj = (j0 + 4 * kq < T);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[8];
+#pragma unroll
+                    for (int jd = 0; jd < 8; ++jd) {
+                        const float4 t4 = kst[i][jd];
+                        const float x = (e == 0) ? t4.x : (e == 1) ? t4.y : (e == 2) ? t4.z : t4.w;
+                        v[jd] = (okj && 8 * d8 + jd < dk) ? x : 0.f;
+                    }
+                    u32x4 f;
+                    f.x = pack_hi(rne_bf16(v[0]), rne_bf16(v[1]));
+                    f.y = pack_hi(rne_bf16(v[2]), rne_bf16(v[3]));
+                    f.z = pack_hi(rne_bf16(v[4]), rne_bf16(v[5]));
+                    f.w = pack_hi(rne_bf16(v[6]), rne_bf16(v[7]));
+                    *reinterpret_cast<u32x4 *>(Kb + (d8 * AKT + 4 * kq + e) * 4) = f;
+                }
+            }
+        }
+        if (tid < AKT) Ms[buf * AKT + tid] = (j0 + tid < T) ? mst : 1.f;
+    };
+    auto store_v = [&](int jt, int buf) __attribute__((always_inline)) {
+        const int j0 = jt * AKT;
+        unsigned *Vb = Vs + buf * VBUF;
+#pragma unroll
+        for (int i = 0; i < VCPT; ++i) {
+            const int c = tid + 256 * i;
+            const int kq = c % KQ, d = c / KQ;
+            const bool ok = (j0 + 4 * kq < T) && (d < dk);
+            const float4 t4 = vst[i];
+            const unsigned lo = ok ? pack_hi(rne_bf16(t4.x), rne_bf16(t4.y)) : 0u;
+            const unsigned hi = ok ? pack_hi(rne_bf16(t4.z), rne_bf16(t4.w)) : 0u;
+            // keys 4kq .. 4kq+3 of 16-group kq >> 2: quads (0, 1, 2, 3) of a group sit in slots (0, 2, 1, 3)
+            const int slot = ((kq & 1) << 1) | ((kq >> 1) & 1);
+            *reinterpret_cast<uint2 *>(Vb + d * AVP + (kq >> 2) * 8 + slot * 2) = make_uint2(lo, hi);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_half = 0.f;
+    const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
+
+    const int ntiles = (T + AKT - 1) / AKT;
+    load_k(0);
+    load_v(0);
+    store_k(0, 0);
+    store_v(0, 0);
+    __syncthreads();
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int j0 = jt * AKT;
+        const int buf = jt & 1;
+        const unsigned *Kb = Ks + buf * KBUF, *Vb = Vs + buf * VBUF;
+        const float *Mb = Ms + buf * AKT;
+        // the next tile's K is in flight under the S^T MFMAs and written once they have issued; its V is in flight under the
+        // softmax and the P V MFMAs: the fp32 staging registers of a tile (64 KB of K + 64 KB of V at 256 channels) are never all live
+        if (jt + 1 < ntiles) load_k(jt + 1);
+
+        // ---- S^T tiles: rows = keys 32 kt + acc_row(r), columns (lanes) = queries ----
+        f32x16 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(Kb + ((2 * ks + half) * AKT + 32 * kt + l31) * 4);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qf[ks]), s[kt], 0, 0, 0);
+            }
+        }
+        if (jt + 1 < ntiles) {
+            store_k(jt + 1, buf ^ 1);
+            load_v(jt + 1);
+        }
+        const bool near_diag = nrel && (j0 + AKT - 1 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int j = j0 + jj;
+                float sv = s[kt][r];
+                if (near_diag) {
+                    const int rel = j - qi;
+                    if (rel >= -p.ws && rel <= p.ws) sv += QRw[l31 * ATT_QRS + rel + p.ws];
+                }
+                if (mi * Mb[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
+                if (j >= T) sv = -INFINITY;                  // beyond the sequence: not part of the softmax
+                if (near_diag) {
+                    const int rel = j - qi;
+                    if (rel >= -p.ws && rel <= p.ws && j < T) Sww[l31 * ATT_QRS + rel + p.ws] = sv;
+                }
+                s[kt][r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float psum = 0.f;
+        u32x4 pf[2 * NKT];                                   // P^T fragments of the 16-key k-steps
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = __expf(s[kt][r] - m_new);             // exp(-inf) = 0 for excluded keys; the result is rounded to bf16 anyway
+                psum += pv[r];
+            }
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                u32x4 f;
+                f.x = pack_hi(rne_bf16(pv[8 * sh + 0]), rne_bf16(pv[8 * sh + 1]));
+                f.y = pack_hi(rne_bf16(pv[8 * sh + 2]), rne_bf16(pv[8 * sh + 3]));
+                f.z = pack_hi(rne_bf16(pv[8 * sh + 4]), rne_bf16(pv[8 * sh + 5]));
+                f.w = pack_hi(rne_bf16(pv[8 * sh + 6]), rne_bf16(pv[8 * sh + 7]));
+                pf[2 * kt + sh] = f;
+            }
+        }
+        l_half = l_half * alpha + psum;
+        m_run = m_new;
+        // the running maximum of a row settles after a few tiles: skip the rescale of the output accumulators (a read-multiply-write
+        // of DT * 16 registers per tile) whenever no query of the wave moved its maximum
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+
+        // ---- O^T += V P^T: k-step s4 sums over the keys 16 s4 + 8 (j >> 2) + 4 half + (j & 3), the order of the V rows ----
+#pragma unroll
+        for (int s4 = 0; s4 < 2 * NKT; ++s4) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(Vb + (t * 32 + l31) * AVP + s4 * 8 + half * 4);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pf[s4]), o[t], 0, 0, 0);
+            }
+        }
+        if (jt + 1 < ntiles) store_v(jt + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- finish: normalise, add the relative-value term (fp32), store ----
+    // (the loop's last barrier has retired every read of the K / V buffers: 2 * KBUF dwords >= 16 rows x 256 channels)
+    for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
+    __syncthreads();
+    const float l_tot = l_half + __shfl_xor(l_half, 32);
+    const float inv = 1.0f / l_tot;
+    float pw[ATT_MAXREL];
+#pragma unroll
+    for (int r = 0; r < ATT_MAXREL; ++r) pw[r] = (r < nrel) ? expf(Sww[l31 * ATT_QRS + r] - m_run) * inv : 0.f;
+    float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float val = o[t][r] * inv;
+            if (d < dk) {
+#pragma unroll
+                for (int rr = 0; rr < ATT_MAXREL; ++rr)
+                    if (rr < nrel) val += pw[rr] * RVs[rr * dk + d];
+                if (qi < T) ob[(long long)d * T + qi] = val;
+            }
+        }
+    }
+}
+
+bool attn_bf16_supported(const AttnParams &p) {
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    return p.dk <= 256 && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
+}
+
+template <int DT, int AKT>
+static int launch_bf16(const AttnParams &p, hipStream_t s) {
+    constexpr int DKR = DT * 32, AVP = AKT / 2 + 4;
+    const size_t lds = 4 * ((size_t)2 * (DKR / 8) * AKT * 4 + (size_t)2 * DKR * AVP + 2 * AKT + 2 * 4 * 32 * ATT_QRS);
+    auto kern = relattn_bf16_kernel<DT, AKT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) { set_error("vs_relattn_fwd (bf16): head dim %d needs %zu B of LDS", p.dk, lds); return VS_EUNSUPPORTED; }
+    dim3 grid((unsigned)ceil_div(p.T, 128), (unsigned)p.nh, (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("relattn_bf16_kernel<%d, %d>", DT, AKT);
+    return VS_OK;
+}
+
+int launch_attn_bf16(const AttnParams &p, hipStream_t s) {
+    const int DT = (int)ceil_div(p.dk, 32);
+    if (DT <= 2) return launch_bf16<2, 64>(p, s);
+    if (DT == 3) return launch_bf16<3, 64>(p, s);
+    if (DT == 4) return launch_bf16<4, 64>(p, s);
+    if (DT <= 6) return launch_bf16<6, 32>(p, s);
+    return launch_bf16<8, 32>(p, s);
+}
+
+}  // namespace vs

@@ -1098,7 +1098,7 @@ extern "C" {
 
 const char *vs_last_error(void) { return g_err; }
 const char *vs_last_kernel_name(void) { return g_last_kernel; }
-int vs_abi_version(void) { return 1; }
+int vs_abi_version(void) { return 2; }
 
 int vs_device_info(char *buf, size_t n) {
     int cnt = 0;

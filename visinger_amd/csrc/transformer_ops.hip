@@ -13,25 +13,13 @@
 // statistics are in-register reductions plus one cross-half exchange, and the probability tile is -- register for
 // register -- the B operand of the P.V product (k-index order chosen to match the accumulator layout): no LDS
 // round trip, no shuffles between the two GEMMs.
-#include "vs_internal.h"
+#include "attn_common.h"
+
+#include <cstdlib>
 
 namespace vs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int ATT_MAXREL = 16;   // 2*window+1 <= 16
-constexpr int ATT_QRS = 17;      // LDS stride of the per-query relative rows
-
-struct AttnParams {
-    const float *q, *k, *v;
-    long long bs;                 // batch stride of q/k/v (floats)
-    const float *rel_k, *rel_v;   // [nh_rel, 2ws+1, dk] or null
-    const float *mask;            // [B, T] or null
-    float *out;
-    long long out_bs;
-    int B, nh, dk, T, ws, nh_rel;
-    float scale;
-};
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -340,7 +328,7 @@ extern "C" {
 
 int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                    const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
-                   int k_channels, int64_t T, int window_size, int n_heads_rel, void *stream) {
+                   int k_channels, int64_t T, int window_size, int n_heads_rel, int math, void *stream) {
     VS_REQUIRE(q && k && v && out, "vs_relattn_fwd: NULL tensor");
     VS_REQUIRE(B > 0 && B <= 65535 && n_heads > 0 && k_channels > 0 && T > 0, "vs_relattn_fwd: bad dims");
     VS_REQUIRE(window_size < 0 || (rel_k && rel_v), "vs_relattn_fwd: window given but relative embeddings are NULL");
@@ -356,6 +344,10 @@ int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_b
     p.B = (int)B; p.nh = n_heads; p.dk = k_channels; p.T = (int)T; p.ws = window_size; p.nh_rel = n_heads_rel;
     p.scale = 1.0f / sqrtf((float)k_channels);
     hipStream_t s = as_stream(stream);
+    VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6, "vs_relattn_fwd: unknown arithmetic %d", math);
+    // VS_MATH_BF16: both GEMMs on the bf16 matrix instruction (attention_bf16.hip); any other arithmetic, and shapes that kernel does
+    // not take (T % 4 != 0, unaligned rows), run the exact-fp32 MFMA kernel below
+    if (math == VS_MATH_BF16 && attn_bf16_supported(p) && !getenv("VS_NO_BF16_ATTN")) return launch_attn_bf16(p, s);
     const int DT = (int)ceil_div(k_channels, 32);
     switch (DT) {
         case 1: return launch_attn<1, 4, false>(p, s);

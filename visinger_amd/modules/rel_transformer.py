@@ -143,7 +143,8 @@ class MultiHeadAttention(nn.Module):
             conv.run(src, in_act=ia, mask=m2, y_ptr=_off(qkv, j * C * T), y_bs=3 * C * T)
         rel_k = self.emb_rel_k if self.window_size is not None else None
         rel_v = self.emb_rel_v if self.window_size is not None else None
-        att = rel_attention(qkv, self.n_heads, rel_k, rel_v, m2, self.window_size)
+        # the attention core follows the arithmetic of the projections around it (bf16 GEMMs only under VS_MATH_BF16)
+        att = rel_attention(qkv, self.n_heads, rel_k, rel_v, m2, self.window_size, math=self.conv_q._op(bind=False).math)
         return self.conv_o.run(att)
 
 

@@ -218,8 +218,9 @@ def weightnorm_fold(v, g):
     return w
 
 
-def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=None, out=None):
-    """a6: attention core on a fused [B, 3C, T] q|k|v buffer -> [B, C, T]."""
+def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=None, out=None, math=L.MATH_F32):
+    """a6: attention core on a fused [B, 3C, T] q|k|v buffer -> [B, C, T].  math = L.MATH_BF16: both GEMMs on the bf16 matrix
+    instruction (the arithmetic of the q / k / v convs around it, BASELINE config 5); otherwise exact fp32."""
     lib = L.require_gpu()
     B, C3, T = qkv.shape
     C = C3 // 3
@@ -233,7 +234,7 @@ def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=N
                                L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
                                L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
                                C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
-                               L.stream_ptr()))
+                               int(math), L.stream_ptr()))
     if PROFILER.enabled:
         e1.record()      # algorithmic work: Q K^T and P V over the full [T, T] score matrix = 4 * T * T * k_channels per head
         PROFILER.records.append((lib.vs_last_kernel_name().decode(), 4.0 * B * C * T * T, 4.0 * B * 4 * C * T, e0, e1))

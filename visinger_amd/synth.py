@@ -6,14 +6,16 @@ import numpy as np
 import torch
 
 
-def bucket_by_length(lengths, max_frames_per_batch, max_items_per_batch=256):
+def bucket_by_length(lengths, max_frames_per_batch, max_items_per_batch=256, keys=None):
     """Sort by length (descending) and cut batches under a padded-frame budget (the reference's batch_by_size idea,
-    utils/commons/dataset_utils.py:181-191, without its dataset plumbing).  Returns lists of item indices."""
-    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    utils/commons/dataset_utils.py:181-191, without its dataset plumbing).  Returns lists of item indices.
+    keys (optional, one per item): items of different key never share a batch (batches are cut where the key changes)."""
+    order = sorted(range(len(lengths)), key=lambda i: ((keys[i] if keys is not None else 0), -int(lengths[i])))
     batches, cur = [], []
     for i in order:
         longest = int(lengths[cur[0]]) if cur else int(lengths[i])
-        if cur and (longest * (len(cur) + 1) > max_frames_per_batch or len(cur) >= max_items_per_batch):
+        if cur and (longest * (len(cur) + 1) > max_frames_per_batch or len(cur) >= max_items_per_batch or
+                    (keys is not None and keys[i] != keys[cur[0]])):
             batches.append(cur)
             cur = []
         cur.append(i)
@@ -53,18 +55,24 @@ def save_wav(wav, path, sr, norm=False):
 
 
 @torch.no_grad()
-def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None):
+def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None, equal_tokens=False):
     """Run VISinger.forward(infer=True) over length-bucketed batches.  Returns a list of float32 waveforms trimmed to
     each item's own length (frames * hop_size), in the input order.
 
-    Every waveform equals the item's one-at-a-time synthesis (the reference's test_step, tasks/visinger.py:244-263) given the same
-    noise: the prior, the flow and the attention are masked per item by the reference itself, and the HiFi-GAN generator -- which
-    the reference runs unmasked, on one utterance -- is run with the frame mask at every stage (Generator.forward x_mask) whenever
-    a batch holds items of different lengths, so that nothing leaks from the padding into an item's last frames."""
+    Against the item's one-at-a-time synthesis (the reference's test_step, tasks/visinger.py:244-263) on the same noise:
+      * the prior, the flow and the attention are masked per item by the reference itself;
+      * the HiFi-GAN generator -- which the reference runs unmasked, on one utterance -- is run with the frame mask at every stage
+        (Generator.forward x_mask) whenever a batch holds items of different lengths, so nothing leaks from the padding into an
+        item's last frames;
+      * the reference's TextEncoder views its positional-embedding table by the PADDED token count (encoder.py:52-54, a `seq_len =
+        hidden` mix-up restated literally): an item padded to a longer token sequence gets a different embedding than alone.
+        `equal_tokens=True` lets only items of equal token count share a batch -- then every waveform EQUALS its one-at-a-time
+        synthesis; the default batches by frames only and is exact for the items that define a batch's token length."""
     device = next(model.parameters()).device
     lengths = [int((np.asarray(it["mel2ph"]) > 0).sum()) for it in items]
     out = [None] * len(items)
-    for idx in bucket_by_length(lengths, max_frames_per_batch):
+    keys = [len(it["text_tokens"]) for it in items] if equal_tokens else None
+    for idx in bucket_by_length(lengths, max_frames_per_batch, keys=keys):
         batch = collate([items[i] for i in idx], device)
         B, T = batch["mel2ph"].shape
         noise = torch.randn((B, model.hidden_size, T), device=device, generator=generator) * noise_scale
