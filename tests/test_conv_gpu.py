@@ -326,9 +326,10 @@ def test_conv_engine_random_sweep(seed, monkeypatch):
 
 @pytest.mark.parametrize("C,k,d,T,B", [(32, 3, 1, 2048, 2), (32, 7, 3, 1500, 1), (32, 11, 5, 1024, 2), (64, 3, 5, 1000, 1),
                                         (64, 7, 1, 700, 2), (64, 11, 3, 516, 1), (32, 5, 1, 37, 1), (32, 3, 3, 4, 2), (64, 9, 1, 250, 1)])
-@pytest.mark.parametrize("math", [L.MATH_SPLIT6, L.MATH_F32])
+@pytest.mark.parametrize("math", [L.MATH_SPLIT6, L.MATH_F32, L.MATH_BF16])
 def test_resblock_pair_fused_launch(oracle, C, k, d, T, B, math):
-    """csrc/resblock_pair_split.hip (split-bf16 x6, the default) and csrc/resblock_pair.hip (fp32 MFMA): y = conv2(lrelu(conv1(lrelu(x)))) + x [+ acc] [* scale] in one launch vs the fp64 oracle; tiles
+    """csrc/resblock_pair_split.hip (split-bf16 x6, the default; plain bf16 operands for VS_MATH_BF16, at a bf16 tolerance: two
+    convs of C*k bf16 products each) and csrc/resblock_pair.hip (fp32 MFMA): y = conv2(lrelu(conv1(lrelu(x)))) + x [+ acc] [* scale] in one launch vs the fp64 oracle; tiles
     in the interior (vector epilogue), at both sequence ends, lengths below one tile and not a multiple of 4 (element-wise
     epilogue), every (k, dilation) of the MRF blocks."""
     from visinger_amd.ops import ConvOp, respair_forward, respair_supported
@@ -346,8 +347,11 @@ def test_resblock_pair_fused_launch(oracle, C, k, d, T, B, math):
     t = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w1, b1, dilation=d, padding=d * (k - 1) // 2)
     ref = oracle.conv1d(oracle.leaky_relu(t), w2, b2, padding=(k - 1) // 2) + x
     xd = dev(x)
+    tol = 2e-5 if math != L.MATH_BF16 else 3e-2
     y = respair_forward(op1, op2, xd, torch.empty_like(xd), res=xd)
-    close(y, ref)
+    close(y, ref, tol)
+    assert op1.kernel_instance().startswith("respair_kernel<" if math == L.MATH_F32 else "respair_split_kernel<")
+    assert op1.kernel_instance().endswith({L.MATH_F32: ">", L.MATH_SPLIT6: ", 6>", L.MATH_BF16: ", 1>"}[math])
     acc_t = dev(accb)
     respair_forward(op1, op2, xd, acc_t, res=xd, acc=acc_t, scale=1.0 / 3.0)       # in-place accumulate, MRF average
-    close(acc_t, (ref + accb) / 3.0)
+    close(acc_t, (ref + accb) / 3.0, tol)

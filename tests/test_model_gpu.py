@@ -237,6 +237,13 @@ def test_batched_synthesis_driver_matches_single_items(tiny):
                      noise=nz)["wav_out"][1, :T1 * hop].cpu().numpy()
     assert alone1.shape == both2[1].shape and np.abs(alone1 - both2[1]).max() <= 2e-6
     assert np.abs(unmasked - alone1).max() > 1e-5      # the leak the mask removes (conv_pre's bias + speaker condition in the padding)
+    # graph-replayed batches (synth.GraphedStep): first call captures each batch shape, the second replays; same waveforms
+    graphs = {}
+    for _ in range(2):
+        g = torch.Generator(device="cuda").manual_seed(0)
+        replayed = synth.synthesize(m, pair, hop, generator=g, equal_tokens=True, graphs=graphs)
+        assert all(np.array_equal(a_, b_) for a_, b_ in zip(replayed, both2))
+    assert len(graphs) == 1
     pcm = synth.to_int16(both[0])
     assert pcm.dtype == np.int16 and np.abs(pcm).max() == 32767
 

@@ -300,22 +300,28 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     __syncthreads();
     const float l_tot = l_half + __shfl_xor(l_half, 32);
     const float inv = 1.0f / l_tot;
-    float pw[ATT_MAXREL];
 #pragma unroll
-    for (int r = 0; r < ATT_MAXREL; ++r) pw[r] = (r < nrel) ? expf(Sww[l31 * ATT_QRS + r] - m_run) * inv : 0.f;
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= inv;
+    // sum_r p[i, i + r - ws] * rel_v[r]: the window index is the (rolled) outer loop so that every access to the output accumulators
+    // has a compile-time index (a runtime-indexed accumulator array lives in scratch memory)
+#pragma unroll 1
+    for (int rr = 0; rr < nrel; ++rr) {
+        const float w = expf(Sww[l31 * ATT_QRS + rr] - m_run) * inv;
+        const float *rv = RVs + rr * dk;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
+    }
     float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float val = o[t][r] * inv;
-            if (d < dk) {
-#pragma unroll
-                for (int rr = 0; rr < ATT_MAXREL; ++rr)
-                    if (rr < nrel) val += pw[rr] * RVs[rr * dk + d];
-                if (qi < T) ob[(long long)d * T + qi] = val;
-            }
+            if (d < dk && qi < T) ob[(long long)d * T + qi] = o[t][r];
         }
     }
 }

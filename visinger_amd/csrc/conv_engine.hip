@@ -1418,6 +1418,15 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // (6 tiles on a LONG launch -- the stride-3 stage of the hop-300 generator, 192 virtual rows: 64 x 512 blocks, three in M)
     if (h->MT >= 3) cfg = ((h->MT % 4) == 2) ? (((long long)p.N * p.B <= 65536) ? 3 : 1) : 0;
     else cfg = (h->MT == 2) ? 1 : 2;
+    // Short launches (single utterances, T_mel-sized tensors): a 128 x 256 tile grid of fewer workgroups than CUs leaves most of
+    // the chip idle while each workgroup runs its full K loop -- the launch lasts as long as ONE workgroup.  On the bf16-pipe
+    // engine take 64-row (then 32-row) tiles until the grid covers the CUs: the same kernel family, 2x / 4x the workgroups, each
+    // with half / a quarter of the MFMAs per wave (B=1, T_mel=1024 synthesis latency: DESIGN.md 4.2).
+    if (h->math && !getenv("VS_NO_SMALL_GRID")) {
+        const long long ncol = ceil_div(p.N, 256) * p.B;
+        if (cfg == 0 && ncol * ceil_div(h->MT, 4) < 256) cfg = 3;
+        if (cfg == 3 && ncol * ceil_div(h->MT, 2) < 256 && (long long)p.N * p.B <= 65536) cfg = 2;
+    }
     if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
     if (h->math) p.wp = h->ws.as<float>();
     auto launch = [&](const ConvParams &q) -> int {

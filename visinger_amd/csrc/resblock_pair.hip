@@ -329,9 +329,8 @@ int vs_respair_forward(vs_conv_t *c1, vs_conv_t *c2, const vs_conv_io_t *io, voi
     p.fast_epi = (io->T % 4 == 0) && al16(p.y) && (p.y_bs % 4 == 0) && (!p.res || (al16(p.res) && p.res_bs % 4 == 0)) &&
                  (!p.acc || (al16(p.acc) && p.acc_bs % 4 == 0));
     hipStream_t s = as_stream(stream);
-    if (c1->math == VS_MATH_SPLIT6 && c2->math == VS_MATH_SPLIT6) return vs_respair_split_launch(c1, c2, io, p.fast_epi, s);
     VS_REQUIRE(c1->math == c2->math, "vs_respair_forward: the two convs of a pair must use the same arithmetic");
-    VS_REQUIRE(c1->math == VS_MATH_F32, "vs_respair_forward: no fused pair in bf16 arithmetic");
+    if (c1->math != VS_MATH_F32) return vs_respair_split_launch(c1, c2, io, p.fast_epi, s);
     if (C == 32) { p.W1 = 512 + (p.K - 1) * p.d1; return launch_pair<1, 4>(p, s); }
     p.W1 = 256 + (p.K - 1) * p.d1;
     return launch_pair<2, 2>(p, s);

@@ -56,10 +56,13 @@ __device__ __forceinline__ void pstamp(const PairSplitParams &p, int slot) {
         p.stamps[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 64 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int NT_W, int WAVES_M, int WAVES_N>
+// TERMS = 6: split-bf16 x6 (three planes, fp32 class); TERMS = 1: operands rounded to bf16 (one plane) -- VS_MATH_BF16, where a
+// narrow conv is even further below the HBM ridge as its own launch.
+template <int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitParams p) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
-    constexpr int NPL = 3;
+    static_assert(TERMS == 6 || TERMS == 1, "split-bf16 x6 or plain bf16");
+    constexpr int NPL = (TERMS == 6) ? 3 : 1;
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int WT = BN + QHALO;                 // column pitch of the intermediate tile
     constexpr int CIT = (BN + 64 + 63) / 64;       // (K - 1) * d1 <= 64
@@ -173,7 +176,8 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[ta]), __builtin_bit_cast(bf16x8, bf[tb]),
                                                                  acc[j], 0, 0, 0);
             };
-            mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0);      // smallest terms first
+            if constexpr (TERMS == 6) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); }      // smallest terms first
+            mm(0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) bf[pl] = bn[pl];
@@ -322,12 +326,12 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     }
 }
 
-template <int NT_W, int WAVES_M, int WAVES_N>
+template <int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 static int launch_pair_split_cfg(PairSplitParams p, hipStream_t s) {
-    constexpr int BN = 32 * NT_W * WAVES_N, WT = BN + QHALO;
-    auto kern = respair_split_kernel<NT_W, WAVES_M, WAVES_N>;
+    constexpr int BN = 32 * NT_W * WAVES_N, WT = BN + QHALO, NPL = (TERMS == 6) ? 3 : 1;
+    auto kern = respair_split_kernel<NT_W, WAVES_M, WAVES_N, TERMS>;
     p.W1 = BN + (p.K - 1) * p.d1;
-    const size_t lds = std::max<size_t>({(size_t)2 * 3 * 2 * p.W1 * 16, (size_t)3 * (p.C / 8) * WT * 16,
+    const size_t lds = std::max<size_t>({(size_t)2 * NPL * 2 * p.W1 * 16, (size_t)NPL * (p.C / 8) * WT * 16,
                                          (size_t)4 * 8 * (32 * NT_W) * sizeof(float)});
     static bool attr_set = false;
     if (!attr_set) {
@@ -337,7 +341,7 @@ static int launch_pair_split_cfg(PairSplitParams p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, BN - p.PH), 1, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("respair_split_kernel<%d, %d, %d>", NT_W, WAVES_M, WAVES_N);
+    set_last_kernel("respair_split_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, TERMS);
     return VS_OK;
 }
 
@@ -347,7 +351,7 @@ using namespace vs;
 
 extern unsigned long long *g_stamp_buf;   // conv_engine.hip (vs_debug_set_stamp_buffer)
 
-// called by vs_respair_forward (resblock_pair.hip) when both convs run the split-bf16 x6 arithmetic
+// called by vs_respair_forward (resblock_pair.hip) when both convs run on the bf16 matrix pipe (both split-bf16 x6, or both bf16)
 int vs_respair_split_launch(const vs_conv *c1, const vs_conv *c2, const vs_conv_io_t *io, int fast_epi, hipStream_t s) {
     PairSplitParams p;
     memset(&p, 0, sizeof(p));
@@ -364,6 +368,10 @@ int vs_respair_split_launch(const vs_conv *c1, const vs_conv *c2, const vs_conv_
     p.PH = ((c1->k - 1) + 3) & ~3;
     p.fast_epi = fast_epi;
     p.stamps = g_stamp_buf;
-    if (C == 32) return launch_pair_split_cfg<2, 1, 4>(p, s);
-    return launch_pair_split_cfg<2, 2, 2>(p, s);
+    if (c1->math == VS_MATH_BF16) {
+        if (C == 32) return launch_pair_split_cfg<2, 1, 4, 1>(p, s);
+        return launch_pair_split_cfg<2, 2, 2, 1>(p, s);
+    }
+    if (C == 32) return launch_pair_split_cfg<2, 1, 4, 6>(p, s);
+    return launch_pair_split_cfg<2, 2, 2, 6>(p, s);
 }

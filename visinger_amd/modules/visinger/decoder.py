@@ -73,11 +73,9 @@ class Generator(nn.Module):
         _forward_only_guard(self)
         x = x.contiguous().float()
         B, _, T = x.shape
-        mask = None
-        if x_mask is not None:
-            mask = mask2d(x_mask, B, T)
-            if bool((mask == 1).all()):
-                mask = None                                     # nothing padded: the fused (unmasked) launches
+        # (the caller passes x_mask only for batches that really hold padding: no device-side check here, it would be a host
+        # synchronisation in the middle of a capturable step)
+        mask = mask2d(x_mask, B, T) if x_mask is not None else None
         cb = None
         if g is not None:
             cb = self.cond.run(g.contiguous().float())          # [B, C0, 1] -> per-item bias of conv_pre

@@ -363,11 +363,15 @@ def respair_supported(op1, op2, profitable_only=False):
     the separate F(2,3) launches do 30 % less matrix work than the fused direct form."""
     if os.environ.get("VS_NO_RESPAIR") or not op1.lib.vs_respair_supported(op1.h, op2.h):
         return False
-    if op1.math != op2.math or op1.math == L.MATH_BF16:
+    if op1.math != op2.math:
         return False
     if not profitable_only or os.environ.get("VS_RESPAIR_FORCE"):
         return True
     C, k, d = op1.c_in, op1.k, op1.dil
+    if op1.math == L.MATH_BF16:
+        # plain bf16 operands: a sixth of the matrix work of the split engine on the same tensor passes -- every 32- / 64-channel
+        # conv is far below the HBM ridge as its own launch, the fused pair moves 3 tensor passes instead of 6
+        return True
     if op1.math == L.MATH_SPLIT6:
         # csrc/resblock_pair_split.hip against two launches of the split engine (tools/pair_bench.py, B=32 production shapes):
         # 32 channels x1.46-1.61 (k=3), x1.25 (k=7), x1.13 (k=11); 64 channels x1.22 (k=3), a tie at k=7, x0.91 at k=11 (its

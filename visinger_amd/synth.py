@@ -54,8 +54,41 @@ def save_wav(wav, path, sr, norm=False):
     wavfile.write(path[:-4] + ".wav", sr, to_int16(wav, norm=norm))
 
 
+class GraphedStep:
+    """One synthesis step (VISinger.forward(infer=True)) of a FIXED shape captured into a HIP graph and replayed: what a serving
+    loop with recurring batch shapes does.  Every launch of the step goes to torch's current stream through the C ABI, nothing
+    allocates with hipMalloc or synchronises with the host after the warm-up, so the ~700 launches of a step replay as one graph
+    (tests/test_model_gpu.py::test_synthesis_step_is_graph_capturable).  Inputs are copied into the graph's static buffers."""
+
+    def __init__(self, model, batch, noise, mask_decoder):
+        self.static = {k: v.clone() for k, v in batch.items()}
+        self.noise = noise.clone()
+
+        def run():
+            b = self.static
+            return model(b["text_tokens"], b["pitch_tokens"], b["dur_tokens"], b["mel2ph"], spk_id=b["spk_id"], infer=True,
+                         noise=self.noise, mask_decoder=mask_decoder)["wav_out"]
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up off the capture: packs weights, sizes every workspace
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = run()
+
+    def __call__(self, batch, noise):
+        for k, v in batch.items():
+            self.static[k].copy_(v)
+        self.noise.copy_(noise)
+        self.graph.replay()
+        return self.out
+
+
 @torch.no_grad()
-def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None, equal_tokens=False):
+def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None, equal_tokens=False,
+               graphs=None):
     """Run VISinger.forward(infer=True) over length-bucketed batches.  Returns a list of float32 waveforms trimmed to
     each item's own length (frames * hop_size), in the input order.
 
@@ -67,7 +100,11 @@ def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1
       * the reference's TextEncoder views its positional-embedding table by the PADDED token count (encoder.py:52-54, a `seq_len =
         hidden` mix-up restated literally): an item padded to a longer token sequence gets a different embedding than alone.
         `equal_tokens=True` lets only items of equal token count share a batch -- then every waveform EQUALS its one-at-a-time
-        synthesis; the default batches by frames only and is exact for the items that define a batch's token length."""
+        synthesis; the default batches by frames only and is exact for the items that define a batch's token length.
+
+    graphs: a dict owned by the caller; when given, each batch shape (B, T_tokens, T_frames, ragged) is captured into a HIP graph
+    on first use (GraphedStep) and replayed afterwards -- the launch chain of a small batch (B=1: ~700 dependent launches) then
+    costs one graph launch instead of ~700 host-side launches."""
     device = next(model.parameters()).device
     lengths = [int((np.asarray(it["mel2ph"]) > 0).sum()) for it in items]
     out = [None] * len(items)
@@ -76,9 +113,15 @@ def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1
         batch = collate([items[i] for i in idx], device)
         B, T = batch["mel2ph"].shape
         noise = torch.randn((B, model.hidden_size, T), device=device, generator=generator) * noise_scale
-        wav = model(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"],
-                    spk_id=batch["spk_id"], infer=True, noise=noise,
-                    mask_decoder=len({lengths[i] for i in idx}) > 1)["wav_out"].float().cpu().numpy()
+        ragged = len({lengths[i] for i in idx}) > 1
+        if graphs is not None:
+            key = (B, batch["text_tokens"].shape[1], T, ragged)
+            if key not in graphs:
+                graphs[key] = GraphedStep(model, batch, noise, ragged)
+            wav = graphs[key](batch, noise).float().cpu().numpy()
+        else:
+            wav = model(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"],
+                        spk_id=batch["spk_id"], infer=True, noise=noise, mask_decoder=ragged)["wav_out"].float().cpu().numpy()
         for b, i in enumerate(idx):
             out[i] = wav[b, :lengths[i] * hop_size].copy()
     return out
