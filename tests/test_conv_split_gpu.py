@@ -150,3 +150,62 @@ def test_bf16_attention_matches_fp32_kernel(dk, nh, T, ws, share):
         a = rel_attention(q3, nh, rel_k, rel_v, m3, ws, math=L.MATH_BF16)
         assert _lib.lib().vs_last_kernel_name().decode().startswith("relattn_kernel<")
         assert torch.equal(a, rel_attention(q3, nh, rel_k, rel_v, m3, ws, math=L.MATH_F32))
+
+
+@pytest.mark.parametrize("Cin,Cout,k,d,T,B", [(128, 128, 3, 1, 1024, 2), (128, 128, 3, 3, 700, 1), (128, 128, 3, 5, 516, 2), (256, 256, 11, 1, 512, 1),
+                                              (128, 128, 11, 3, 1000, 2), (128, 128, 11, 5, 2048, 1), (256, 256, 7, 1, 300, 2), (128, 128, 7, 3, 640, 1),
+                                              (128, 128, 7, 5, 900, 1), (192, 768, 9, 1, 333, 2), (200, 128, 3, 1, 130, 1), (64, 256, 11, 1, 37, 3),
+                                              (128, 128, 3, 1, 4, 2), (136, 384, 9, 1, 260, 1)])
+def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
+    """csrc/conv_wsplit.hip: minimal filtering F(2,3) on the split-bf16 x6 arithmetic (4 products of 6 cross terms per output pair
+    and tap group instead of 6) against the fp64 oracle, with every fused option of the LINEAR epilogue it serves -- residual,
+    accumulate + scale (the MRF average), leaky-relu / mask on the input, ReLU and mask on the output, per-item conditioning bias --
+    interior tiles, both sequence ends, lengths below one tile and not a multiple of 4 (element-wise epilogue), channel counts that
+    are not a multiple of the 16-channel chunk; and next to the direct split kernel on the same data (decoder.py:72-87 resblock
+    convs, rel_transformer.py:332-333 FFN k = 9)."""
+    from visinger_amd.ops import ConvOp
+    monkeypatch.setenv("VS_WSPLIT_FORCE", "1")            # k = 7 too (zero-padded last group)
+    r = np.random.default_rng(Cin * 13 + Cout + k * 7 + d + T)
+    x = r.standard_normal((B, Cin, T)).astype(np.float32)
+    v = r.standard_normal((Cout, Cin, k)).astype(np.float32)
+    g = (0.5 + r.random((Cout, 1, 1))).astype(np.float32)
+    bias = r.standard_normal(Cout).astype(np.float32)
+    res = r.standard_normal((B, Cout, T)).astype(np.float32)
+    accb = r.standard_normal((B, Cout, T)).astype(np.float32)
+    cond = r.standard_normal((B, Cout)).astype(np.float32)
+    mask = np.ones((B, T), np.float32)
+    mask[-1, (2 * T) // 3:] = 0
+    w = oracle.weight_norm(v, g) / np.sqrt(Cin * k)
+    pad = d * (k - 1) // 2
+    op = ConvOp(L.CONV1D, Cin, Cout, k, d, pad)
+    op.set_weights(dev(v / np.sqrt(Cin * k)), dev(g), dev(bias))
+    xl = oracle.leaky_relu(x.astype(np.float64))
+
+    def close(y, ref, tol=2e-5):
+        got = y.detach().cpu().double().numpy()
+        assert np.isfinite(got).all()
+        err = np.abs(got - ref) / (1.0 + np.abs(ref))
+        assert err.max() <= tol, f"max scaled err {err.max():.3e}"
+
+    conv = oracle.conv1d(xl, w, bias, dilation=d, padding=pad)
+    y = op.forward(dev(x), in_act=L.IN_LRELU)
+    assert op.kernel_instance() == f"conv_wsplit_kernel<{d}, {-(-k // 3)}>", op.kernel_instance()
+    close(y, conv)
+    close(op.forward(dev(x), in_act=L.IN_LRELU, res=dev(res)), conv + res)                                   # inner resblock conv
+    acc_t = dev(accb)
+    op.forward(dev(x), in_act=L.IN_LRELU, res=dev(res), acc=acc_t, y=acc_t, scale=1.0 / 3.0)                   # last conv of a block
+    close(acc_t, (conv + res + accb) / 3.0)
+    m3 = mask[:, None, :]
+    convm = oracle.conv1d(x.astype(np.float64) * m3, w, bias, dilation=d, padding=pad)
+    close(op.forward(dev(x), in_act=L.IN_MASK, mask=dev(mask), out_act=L.OUT_RELU), np.maximum(convm, 0.0))   # FFN conv_1
+    convlm = oracle.conv1d(xl * m3, w, bias, dilation=d, padding=pad)
+    close(op.forward(dev(x), in_act=L.IN_LRELU_MASK, mask=dev(mask), out_mask=True, bias_b=dev(cond)), (convlm + cond[:, :, None]) * m3)
+    # same arithmetic class as the direct split kernel on the same data (not bit-identical: different summation order)
+    monkeypatch.setenv("VS_NO_WSPLIT", "1")
+    yd = op.forward(dev(x), in_act=L.IN_LRELU)
+    assert op.kernel_instance().startswith("conv_split_kernel<")
+    ref_rms = float(np.sqrt((conv ** 2).mean()))
+    e_w = float(np.sqrt(((y.cpu().double().numpy() - conv) ** 2).mean())) / ref_rms
+    e_d = float(np.sqrt(((yd.cpu().double().numpy() - conv) ** 2).mean())) / ref_rms
+    print(f"wsplit {Cin}->{Cout} k{k} d{d} T{T}: rms err F(2,3)-split {e_w:.2e}, direct split {e_d:.2e}")
+    assert e_w <= 2.5 * e_d + 1e-8 and e_w <= 3e-6

@@ -1175,6 +1175,8 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
         h->wino_groups = (int)ceil_div(k, 3);
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
+    // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
+    h->wsplit = h->wino_groups > 0 && (h->MT % 4) == 0 && flags == 0 && wsplit_instance(dil, h->wino_groups);
     // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
     // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
     // VS_CONV_MATH=0 / 1 / 6: process-wide A/B switch for handles created from here on.
@@ -1201,6 +1203,9 @@ int vs_conv_set_math(vs_conv_t *h, int math, void *stream) {
     if (h->math == math) return VS_OK;
     h->math = math;
     if (math && h->weights_set) VS_TRY(pack_split_planes(h, as_stream(stream)));
+    // (the F(2,3) transform of the split engine is packed from the caller's weights in vs_conv_set_weights only: after a change of
+    // arithmetic the direct split kernel serves the handle until its weights are set again)
+    if (math != VS_MATH_SPLIT6) h->wsplit_packed = false;
     return VS_OK;
 }
 
@@ -1258,6 +1263,12 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     }
     VS_CHECK_HIP(hipGetLastError());
     if (h->math) VS_TRY(pack_split_planes(h, s));
+    h->wsplit_packed = false;
+    if (h->wsplit && h->math == VS_MATH_SPLIT6 && !getenv("VS_NO_WSPLIT")) {
+        VS_TRY(h->wsw.reserve(wsplit_bytes(h->MT_alloc, h->nchunks, h->wino_groups)));
+        VS_TRY(pack_wsplit(w, scale, h->wsw.p, h->c_in, h->c_out, h->k, h->MT_alloc, h->nchunks, h->wino_groups, s));
+        h->wsplit_packed = true;
+    }
     h->weights_set = true;
     return VS_OK;
 }
@@ -1410,6 +1421,16 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         if (h->dil == 1) return launch_wino_dil<1>(q, h->MT, span_w, spec, s);
         if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, spec, s);
         return launch_wino_dil<5>(q, h->MT, span_w, spec, s);
+    }
+    // F(2,3) on the split-bf16 x6 arithmetic (conv_wsplit.hip): 4/6 (k = 3, 9) and 16/22 (k = 11) of the direct engine's matrix work;
+    // k = 7 (12/14 with the zero-padded last group) only where it measured faster.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B switches.
+    if (h->math == VS_MATH_SPLIT6 && h->wsplit_packed && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
+        (h->k != 7 || getenv("VS_WSPLIT_FORCE"))) {
+        ConvParams q = p;
+        q.wp = h->wsw.as<float>();
+        q.KT = h->wino_groups;
+        q.lo = -h->pad;
+        return launch_wsplit(q, h->dil, h->wino_groups, s);
     }
     // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,
     // coupling `pre` and last res/skip convs) AND the launch is short (T_mel-sized): there 64 x 256 blocks waste no MFMA

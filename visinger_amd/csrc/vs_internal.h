@@ -86,6 +86,9 @@ struct vs_conv {
     bool has_bias = false;
     int math = 0;                              // 0: fp32 MFMA / F(2,3); 6: split-bf16 x6 (fp32 class); 1: bf16 (conv_split.hip)
     vs::DevBuf ws;                             // bf16 plane fragments of the split engine, when math != 0
+    bool wsplit = false;                       // eligible for conv_wsplit_kernel (F(2,3) on the split-bf16 x6 arithmetic)
+    bool wsplit_packed = false;                // wsw holds the transformed weights of the current version
+    vs::DevBuf wsw;                            // Us[m_tile][chunk][group][xi][plane][64][8 bf16] (conv_wsplit.hip)
 };
 
 
