@@ -168,17 +168,18 @@ def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
     r = np.random.default_rng(Cin * 13 + Cout + k * 7 + d + T)
     x = r.standard_normal((B, Cin, T)).astype(np.float32)
     v = r.standard_normal((Cout, Cin, k)).astype(np.float32)
-    g = (0.5 + r.random((Cout, 1, 1))).astype(np.float32)
+    g = ((0.5 + r.random((Cout, 1, 1))) * np.sqrt(1.0 / (Cin * k)) * np.sqrt(Cin * k)).astype(np.float32)    # row norms ~ 0.5 .. 1.5
+    g = (g / np.sqrt(Cin * k) * np.linalg.norm(v.reshape(Cout, -1), axis=1).reshape(Cout, 1, 1)).astype(np.float32)   # unit-variance outputs
     bias = r.standard_normal(Cout).astype(np.float32)
     res = r.standard_normal((B, Cout, T)).astype(np.float32)
     accb = r.standard_normal((B, Cout, T)).astype(np.float32)
     cond = r.standard_normal((B, Cout)).astype(np.float32)
     mask = np.ones((B, T), np.float32)
     mask[-1, (2 * T) // 3:] = 0
-    w = oracle.weight_norm(v, g) / np.sqrt(Cin * k)
+    w = oracle.weight_norm(v, g)
     pad = d * (k - 1) // 2
     op = ConvOp(L.CONV1D, Cin, Cout, k, d, pad)
-    op.set_weights(dev(v / np.sqrt(Cin * k)), dev(g), dev(bias))
+    op.set_weights(dev(v), dev(g), dev(bias))
     xl = oracle.leaky_relu(x.astype(np.float64))
 
     def close(y, ref, tol=2e-5):

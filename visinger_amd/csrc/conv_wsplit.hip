@@ -21,7 +21,7 @@
 //     2d, are combined and split -- no barrier inside the transform;
 //   * a wave owns 32 rows x 64 pair columns x 4 xi = 8 accumulator tiles (128 registers), so a weight fragment feeds two column
 //     tiles only: 3 x 16 B per 12 MFMAs from L2, four times the direct engine's rate -- requested three sub-steps ahead through a
-//     4-slot register ring;
+//     4-slot register ring (inline asm, hand-counted vmcnt);
 //   * one sub-step = (chunk, group, xi): 2 column tiles x 6 cross products; the body of a chunk is straight-line code (G is a
 //     template argument).
 // Epilogue: the output transform in registers, then the LDS-transposed vector epilogue of conv_wino_kernel (pairs interleaved on
@@ -245,60 +245,92 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     // sub-step ss = (chunk * G + g) * 4 + xi: three 16-byte weight fragments (planes h, m, l of U_xi), 2 column tiles x 6 MFMAs.
     // Fragments are requested RING - 1 = 3 sub-steps ahead; 4 G sub-steps per chunk are a multiple of the ring period, so the
     // body of a chunk is straight-line code with compile-time ring slots.
+    //
+    // The weight loads are inline asm with HAND-COUNTED vmcnt waits (as in conv_split_kernel: left to hipcc the wait in front of a
+    // sub-step's first MFMA is vmcnt(0) or vmcnt(1), i.e. it also waits for the fragments requested a few instructions earlier for
+    // sub-step ss + 3 -- one exposed L2 round trip per sub-step).  vmcnt counts vector-memory operations in issue order, so "the
+    // fragments of THIS sub-step have landed" = at most (everything issued after them) outstanding: the three younger requests (9
+    // loads; the request is unconditional, clamped to the last sub-step, so the count is a constant) plus, in the first four
+    // sub-steps of a chunk, the activation loads of chunk + 2, which are issued right AFTER the request of sub-step 0 so that they
+    // stay younger than the fragments of sub-steps 0 .. 3 (csrc/build.py fails the build if this kernel uses scratch: a spill
+    // would be a vector-memory instruction behind the count's back).
     constexpr int SPC = 4 * G;                                   // sub-steps per chunk
     const int nss = p.nchunks * SPC;
     const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.wp) + (long long)mt0 * nss * (3 * 64) + lane;
     u32x4 ar[4][3];
     auto load_a = [&](u32x4 (&dst)[3], int ss) __attribute__((always_inline)) {
-        const u32x4 *src = wbase + (long long)ss * (3 * 64);
-        dst[0] = src[0];
-        dst[1] = src[64];
-        dst[2] = src[128];
+        const u32x4 *src = wbase + (long long)min(ss, nss - 1) * (3 * 64);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst[0]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"(dst[1]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=&v"(dst[2]) : "v"(src) : "memory");
     };
-    if (nss > 0) load_a(ar[0], 0);
-    if (nss > 1) load_a(ar[1], 1);
-    if (nss > 2) load_a(ar[2], 2);
+    const int NY = ((in_act >= VS_IN_MASK) ? 5 : 4) * CIT;       // activation (+ mask) loads of one stage_load
+    auto wait_a = [&](u32x4 (&a)[3], bool staged) __attribute__((always_inline)) {
+        if (staged) {
+            if (NY == 4 * CIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + 4 * CIT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + 5 * CIT) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(a[pl]));
+    };
+    load_a(ar[0], 0);
+    load_a(ar[1], 1);
+    load_a(ar[2], 2);
 
     stamp(p, 0);
     stage_load(0);
-    stage_store(0);
-    if (p.nchunks > 1) stage_load(1);
+    stage_store(0);                 // (hipcc waits vmcnt(0) for the staged registers: covers the three requests above as well)
     __syncthreads();
     stamp(p, 1);
 
+    // B fragments of (sub-step u, tile j): V0 = A[n], V1 = P[n], V2 = Q[n], V3 = A[n + d] with n = t(c) + 3 g d
+    auto read_b = [&](u32x4 (&bf)[3], int u, int j) __attribute__((always_inline)) {
+        const int g = u >> 2, xi = u & 3;
+        const int arr = (xi == 1) ? 1 : (xi == 2) ? 2 : 0;
+        const int shift = 3 * g * DIL + ((xi == 3) ? DIL : 0);
+        const unsigned *xs = Vb + arr * ARSZ + (lhalf * W + posr[j] + shift) * 4;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ);
+    };
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const bool stage_next = chunk + 1 < p.nchunks;
+        u32x4 b0[3], b1[3];
+        read_b(b0, 0, 0);
 #pragma unroll
         for (int u = 0; u < SPC; ++u) {
-            const int g = u >> 2, xi = u & 3;
+            const int xi = u & 3;
             const int ss = chunk * SPC + u;
-            if (ss + 3 < nss) load_a(ar[(u + 3) & 3], ss + 3);
-            // V0 = A[n], V1 = P[n], V2 = Q[n], V3 = A[n + d] with n = t(c) + 3 g d
-            const int arr = (xi == 1) ? 1 : (xi == 2) ? 2 : 0;
-            const int shift = 3 * g * DIL + ((xi == 3) ? DIL : 0);
-            const unsigned *xs0 = Vb + arr * ARSZ + (lhalf * W + posr[0] + shift) * 4;
-            const unsigned *xs1 = Vb + arr * ARSZ + (lhalf * W + posr[1] + shift) * 4;
-            u32x4 b0[3], b1[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b0[pl] = *reinterpret_cast<const u32x4 *>(xs0 + pl * PLSZ);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b1[pl] = *reinterpret_cast<const u32x4 *>(xs1 + pl * PLSZ);
+            load_a(ar[(u + 3) & 3], ss + 3);
+            if (u == 0 && stage_next) stage_load(chunk + 1);          // (registers free: chunk's own data went to LDS before the barrier)
+            read_b(b1, u, 1);
+            wait_a(ar[u & 3], stage_next && u < 4);
             const u32x4(&a)[3] = ar[u & 3];
             auto mm = [&](f32x16 &c, const u32x4(&bf)[3], int ta, int tb) __attribute__((always_inline)) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ta]), __builtin_bit_cast(bf16x8, bf[tb]), c, 0, 0, 0);
             };
+            __builtin_amdgcn_sched_barrier(0);
             // smallest terms first
             mm(acc[xi][0], b0, 1, 1); mm(acc[xi][0], b0, 2, 0); mm(acc[xi][0], b0, 0, 2);
             mm(acc[xi][0], b0, 1, 0); mm(acc[xi][0], b0, 0, 1); mm(acc[xi][0], b0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u + 1 < SPC) read_b(b0, u + 1, 0);                    // the next sub-step's first tile, under this one's second
+            __builtin_amdgcn_sched_barrier(0);
             mm(acc[xi][1], b1, 1, 1); mm(acc[xi][1], b1, 2, 0); mm(acc[xi][1], b1, 0, 2);
             mm(acc[xi][1], b1, 1, 0); mm(acc[xi][1], b1, 0, 1); mm(acc[xi][1], b1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (chunk == 1) stamp(p, 8);
         __syncthreads();                                  // every wave is done with the transformed arrays of this chunk
-        if (chunk + 1 < p.nchunks) {
+        if (stage_next) {
             stage_store(chunk + 1);
-            if (chunk + 2 < p.nchunks) stage_load(chunk + 2);
+            if (chunk == 1) stamp(p, 9);
             __syncthreads();
+            if (chunk == 1) stamp(p, 10);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of the asm loads may be in flight past here
 
     stamp(p, 2);
     // ------------------------------------------------------------------------------------------------- epilogue
