@@ -1176,7 +1176,8 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
     // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
-    h->wsplit = h->wino_groups > 0 && (h->MT % 4) == 0 && flags == 0 && wsplit_instance(dil, h->wino_groups);
+    h->wsplit = h->wino_groups > 0 && (h->MT % 4) == 0 && flags == 0 && wsplit_instance(dil, h->wino_groups) &&
+                (k >= 9 || getenv("VS_WSPLIT_FORCE"));      // (where it pays: see vs_conv_forward)
     // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
     // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
     // VS_CONV_MATH=0 / 1 / 6: process-wide A/B switch for handles created from here on.
@@ -1422,10 +1423,13 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, spec, s);
         return launch_wino_dil<5>(q, h->MT, span_w, spec, s);
     }
-    // F(2,3) on the split-bf16 x6 arithmetic (conv_wsplit.hip): 4/6 (k = 3, 9) and 16/22 (k = 11) of the direct engine's matrix work;
-    // k = 7 (12/14 with the zero-padded last group) only where it measured faster.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B switches.
+    // F(2,3) on the split-bf16 x6 arithmetic (conv_wsplit.hip) where it measured faster than the direct split kernel
+    // (tools/wsplit_bench.py, B=32 production shapes): k = 11 (16/22 of the matrix work) x1.06 .. x1.20, FFN k = 9 (12/18) x1.27.
+    // Its three transformed arrays cost 4x the staging work of the direct kernel per 16-channel chunk (tools/wsplit_stamps.py:
+    // 2.0 us of staging against 1.5 us of MFMAs at k = 3, 3.2 against 7.5 at k = 11), so k = 3 (4/6, x0.86 .. x0.98) and k = 7
+    // (12/14 with the zero-padded last group, x0.90 .. x1.02) stay on the direct kernel.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B.
     if (h->math == VS_MATH_SPLIT6 && h->wsplit_packed && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
-        (h->k != 7 || getenv("VS_WSPLIT_FORCE"))) {
+        (ceil_div(p.N, 120) * p.B * (h->MT / 4) >= 256 || getenv("VS_WSPLIT_FORCE"))) {      // (short launches: the small direct tiles)
         ConvParams q = p;
         q.wp = h->wsw.as<float>();
         q.KT = h->wino_groups;
