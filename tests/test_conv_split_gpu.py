@@ -210,3 +210,51 @@ def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
     e_d = float(np.sqrt(((yd.cpu().double().numpy() - conv) ** 2).mean())) / ref_rms
     print(f"wsplit {Cin}->{Cout} k{k} d{d} T{T}: rms err F(2,3)-split {e_w:.2e}, direct split {e_d:.2e}")
     assert e_w <= 2.5 * e_d + 1e-8 and e_w <= 3e-6
+
+
+@pytest.mark.parametrize("dk,nh,T,ws,share", [(96, 2, 1024, 4, True), (64, 2, 260, 4, False), (128, 1, 516, None, True), (32, 4, 64, 4, True),
+                                              (96, 2, 36, 4, True), (80, 3, 132, 7, False)])
+def test_split6_attention_is_fp32_class(oracle, dk, nh, T, ws, share):
+    """vs_relattn_fwd with math = VS_MATH_SPLIT6 (the default arithmetic of the path; csrc/attention_bf16.hip with TERMS = 6: q / sqrt(dk),
+    k, v and the probabilities split exactly into three bf16 planes, six cross products per product) against the exact-fp32 MFMA
+    kernel AND the fp64 oracle (rel_transformer.py:148-179): fp32-class agreement -- the same bar the fp32 kernel is held to."""
+    from visinger_amd.ops import rel_attention
+    from visinger_amd import _lib
+    g = torch.Generator().manual_seed(dk * 11 + T)
+    B, C = 3, dk * nh
+    qkv = torch.randn(B, 3 * C, T, generator=g)
+    nrel = 0 if ws is None else 2 * ws + 1
+    rel_k = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5) if nrel else None
+    rel_v = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5) if nrel else None
+    lens = torch.tensor([T, max(1, (2 * T) // 3), 0])
+    mask = (torch.arange(T)[None] < lens[:, None]).float()
+    cu = lambda t: None if t is None else t.cuda()
+    ref32 = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_F32)
+    got = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_SPLIT6)
+    assert _lib.lib().vs_last_kernel_name().decode().startswith("relattn_bf16_kernel<") and _lib.lib().vs_last_kernel_name().decode().endswith(", 6>")
+    assert float((got - ref32).abs().max()) <= 2e-5
+    # fp64 oracle of the same attention core (masked rows attend uniformly: -1e4 fill)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].double().view(B, nh, dk, T).transpose(2, 3) for i in range(3))
+    sc = (q / dk ** 0.5) @ k.transpose(-1, -2)
+    idx = torch.arange(T)
+    rel = idx[None, :] - idx[:, None]
+    if nrel:
+        rk = rel_k.double().expand(nh, nrel, dk) if share else rel_k.double()
+        rv = rel_v.double().expand(nh, nrel, dk) if share else rel_v.double()
+        qr = (q / dk ** 0.5) @ rk.transpose(-1, -2)[None]                        # [B, nh, T, nrel]
+        band = rel.abs() <= ws
+        sc = sc + torch.gather(qr, 3, (rel + ws).clamp(0, 2 * ws)[None, None].expand(B, nh, T, T)) * band
+    am = mask.double()[:, None, :, None] * mask.double()[:, None, None, :]
+    sc = sc.masked_fill(am == 0, -1e4)
+    pr = torch.softmax(sc, -1)
+    out = pr @ v
+    if nrel:
+        cols = idx[:, None] + torch.arange(-ws, ws + 1)[None, :]
+        ok = (cols >= 0) & (cols < T)
+        pw = torch.gather(pr, 3, cols.clamp(0, T - 1)[None, None].expand(B, nh, T, nrel)) * ok
+        out = out + pw @ rv[None]
+    ref64 = out.transpose(2, 3).reshape(B, C, T)
+    e6 = float((got.cpu().double() - ref64).abs().max())
+    e32 = float((ref32.cpu().double() - ref64).abs().max())
+    print(f"attention dk={dk} T={T}: max err vs fp64 split6 {e6:.2e}, fp32 MFMA {e32:.2e}")
+    assert e6 <= 2e-5 and e6 <= 3.0 * e32 + 2e-6

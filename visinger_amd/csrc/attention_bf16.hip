@@ -22,19 +22,30 @@ namespace vs {
 
 // AKT = keys per tile: 64 for heads of up to 128 channels (two S^T accumulator tiles per wave), 32 for wider heads (the fp32 staging
 // registers of a tile scale with DT * AKT: at 256 channels a 64-key tile does not fit next to 128 output accumulators).
-template <int DT, int AKT>
+// TERMS = 1: bf16 operands (VS_MATH_BF16).  TERMS = 6: the split-bf16 x6 arithmetic of conv_split.hip -- q / sqrt(dk), k, v and the
+// probabilities split EXACTLY into three bf16 planes, six cross products per product: fp32-class scores and outputs at 16/6 of the
+// fp32 matrix rate (VS_MATH_SPLIT6, the default arithmetic of the path); three times the LDS per tile, so 32-key tiles, ONE K / V
+// buffer (two barriers per tile) and two workgroups per CU that overlap each other; heads of up to 128 channels.
+template <int DT, int AKT, int TERMS>
 __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(const AttnParams p) {
+    static_assert(TERMS == 1 || TERMS == 6, "plain bf16 or split-bf16 x6");
+    constexpr int NPL = (TERMS == 6) ? 3 : 1;
+    constexpr int NBUF = (TERMS == 6) ? 1 : 2;
     constexpr int DKR = DT * 32;                     // padded head dim
     constexpr int NKS = DKR / 16;                    // k-steps of S^T = K^T Q
     constexpr int NKT = AKT / 32;                    // S^T accumulator tiles per key tile
     constexpr int KQ = AKT / 4;                      // key quads per tile
+    constexpr int KW = (TERMS == 6) ? 2 : 4;         // keys per K staging cell (work per thread x planes: finer cells for the split)
+    constexpr int KQW = AKT / KW;                    // K cells along the keys
     constexpr int AVP = AKT / 2 + 4;                 // V row pitch in dwords (AKT keys x 2 B + 16 B: conflict-free ds_read_b128 down a column)
-    constexpr int KCELLS = (DKR / 8) * KQ;           // (d8, key quad) cells of the K tile, 8 float4 loads each
+    constexpr int KCELLS = (DKR / 8) * KQW;          // (d8, key group) cells of the K tile, 8 loads of KW floats each
     constexpr int KCPT = (KCELLS + 255) / 256;
     constexpr int VCELLS = DKR * KQ;                 // (d, key quad) cells of the V tile, one float4 each
     constexpr int VCPT = VCELLS / 256;
-    constexpr int KBUF = (DKR / 8) * AKT * 4;        // dwords per K buffer
-    constexpr int VBUF = DKR * AVP;                  // dwords per V buffer
+    constexpr int KPL = (DKR / 8) * AKT * 4;         // dwords per K plane
+    constexpr int VPL = DKR * AVP;                   // dwords per V plane
+    constexpr int KBUF = NPL * KPL;                  // dwords per K buffer
+    constexpr int VBUF = NPL * VPL;                  // dwords per V buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,9 +55,9 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     const int dk = p.dk, T = p.T;
     const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
 
-    unsigned *Ks = reinterpret_cast<unsigned *>(smem);      // [2][DKR/8][64 keys][4 dwords]
-    unsigned *Vs = Ks + 2 * KBUF;                            // [2][DKR][AVP]
-    float *Ms = reinterpret_cast<float *>(Vs + 2 * VBUF);    // [2][64] key mask of the tile
+    unsigned *Ks = reinterpret_cast<unsigned *>(smem);      // [NBUF][plane][DKR/8][AKT keys][4 dwords]
+    unsigned *Vs = Ks + NBUF * KBUF;                         // [NBUF][plane][DKR][AVP]
+    float *Ms = reinterpret_cast<float *>(Vs + NBUF * VBUF); // [2][AKT] key mask of the tile
     float *QRs = Ms + 2 * AKT;                               // [4][32][ATT_QRS] rel-key logits
     float *Sws = QRs + 4 * 32 * ATT_QRS;                     // [4][32][ATT_QRS] in-window raw scores
     float *RVs = smem;                                       // [nrel][dk] relative value embeddings: over the K buffers, after the loop
@@ -61,7 +72,26 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     // ---- query fragments: B operand of S^T = K^T Q, element j of k-step ks = Q[d = 16 ks + 8 half + j][query l31] ----
     const int qi = i0 + l31;
     const int qic = min(qi, T - 1);
-    u32x4 qf[NKS];
+    // eight fp32 values -> NPL bf16-plane fragments (RNE for one plane, the exact three-way split otherwise)
+    auto planes8 = [&](const float (&v)[8], u32x4 (&f)[NPL]) __attribute__((always_inline)) {
+        unsigned d[4][NPL];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split_pair<NPL>(v[2 * t], v[2 * t + 1], d[t]);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            u32x4 o; o.x = d[0][pl]; o.y = d[1][pl]; o.z = d[2][pl]; o.w = d[3][pl];
+            f[pl] = o;
+        }
+    };
+    // D += sum over the cross products of the planes of a and b, smallest terms first (conv_split.hip)
+    auto mma = [&](f32x16 &c, const u32x4 (&a)[NPL], const u32x4 (&bq)[NPL]) __attribute__((always_inline)) {
+        auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ta]), __builtin_bit_cast(bf16x8, bq[tb]), c, 0, 0, 0);
+        };
+        if constexpr (TERMS == 6) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); }
+        mm(0, 0);
+    };
+    u32x4 qf[NKS][NPL];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         float qv[8];
@@ -71,12 +101,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             const float v = qb[(long long)min(d, dk - 1) * T + qic];
             qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
         }
-        u32x4 f;
-        f.x = pack_hi(rne_bf16(qv[0]), rne_bf16(qv[1]));
-        f.y = pack_hi(rne_bf16(qv[2]), rne_bf16(qv[3]));
-        f.z = pack_hi(rne_bf16(qv[4]), rne_bf16(qv[5]));
-        f.w = pack_hi(rne_bf16(qv[6]), rne_bf16(qv[7]));
-        qf[ks] = f;
+        planes8(qv, qf[ks]);
     }
     // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] from the fp32 query (a rolled loop: prologue code, kept off the
     // register budget of the main loop); each lane half covers every other group of 8 channels
@@ -110,19 +135,26 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     }
 
     // ---- K / V tile staging ----
-    float4 kst[KCPT][8], vst[VCPT];
+    float kst[KCPT][8][KW];
+    float4 vst[VCPT];
     float mst = 1.f;
     auto load_k = [&](int jt) __attribute__((always_inline)) {
         const int j0 = jt * AKT;
 #pragma unroll
         for (int i = 0; i < KCPT; ++i) {
             const int c = tid + 256 * i;
-            const int kq = c % KQ, d8 = c / KQ;
-            const int jc = min(j0 + 4 * kq, T - 4);                  // T % 4 == 0: a quad is wholly inside or wholly outside
+            const int kq = c % KQW, d8 = c / KQW;
+            const int jc = min(j0 + KW * kq, T - KW);                // T % 4 == 0: a cell is wholly inside or wholly outside
 #pragma unroll
             for (int jd = 0; jd < 8; ++jd) {
                 const int d = min(8 * d8 + jd, dk - 1);
-                kst[i][jd] = *reinterpret_cast<const float4 *>(kb + (long long)d * T + jc);
+                if constexpr (KW == 4) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(kb + (long long)d * T + jc);
+                    kst[i][jd][0] = t4.x; kst[i][jd][1] = t4.y; kst[i][jd][2] = t4.z; kst[i][jd][3] = t4.w;
+                } else {
+                    const float2 t2 = *reinterpret_cast<const float2 *>(kb + (long long)d * T + jc);
+                    kst[i][jd][0] = t2.x; kst[i][jd][1] = t2.y;
+                }
             }
         }
         if (tid < AKT) mst = maskb ? maskb[min(j0 + tid, T - 1)] : 1.f;
@@ -143,24 +175,18 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 #pragma unroll
         for (int i = 0; i < KCPT; ++i) {
             const int c = tid + 256 * i;
-            const int kq = c % KQ, d8 = c / KQ;
+            const int kq = c % KQW, d8 = c / KQW;
             if (KCELLS % 256 == 0 || c < KCELLS) {
-                const bool okj = (j0 + 4 * kq < T);
+                const bool okj = (j0 + KW * kq < T);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < KW; ++e) {
                     float v[8];
 #pragma unroll
-                    for (int jd = 0; jd < 8; ++jd) {
-                        const float4 t4 = kst[i][jd];
-                        const float x = (e == 0) ? t4.x : (e == 1) ? t4.y : (e == 2) ? t4.z : t4.w;
-                        v[jd] = (okj && 8 * d8 + jd < dk) ? x : 0.f;
-                    }
-                    u32x4 f;
-                    f.x = pack_hi(rne_bf16(v[0]), rne_bf16(v[1]));
-                    f.y = pack_hi(rne_bf16(v[2]), rne_bf16(v[3]));
-                    f.z = pack_hi(rne_bf16(v[4]), rne_bf16(v[5]));
-                    f.w = pack_hi(rne_bf16(v[6]), rne_bf16(v[7]));
-                    *reinterpret_cast<u32x4 *>(Kb + (d8 * AKT + 4 * kq + e) * 4) = f;
+                    for (int jd = 0; jd < 8; ++jd) v[jd] = (okj && 8 * d8 + jd < dk) ? kst[i][jd][e] : 0.f;
+                    u32x4 f[NPL];
+                    planes8(v, f);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x4 *>(Kb + pl * KPL + (d8 * AKT + KW * kq + e) * 4) = f[pl];
                 }
             }
         }
@@ -175,11 +201,14 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             const int kq = c % KQ, d = c / KQ;
             const bool ok = (j0 + 4 * kq < T) && (d < dk);
             const float4 t4 = vst[i];
-            const unsigned lo = ok ? pack_hi(rne_bf16(t4.x), rne_bf16(t4.y)) : 0u;
-            const unsigned hi = ok ? pack_hi(rne_bf16(t4.z), rne_bf16(t4.w)) : 0u;
+            unsigned lo[NPL], hi[NPL];
+            split_pair<NPL>(ok ? t4.x : 0.f, ok ? t4.y : 0.f, lo);
+            split_pair<NPL>(ok ? t4.z : 0.f, ok ? t4.w : 0.f, hi);
             // keys 4kq .. 4kq+3 of 16-group kq >> 2: quads (0, 1, 2, 3) of a group sit in slots (0, 2, 1, 3)
             const int slot = ((kq & 1) << 1) | ((kq >> 1) & 1);
-            *reinterpret_cast<uint2 *>(Vb + d * AVP + (kq >> 2) * 8 + slot * 2) = make_uint2(lo, hi);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                *reinterpret_cast<uint2 *>(Vb + pl * VPL + d * AVP + (kq >> 2) * 8 + slot * 2) = make_uint2(lo[pl], hi[pl]);
         }
     };
 
@@ -199,12 +228,16 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     __syncthreads();
     for (int jt = 0; jt < ntiles; ++jt) {
         const int j0 = jt * AKT;
-        const int buf = jt & 1;
+        const int buf = (NBUF == 2) ? (jt & 1) : 0;
         const unsigned *Kb = Ks + buf * KBUF, *Vb = Vs + buf * VBUF;
         const float *Mb = Ms + buf * AKT;
-        // the next tile's K is in flight under the S^T MFMAs and written once they have issued; its V is in flight under the
-        // softmax and the P V MFMAs: the fp32 staging registers of a tile (64 KB of K + 64 KB of V at 256 channels) are never all live
-        if (jt + 1 < ntiles) load_k(jt + 1);
+        // two buffers: the next tile's K is in flight under the S^T MFMAs and written once they have issued, its V is in flight under
+        // the softmax and the P V MFMAs (the fp32 staging registers of a tile -- 64 KB of K + 64 KB of V at 256 channels -- are never
+        // all live).  One buffer (split arithmetic): both are in flight under the whole tile and written between two barriers.
+        if (jt + 1 < ntiles) {
+            load_k(jt + 1);
+            if constexpr (NBUF == 1) load_v(jt + 1);
+        }
 
         // ---- S^T tiles: rows = keys 32 kt + acc_row(r), columns (lanes) = queries ----
         f32x16 s[NKT];
@@ -216,13 +249,18 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                const u32x4 a = *reinterpret_cast<const u32x4 *>(Kb + ((2 * ks + half) * AKT + 32 * kt + l31) * 4);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, qf[ks]), s[kt], 0, 0, 0);
+                u32x4 a[NPL];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    a[pl] = *reinterpret_cast<const u32x4 *>(Kb + pl * KPL + ((2 * ks + half) * AKT + 32 * kt + l31) * 4);
+                mma(s[kt], a, qf[ks]);
             }
         }
-        if (jt + 1 < ntiles) {
-            store_k(jt + 1, buf ^ 1);
-            load_v(jt + 1);
+        if constexpr (NBUF == 2) {
+            if (jt + 1 < ntiles) {
+                store_k(jt + 1, buf ^ 1);
+                load_v(jt + 1);
+            }
         }
         const bool near_diag = nrel && (j0 + AKT - 1 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
         float tmax = -INFINITY;
@@ -249,25 +287,27 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float alpha;
+        if constexpr (TERMS == 6) alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        else alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
         float psum = 0.f;
-        u32x4 pf[2 * NKT];                                   // P^T fragments of the 16-key k-steps
+        u32x4 pf[2 * NKT][NPL];                              // P^T fragments of the 16-key k-steps
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pv[r] = __expf(s[kt][r] - m_new);             // exp(-inf) = 0 for excluded keys; the result is rounded to bf16 anyway
+                // exp(-inf) = 0 for excluded keys; with one bf16 plane the result is rounded to 8 bits anyway: the fast exp
+                if constexpr (TERMS == 6) pv[r] = expf(s[kt][r] - m_new);
+                else pv[r] = __expf(s[kt][r] - m_new);
                 psum += pv[r];
             }
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
-                u32x4 f;
-                f.x = pack_hi(rne_bf16(pv[8 * sh + 0]), rne_bf16(pv[8 * sh + 1]));
-                f.y = pack_hi(rne_bf16(pv[8 * sh + 2]), rne_bf16(pv[8 * sh + 3]));
-                f.z = pack_hi(rne_bf16(pv[8 * sh + 4]), rne_bf16(pv[8 * sh + 5]));
-                f.w = pack_hi(rne_bf16(pv[8 * sh + 6]), rne_bf16(pv[8 * sh + 7]));
-                pf[2 * kt + sh] = f;
+                float v8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = pv[8 * sh + e];
+                planes8(v8, pf[2 * kt + sh]);
             }
         }
         l_half = l_half * alpha + psum;
@@ -286,12 +326,24 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         for (int s4 = 0; s4 < 2 * NKT; ++s4) {
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
-                const u32x4 a = *reinterpret_cast<const u32x4 *>(Vb + (t * 32 + l31) * AVP + s4 * 8 + half * 4);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pf[s4]), o[t], 0, 0, 0);
+                u32x4 a[NPL];
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    a[pl] = *reinterpret_cast<const u32x4 *>(Vb + pl * VPL + (t * 32 + l31) * AVP + s4 * 8 + half * 4);
+                mma(o[t], a, pf[s4]);
             }
         }
-        if (jt + 1 < ntiles) store_v(jt + 1, buf ^ 1);
-        __syncthreads();
+        if constexpr (NBUF == 2) {
+            if (jt + 1 < ntiles) store_v(jt + 1, buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                                 // every wave is done with the (single) K / V buffer
+            if (jt + 1 < ntiles) {
+                store_k(jt + 1, 0);
+                store_v(jt + 1, 0);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- finish: normalise, add the relative-value term (fp32), store ----
@@ -326,16 +378,16 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     }
 }
 
-bool attn_bf16_supported(const AttnParams &p) {
+bool attn_bf16_supported(const AttnParams &p, int terms) {
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    return p.dk <= 256 && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
+    return p.dk <= (terms == 6 ? 128 : 256) && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
 }
 
-template <int DT, int AKT>
+template <int DT, int AKT, int TERMS>
 static int launch_bf16(const AttnParams &p, hipStream_t s) {
-    constexpr int DKR = DT * 32, AVP = AKT / 2 + 4;
-    const size_t lds = 4 * ((size_t)2 * (DKR / 8) * AKT * 4 + (size_t)2 * DKR * AVP + 2 * AKT + 2 * 4 * 32 * ATT_QRS);
-    auto kern = relattn_bf16_kernel<DT, AKT>;
+    constexpr int DKR = DT * 32, AVP = AKT / 2 + 4, NPL = (TERMS == 6) ? 3 : 1, NBUF = (TERMS == 6) ? 1 : 2;
+    const size_t lds = 4 * ((size_t)NBUF * NPL * (DKR / 8) * AKT * 4 + (size_t)NBUF * NPL * DKR * AVP + 2 * AKT + 2 * 4 * 32 * ATT_QRS);
+    auto kern = relattn_bf16_kernel<DT, AKT, TERMS>;
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -345,17 +397,22 @@ static int launch_bf16(const AttnParams &p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, 128), (unsigned)p.nh, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("relattn_bf16_kernel<%d, %d>", DT, AKT);
+    set_last_kernel("relattn_bf16_kernel<%d, %d, %d>", DT, AKT, TERMS);
     return VS_OK;
 }
 
-int launch_attn_bf16(const AttnParams &p, hipStream_t s) {
+int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s) {
     const int DT = (int)ceil_div(p.dk, 32);
-    if (DT <= 2) return launch_bf16<2, 64>(p, s);
-    if (DT == 3) return launch_bf16<3, 64>(p, s);
-    if (DT == 4) return launch_bf16<4, 64>(p, s);
-    if (DT <= 6) return launch_bf16<6, 32>(p, s);
-    return launch_bf16<8, 32>(p, s);
+    if (terms == 6) {
+        if (DT <= 2) return launch_bf16<2, 32, 6>(p, s);
+        if (DT == 3) return launch_bf16<3, 32, 6>(p, s);
+        return launch_bf16<4, 32, 6>(p, s);
+    }
+    if (DT <= 2) return launch_bf16<2, 64, 1>(p, s);
+    if (DT == 3) return launch_bf16<3, 64, 1>(p, s);
+    if (DT == 4) return launch_bf16<4, 64, 1>(p, s);
+    if (DT <= 6) return launch_bf16<6, 32, 1>(p, s);
+    return launch_bf16<8, 32, 1>(p, s);
 }
 
 }  // namespace vs

@@ -19,9 +19,10 @@ struct AttnParams {
     float scale;
 };
 
-// attention_bf16.hip: bf16 operands, fp32 softmax / accumulation; needs T % 4 == 0, 16-byte aligned q / k / v rows, dk <= 256.
-// Returns VS_EUNSUPPORTED without touching the error string when the shape does not qualify (the caller falls back to fp32).
-bool attn_bf16_supported(const AttnParams &p);
-int launch_attn_bf16(const AttnParams &p, hipStream_t s);
+// attention_bf16.hip: both GEMMs on the bf16 matrix instruction, fp32 softmax / accumulation; terms = 1: bf16 operands (dk <= 256),
+// terms = 6: the exact three-plane split with six cross products (fp32 class, dk <= 128).  Needs T % 4 == 0 and 16-byte aligned
+// q / k / v rows: when attn_bf16_supported() says no, the caller runs the exact-fp32 MFMA kernel.
+bool attn_bf16_supported(const AttnParams &p, int terms);
+int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s);
 
 }  // namespace vs

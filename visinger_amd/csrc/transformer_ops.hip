@@ -347,7 +347,10 @@ int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_b
     VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6, "vs_relattn_fwd: unknown arithmetic %d", math);
     // VS_MATH_BF16: both GEMMs on the bf16 matrix instruction (attention_bf16.hip); any other arithmetic, and shapes that kernel does
     // not take (T % 4 != 0, unaligned rows), run the exact-fp32 MFMA kernel below
-    if (math == VS_MATH_BF16 && attn_bf16_supported(p) && !getenv("VS_NO_BF16_ATTN")) return launch_attn_bf16(p, s);
+    // VS_MATH_SPLIT6 (the default arithmetic of the path): the same kernel with every operand split exactly into three bf16 planes and
+    // six cross products per product -- fp32-class scores and outputs at 16/6 of the fp32 matrix rate; VS_MATH_F32: the kernel below
+    if (math == VS_MATH_BF16 && attn_bf16_supported(p, 1) && !getenv("VS_NO_BF16_ATTN")) return launch_attn_bf16(p, 1, s);
+    if (math == VS_MATH_SPLIT6 && attn_bf16_supported(p, 6) && !getenv("VS_NO_SPLIT_ATTN")) return launch_attn_bf16(p, 6, s);
     const int DT = (int)ceil_div(k_channels, 32);
     switch (DT) {
         case 1: return launch_attn<1, 4, false>(p, s);
