@@ -30,10 +30,11 @@ def load(pass_dir, counter):
 
 
 def short(name):
+    """vs::kernel<template args>(params) -> kernel<args> without blanks (the spelling of the profiles/*.json keys)"""
     m = re.search(r"vs::(\w+)(<[^>]*>)?", name)
     if not m:
         return name
-    return m.group(1) + (m.group(2) or "").replace(" ", "") if ("conv_mfma" in name or "conv_wino" in name or "conv_split" in name or "respair" in name) else m.group(1)
+    return m.group(1) + (m.group(2) or "").replace(" ", "")
 
 
 def main():
