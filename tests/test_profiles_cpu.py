@@ -10,11 +10,36 @@ DOM = "conv_split_kernel<1,8,4,1,6>"
 def test_bench_reads_committed_pmc_summaries():
     import bench
     t = bench.pmc_traffic(DOM)
-    assert t is not None and 0.5e9 < t["bytes_per_launch"] < 3e9 and "profiles/" in t["source"]   # HBM bytes per launch, dominant instance
+    assert t is not None and 0.5e9 < t["bytes_per_launch"] < 3e9 and "profiles/r02_a" in t["source"]   # HBM bytes per launch, dominant instance
     assert bench.pmc_traffic("conv_split_kernel<1, 8, 4, 1, 6>") == t     # the library's spelling (rocprofv3's: blanks after commas)
     m = bench.pmc_mfma_executed(DOM)
     assert m is not None and 800.0 < m["tflops"] < 2500.0 and 0.3 < m["pipe_busy"] <= 1.0
     assert bench.pmc_traffic("no_such_kernel") is None and bench.pmc_mfma_executed("no_such_kernel") is None
+
+
+def test_round2_bench_line_follows_the_roofline_contract_and_agrees_with_rocprofv3():
+    """profiles/r02_a_*: `achieved` / `frac` are ALGORITHMIC FLOPs against the stated peak, the executed figure sits
+    under its own keys, and rocprofv3's average launch of the dominant instance equals the HIP-event average of the same run."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_a_bench_line_profiled.json")))
+    r = line["roofline"]
+    assert r["kernel"] == "conv_split_kernel<1, 8, 4, 1, 6>" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["peak"] - 2500.0 / 6) < 1e-6
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 1e-6 * r["achieved"]      # GFLOP / ms = TFLOP/s
+    assert abs(r["frac_executed"] - 6 * r["achieved"] / 2500.0) < 1e-9 and abs(r["frac_vs_fp32_mfma_peak"] - r["achieved"] / 157.3) < 1e-9
+    assert 0 < r["step"]["frac"] < 1 and abs(r["step"]["frac"] - r["step"]["achieved"] / r["step"]["peak"]) < 1e-9
+    with open(os.path.join(ROOT, "profiles", "r02_a_bench_kernel_stats.csv"), newline="") as f:
+        rows = {row["Name"]: row for row in csv.DictReader(f)}
+    avg_ms = float(rows["void vs::conv_split_kernel<1, 8, 4, 1, 6>(vs::ConvParams)"]["AverageNs"]) * 1e-6
+    assert abs(avg_ms - r["avg_launch_ms"]) <= 0.02 * avg_ms
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02_a_bench_line.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_stats", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "fp32_mfma_engine"):
+        assert key in full, key
+    assert full["steps"] == 30 and full["warmup"] == 10 and full["fp32_mfma_engine"]["steps"] == 30
+    assert full["ms_per_step_stats"]["min_ms"] <= full["ms_per_step_stats"]["median_ms"] <= full["ms_per_step_stats"]["max_ms"]
+    assert full["cpu_baseline"]["kind"] == "port" and full["flow_logdet_rel_err"] <= 1e-4
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_a_pmc_traffic.json")))["kernels"]
+    assert "conv_wsplit_kernel<1,4>" in t and "relattn_bf16_kernel<3,32,6>" in t
 
 
 def test_committed_bench_line_and_kernel_stats_agree():

@@ -1434,6 +1434,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         q.wp = h->wsw.as<float>();
         q.KT = h->wino_groups;
         q.lo = -h->pad;
+        if (const char *e = getenv("VS_WSPLIT_STAGGER")) q.dbg = atoi(e);
         return launch_wsplit(q, h->dil, h->wino_groups, s);
     }
     // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,

@@ -280,6 +280,12 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     load_a(ar[2], 2);
 
     stamp(p, 0);
+    // Two workgroups share a CU and each alternates a VALU / LDS phase (transform) with an MFMA phase per chunk: started together
+    // they transform together and then compete for the matrix pipe.  p.dbg > 0 (VS_WSPLIT_STAGGER, experiment): the workgroups of
+    // every other dispatch round of 256 start p.dbg x 64 cycles late.
+    if (p.dbg > 0 && (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1)) {
+        for (int i = 0; i < p.dbg; i += 32) __builtin_amdgcn_s_sleep(32);
+    }
     stage_load(0);
     stage_store(0);                 // (hipcc waits vmcnt(0) for the staged registers: covers the three requests above as well)
     __syncthreads();
