@@ -155,7 +155,9 @@ def test_bf16_attention_matches_fp32_kernel(dk, nh, T, ws, share):
 @pytest.mark.parametrize("Cin,Cout,k,d,T,B", [(128, 128, 3, 1, 1024, 2), (128, 128, 3, 3, 700, 1), (128, 128, 3, 5, 516, 2), (256, 256, 11, 1, 512, 1),
                                               (128, 128, 11, 3, 1000, 2), (128, 128, 11, 5, 2048, 1), (256, 256, 7, 1, 300, 2), (128, 128, 7, 3, 640, 1),
                                               (128, 128, 7, 5, 900, 1), (192, 768, 9, 1, 333, 2), (200, 128, 3, 1, 130, 1), (64, 256, 11, 1, 37, 3),
-                                              (128, 128, 3, 1, 4, 2), (136, 384, 9, 1, 260, 1)])
+                                              (128, 128, 3, 1, 4, 2), (136, 384, 9, 1, 260, 1),
+                                              (64, 64, 11, 1, 1024, 2), (64, 64, 11, 3, 700, 1), (64, 64, 11, 5, 516, 2), (64, 64, 7, 1, 300, 1),
+                                              (64, 64, 7, 5, 1000, 1), (64, 64, 3, 3, 130, 2), (48, 192, 9, 1, 250, 1), (64, 64, 3, 1, 2, 1)])
 def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
     """csrc/conv_wsplit.hip: minimal filtering F(2,3) on the split-bf16 x6 arithmetic (4 products of 6 cross terms per output pair
     and tap group instead of 6) against the fp64 oracle, with every fused option of the LINEAR epilogue it serves -- residual,
@@ -190,7 +192,8 @@ def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
 
     conv = oracle.conv1d(xl, w, bias, dilation=d, padding=pad)
     y = op.forward(dev(x), in_act=L.IN_LRELU)
-    assert op.kernel_instance() == f"conv_wsplit_kernel<{d}, {-(-k // 3)}>", op.kernel_instance()
+    # (128-row workgroups where the rows are whole multiples of 128, else 64-row workgroups: the 64-channel stage)
+    assert op.kernel_instance() == f"conv_wsplit_kernel<{d}, {-(-k // 3)}, {1 if Cout % 128 == 0 else 2}>", op.kernel_instance()
     close(y, conv)
     close(op.forward(dev(x), in_act=L.IN_LRELU, res=dev(res)), conv + res)                                   # inner resblock conv
     acc_t = dev(accb)

@@ -21,7 +21,7 @@ def run(op, x, y, res, n):
 
 
 tot_w = tot_d = 0.0
-for cin, cout, T in ((256, 256, 8192), (128, 128, 65536), (192, 768, 1024)):
+for cin, cout, T in ((256, 256, 8192), (128, 128, 65536), (64, 64, 131072), (192, 768, 1024)):
     for k in ((3, 7, 11) if cin == cout else (9,)):
         for d in ((1, 3, 5) if cin == cout else (1,)):
             op = ConvOp(L.CONV1D, cin, cout, k, d, d * (k - 1) // 2)

@@ -110,7 +110,7 @@ struct vs_split_pack {            // re-pack of the fp32 fragment-order weights 
 };
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);
-// cfg: tile shape as chosen by vs_conv_forward for the direct engine (0: 128 rows, 1/3: 64, 2: 32; 4/5: paired); span = receptive span
+// cfg: tile shape as chosen by vs_conv_forward for the direct engine (0: 128 rows, 1/3: 64, 2: 32 x 256, 6: 32 x 128; 4/5: paired); span = receptive span
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);
 
 

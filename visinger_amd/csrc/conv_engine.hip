@@ -1176,7 +1176,7 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
     // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
-    h->wsplit = h->wino_groups > 0 && (h->MT % 4) == 0 && flags == 0 && wsplit_instance(dil, h->wino_groups) &&
+    h->wsplit = h->wino_groups > 0 && (h->MT % 2) == 0 && flags == 0 && wsplit_instance(dil, h->wino_groups) &&
                 (k >= 9 || getenv("VS_WSPLIT_FORCE"));      // (where it pays: see vs_conv_forward)
     // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
     // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
@@ -1429,7 +1429,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // 2.0 us of staging against 1.5 us of MFMAs at k = 3, 3.2 against 7.5 at k = 11), so k = 3 (4/6, x0.86 .. x0.98) and k = 7
     // (12/14 with the zero-padded last group, x0.90 .. x1.02) stay on the direct kernel.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B.
     if (h->math == VS_MATH_SPLIT6 && h->wsplit_packed && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
-        (ceil_div(p.N, 120) * p.B * (h->MT / 4) >= 256 || getenv("VS_WSPLIT_FORCE"))) {      // (short launches: the small direct tiles)
+        (ceil_div(p.N, 120) * p.B * (h->MT / 2) >= 512 || getenv("VS_WSPLIT_FORCE"))) {      // (short launches: the small direct tiles)
         ConvParams q = p;
         q.wp = h->wsw.as<float>();
         q.KT = h->wino_groups;
@@ -1452,6 +1452,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         const long long ncol = ceil_div(p.N, 256) * p.B;
         if (cfg == 0 && ncol * ceil_div(h->MT, 4) < 256) cfg = 3;
         if (cfg == 3 && ncol * ceil_div(h->MT, 2) < 256 && (long long)p.N * p.B <= 65536) cfg = 2;
+        if (cfg == 2 && ncol * h->MT < 128 && h->kind != VS_CONV_TRANSPOSE1D) cfg = 6;     // 128-column tiles: twice the workgroups again
     }
     if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
     if (h->math) p.wp = h->ws.as<float>();

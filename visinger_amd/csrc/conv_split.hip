@@ -356,6 +356,7 @@ static int launch_split_terms(const ConvParams &p, int cfg, int span, hipStream_
         case 1:
         case 3: return launch_split_cfg<1, 4, 2, 2, TERMS>(p, span, s);    //  64 x 256
         case 2: return launch_split_cfg<1, 2, 1, 4, TERMS>(p, span, s);    //  32 x 256
+        case 6: return launch_split_cfg<1, 1, 1, 4, TERMS>(p, span, s);    //  32 x 128 (single utterances: latency)
         case 4: return launch_split_cfg<2, 2, 2, 2, TERMS>(p, span, s);    // paired, 128 virtual rows x 128
         default: return launch_split_cfg<2, 2, 1, 4, TERMS>(p, span, s);   // paired,  64 virtual rows x 256
     }

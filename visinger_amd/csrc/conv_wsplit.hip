@@ -95,11 +95,15 @@ constexpr int WS_MAXWX = 128 + MAX_SPAN;      // staged raw window: outputs of t
 constexpr int WS_CIT = WS_MAXWX / 64;         // column iterations per staged row
 constexpr int WS_WR = WS_MAXWX + 4;           // pitch of the wave-private raw strip (floats)
 
-template <int DIL, int G>
+// WN = 1: four waves stacked in M (128 rows), each with both 32-lane pair tiles of the workgroup's columns; WN = 2: 2 x 2 waves (64
+// rows: the 64-channel stage), each wave with ONE pair tile -- a weight fragment then feeds a single column tile.
+template <int DIL, int G, int WN>
 __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p) {
-    constexpr int PW = (64 / DIL) * DIL;         // valid pair columns per wave (of 64)
-    constexpr int NBW = 2 * PW;                  // outputs per wave = per workgroup (four waves stacked in M)
-    constexpr int BN = NBW;
+    constexpr int NTW = 2 / WN;                  // pair tiles per wave
+    constexpr int WM = 4 / WN;                   // waves along M
+    constexpr int PW = (WN == 1) ? (64 / DIL) * DIL : (32 / DIL) * DIL;     // valid pair columns per wave
+    constexpr int NBW = 2 * PW;                  // outputs per wave
+    constexpr int BN = NBW * WN;                 // outputs per workgroup
     constexpr int W = BN + 3 * (G - 1) * DIL + DIL;   // positions of the transformed arrays that are read
     constexpr int WX = W + 2 * DIL;              // raw window = BN + 3 G d
     constexpr int CIT = (WX + 63) / 64;
@@ -114,7 +118,8 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
     const int n0 = blockIdx.x * BN;
-    const int mt0 = blockIdx.y * 4 + wave;
+    const int wm = wave % WM, wn = wave / WM;
+    const int mt0 = blockIdx.y * WM + wm;
     unsigned *const Vb = reinterpret_cast<unsigned *>(smem);             // [array(3)][plane(3)][k-group(2)][W][4 dwords]
     float *const RAWw = smem + 3 * ARSZ + wave * 4 * WS_WR;              // this wave's [4 channels][WS_WR] raw strip
     const float *const xb = p.x + (long long)b * p.x_bs;
@@ -124,14 +129,14 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
 
     // M0 starts from the row's bias and M3 from its negative (y[t] = M0+M1+M2, y[t+d] = M1-M2-M3)
     const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
-    f32x16 acc[4][2];
+    f32x16 acc[4][NTW];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = mt0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
         float bv = p.biasp[row];
         if (bbias) bv += bbias[min(row, p.M - 1)];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NTW; ++j) {
             acc[0][j][r] = bv;
             acc[1][j][r] = 0.f;
             acc[2][j][r] = 0.f;
@@ -140,12 +145,12 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     }
 
     // pair column c -> first output of the pair t(c) = (c / d) 2d + c % d, relative to the tile's first output
-    int posr[2];
+    int posr[NTW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NTW; ++j) {
         const int c = j * 32 + l31;
         const int t = (c / DIL) * (2 * DIL) + (c % DIL);
-        posr[j] = (c < PW) ? t : 0;          // idle columns read a valid LDS address
+        posr[j] = wn * NBW + ((c < PW) ? t : 0);          // idle columns read a valid LDS address
     }
 
     // ---- staging: wave w owns channels 4w .. 4w+3 of every chunk (k-group w/2, dwords (w&1)*2 .. +1 of the 16-B cell) ----
@@ -310,22 +315,33 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
             const int ss = chunk * SPC + u;
             load_a(ar[(u + 3) & 3], ss + 3);
             if (u == 0 && stage_next) stage_load(chunk + 1);          // (registers free: chunk's own data went to LDS before the barrier)
-            read_b(b1, u, 1);
+            if constexpr (NTW == 2) read_b(b1, u, 1);
             wait_a(ar[u & 3], stage_next && u < 4);
             const u32x4(&a)[3] = ar[u & 3];
             auto mm = [&](f32x16 &c, const u32x4(&bf)[3], int ta, int tb) __attribute__((always_inline)) {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ta]), __builtin_bit_cast(bf16x8, bf[tb]), c, 0, 0, 0);
             };
-            __builtin_amdgcn_sched_barrier(0);
-            // smallest terms first
-            mm(acc[xi][0], b0, 1, 1); mm(acc[xi][0], b0, 2, 0); mm(acc[xi][0], b0, 0, 2);
-            mm(acc[xi][0], b0, 1, 0); mm(acc[xi][0], b0, 0, 1); mm(acc[xi][0], b0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (u + 1 < SPC) read_b(b0, u + 1, 0);                    // the next sub-step's first tile, under this one's second
-            __builtin_amdgcn_sched_barrier(0);
-            mm(acc[xi][1], b1, 1, 1); mm(acc[xi][1], b1, 2, 0); mm(acc[xi][1], b1, 0, 2);
-            mm(acc[xi][1], b1, 1, 0); mm(acc[xi][1], b1, 0, 1); mm(acc[xi][1], b1, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NTW == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                // smallest terms first
+                mm(acc[xi][0], b0, 1, 1); mm(acc[xi][0], b0, 2, 0); mm(acc[xi][0], b0, 0, 2);
+                mm(acc[xi][0], b0, 1, 0); mm(acc[xi][0], b0, 0, 1); mm(acc[xi][0], b0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < SPC) read_b(b0, u + 1, 0);                // the next sub-step's first tile, under this one's second
+                __builtin_amdgcn_sched_barrier(0);
+                mm(acc[xi][NTW - 1], b1, 1, 1); mm(acc[xi][NTW - 1], b1, 2, 0); mm(acc[xi][NTW - 1], b1, 0, 2);
+                mm(acc[xi][NTW - 1], b1, 1, 0); mm(acc[xi][NTW - 1], b1, 0, 1); mm(acc[xi][NTW - 1], b1, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // one pair tile per wave: the planes of the next sub-step are read under this one's MFMAs (b0 / b1 alternate)
+                u32x4(&bc)[3] = (u & 1) ? b1 : b0;
+                u32x4(&bx)[3] = (u & 1) ? b0 : b1;
+                if (u + 1 < SPC) read_b(bx, u + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(acc[xi][0], bc, 1, 1); mm(acc[xi][0], bc, 2, 0); mm(acc[xi][0], bc, 0, 2);
+                mm(acc[xi][0], bc, 1, 0); mm(acc[xi][0], bc, 0, 1); mm(acc[xi][0], bc, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (chunk == 1) stamp(p, 8);
         __syncthreads();                                  // every wave is done with the transformed arrays of this chunk
@@ -342,7 +358,7 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     // ------------------------------------------------------------------------------------------------- epilogue
     // output transform in place: acc[0] <- y[t(c)], acc[3] <- y[t(c) + d]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float m1 = acc[1][j][r], m2 = acc[2][j][r];
@@ -357,13 +373,13 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     float *const yb = o.y + (long long)b * o.y_bs;
     const float *const resp = has_res ? o.res + (long long)b * o.res_bs : nullptr;
     const float *const accp = has_acc ? o.acc + (long long)b * o.acc_bs : nullptr;
-    const int nw = n0;                           // first output of this wave (the four waves share the columns)
+    const int nw = n0 + wn * NBW;                // first output of this wave
     int lane_e = lane;                           // opaque copy: keeps the epilogue's address arithmetic out of the prologue
     asm volatile("" : "+v"(lane_e));
-    int posw[2], pose[2];
-    bool cvalid[2];
+    int posw[NTW], pose[NTW];
+    bool cvalid[NTW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NTW; ++j) {
         const int c = j * 32 + (lane_e & 31);
         const int t = (c / DIL) * (2 * DIL) + (c % DIL);
         cvalid[j] = c < PW;
@@ -413,7 +429,7 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
+                        for (int j = 0; j < NTW; ++j) {
                             const float y0 = acc[0][j][4 * ps + q], y1 = acc[3][j][4 * ps + q];
                             if constexpr (DIL == 1) {      // the pair is adjacent: one 8-byte write, unit stride across lanes
                                 *reinterpret_cast<float2 *>(Lw + (q + 4 * lhalf) * CWP + posw[j]) = make_float2(y0, y1);
@@ -459,7 +475,7 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     } else {
         // edge workgroups (ragged last time tile): element-wise, predicated stores, clamped loads
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NTW; ++j) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int col = nw + pose[j] + hh * DIL;
@@ -489,27 +505,30 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
     }
 }
 
-template <int DIL, int G>
+template <int DIL, int G, int WN>
 static int launch_wsplit_cfg(const ConvParams &p, hipStream_t s) {
-    constexpr int PW = (64 / DIL) * DIL, NBW = 2 * PW, W = NBW + 3 * (G - 1) * DIL + DIL, CWP = NBW + 8;
-    auto kern = conv_wsplit_kernel<DIL, G>;
+    constexpr int PW = (WN == 1) ? (64 / DIL) * DIL : (32 / DIL) * DIL, NBW = 2 * PW, BN = NBW * WN;
+    constexpr int W = BN + 3 * (G - 1) * DIL + DIL, CWP = NBW + 8;
+    auto kern = conv_wsplit_kernel<DIL, G, WN>;
     const size_t lds = std::max<size_t>((size_t)4 * (3 * 3 * 2 * W * 4 + 4 * 4 * WS_WR), (size_t)4 * 4 * 8 * CWP);
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((unsigned)ceil_div(p.N, NBW), (unsigned)ceil_div(p.MT, 4), (unsigned)p.B);
+    dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, 4 / WN), (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("conv_wsplit_kernel<%d, %d>", DIL, G);
+    set_last_kernel("conv_wsplit_kernel<%d, %d, %d>", DIL, G, WN);
     return VS_OK;
 }
 
-bool wsplit_instance(int dil, int G) { return (dil == 1 && (G == 1 || G == 3 || G == 4)) || ((dil == 3 || dil == 5) && (G == 1 || G == 3 || G == 4) && 3 * G * dil <= MAX_SPAN); }
+bool wsplit_instance(int dil, int G) { return (dil == 1 || dil == 3 || dil == 5) && (G == 1 || G == 3 || G == 4) && 3 * G * dil <= MAX_SPAN; }
 
+// MT % 4 == 0: 128-row workgroups (WN = 1); otherwise MT % 2 == 0: 64-row workgroups (WN = 2)
 int launch_wsplit(const ConvParams &p, int dil, int G, hipStream_t s) {
-#define VS_WS(D, GG) if (dil == D && G == GG) return launch_wsplit_cfg<D, GG>(p, s)
+    const bool wide = (p.MT % 4) == 0;
+#define VS_WS(D, GG) if (dil == D && G == GG) return wide ? launch_wsplit_cfg<D, GG, 1>(p, s) : launch_wsplit_cfg<D, GG, 2>(p, s)
     VS_WS(1, 1); VS_WS(1, 3); VS_WS(1, 4);
     VS_WS(3, 1); VS_WS(3, 3); VS_WS(3, 4);
     VS_WS(5, 1); VS_WS(5, 3); VS_WS(5, 4);
