@@ -1429,7 +1429,9 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // 2.0 us of staging against 1.5 us of MFMAs at k = 3, 3.2 against 7.5 at k = 11), so k = 3 (4/6, x0.86 .. x0.98) and k = 7
     // (12/14 with the zero-padded last group, x0.90 .. x1.02) stay on the direct kernel.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B.
     if (h->math == VS_MATH_SPLIT6 && h->wsplit_packed && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
-        (ceil_div(p.N, 120) * p.B * (h->MT / 2) >= 512 || getenv("VS_WSPLIT_FORCE"))) {      // (short launches: the small direct tiles)
+        ((ceil_div(p.N, 120) * p.B * (h->MT / 2) >= 512 &&              // (short launches: the small direct tiles)
+          ((h->MT % 4) == 0 || h->dil == 1)) ||                         // (64-row workgroups: x1.12 at dilation 1, a tie at 3 / 5)
+         getenv("VS_WSPLIT_FORCE"))) {
         ConvParams q = p;
         q.wp = h->wsw.as<float>();
         q.KT = h->wino_groups;

@@ -394,9 +394,13 @@ __global__ void __launch_bounds__(256, 2) conv_wsplit_kernel(const ConvParams p)
         constexpr int NIT = 8 / RPI;
         typedef float vecf __attribute__((ext_vector_type(VEC)));
         float *const Lw = smem + wave * 8 * CWP;
-        const int lrow = lane_e / LPR;
-        const int cv = (lane_e % LPR) * VEC;
-        const bool active = lane_e < LPR * RPI;
+        // lanes beyond LPR * RPI (dilation 3 / 5: 63 or 60 of 64) repeat the last lane's loads and stores (identical values to identical
+        // addresses) instead of being masked off: with 64-row workgroups they hold VALID pair columns of the other lane half, and
+        // their transposition writes of the first pass of a batch were lost when the load batch in front of it was predicated
+        const int lane_a = min(lane_e, LPR * RPI - 1);
+        const int lrow = lane_a / LPR;
+        const int cv = (lane_a % LPR) * VEC;
+        constexpr bool active = true;
         const int colg = nw + cv;
         vecf mv;
 #pragma unroll
