@@ -117,7 +117,7 @@ int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t 
 // conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)
 bool wsplit_instance(int dil, int G);
 size_t wsplit_bytes(int MT_alloc, int nchunks, int G);
-int pack_wsplit(const float *w, const float *scale, void *ws, int c_in, int c_out, int k, int MT_alloc, int nchunks, int G, hipStream_t s);
+int pack_wsplit(const float *wp, void *ws, int KT, int MT_alloc, int nchunks, int G, hipStream_t s);   // from the fp32 fragments Wp
 int launch_wsplit(const ConvParams &p, int dil, int G, hipStream_t s);
 
 }  // namespace vs

@@ -1204,9 +1204,6 @@ int vs_conv_set_math(vs_conv_t *h, int math, void *stream) {
     if (h->math == math) return VS_OK;
     h->math = math;
     if (math && h->weights_set) VS_TRY(pack_split_planes(h, as_stream(stream)));
-    // (the F(2,3) transform of the split engine is packed from the caller's weights in vs_conv_set_weights only: after a change of
-    // arithmetic the direct split kernel serves the handle until its weights are set again)
-    if (math != VS_MATH_SPLIT6) h->wsplit_packed = false;
     return VS_OK;
 }
 
@@ -1264,12 +1261,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     }
     VS_CHECK_HIP(hipGetLastError());
     if (h->math) VS_TRY(pack_split_planes(h, s));
-    h->wsplit_packed = false;
-    if (h->wsplit && h->math == VS_MATH_SPLIT6 && !getenv("VS_NO_WSPLIT")) {
-        VS_TRY(h->wsw.reserve(wsplit_bytes(h->MT_alloc, h->nchunks, h->wino_groups)));
-        VS_TRY(pack_wsplit(w, scale, h->wsw.p, h->c_in, h->c_out, h->k, h->MT_alloc, h->nchunks, h->wino_groups, s));
-        h->wsplit_packed = true;
-    }
+    h->wsplit_packed = false;      // (the F(2,3) transform of the split engine is rebuilt from Wp by the first launch that uses it)
     h->weights_set = true;
     return VS_OK;
 }
@@ -1428,10 +1420,15 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // Its three transformed arrays cost 4x the staging work of the direct kernel per 16-channel chunk (tools/wsplit_stamps.py:
     // 2.0 us of staging against 1.5 us of MFMAs at k = 3, 3.2 against 7.5 at k = 11), so k = 3 (4/6, x0.86 .. x0.98) and k = 7
     // (12/14 with the zero-padded last group, x0.90 .. x1.02) stay on the direct kernel.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B.
-    if (h->math == VS_MATH_SPLIT6 && h->wsplit_packed && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
+    if (h->math == VS_MATH_SPLIT6 && h->wsplit && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
         ((ceil_div(p.N, 120) * p.B * (h->MT / 2) >= 512 &&              // (short launches: the small direct tiles)
           ((h->MT % 4) == 0 || h->dil == 1)) ||                         // (64-row workgroups: x1.12 at dilation 1, a tie at 3 / 5)
          getenv("VS_WSPLIT_FORCE"))) {
+        if (!h->wsplit_packed) {
+            VS_TRY(h->wsw.reserve(wsplit_bytes(h->MT_alloc, h->nchunks, h->wino_groups)));
+            VS_TRY(pack_wsplit(h->wp.as<float>(), h->wsw.p, h->KT, h->MT_alloc, h->nchunks, h->wino_groups, s));
+            h->wsplit_packed = true;
+        }
         ConvParams q = p;
         q.wp = h->wsw.as<float>();
         q.KT = h->wino_groups;

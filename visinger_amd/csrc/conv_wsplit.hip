@@ -34,13 +34,15 @@
 namespace vs {
 
 struct WsplitPack {
-    const float *w;        // [c_out, c_in, k] (weight or weight_v)
-    const float *scale;    // optional per-row scale g / ||v|| (weight norm), or null
+    const float *wp;       // fp32 fragment-order weights Wp[m_tile][tap][chunk][quad(2)][64][4] (pack_conv_kernel: weight norm folded in)
     void *ws;              // Us[m_tile][chunk][group][xi][plane(3)][64 lanes][8 bf16]
-    int c_in, c_out, k, MT_alloc, nchunks, G;
+    int KT, MT_alloc, nchunks, G;
 };
 
-// lane l <-> row m_tile*32 + (l & 31), channels chunk*16 + 8*(l >> 5) + j
+// lane l <-> row m_tile*32 + (l & 31), channels chunk*16 + 8*(l >> 5) + j.  Reads the handle's own fp32 fragments (lane l of quad qd,
+// element e <-> row l&31, channel chunk*16 + 2*(4*qd + e) + (l>>5)), so the transform can be (re)built whenever it is first needed:
+// after vs_conv_set_weights, after a change of arithmetic -- and never for handles whose launches stay on the direct kernel (the
+// training path re-packs every conv every step).
 __global__ void pack_wsplit_kernel(const WsplitPack q) {
     const long long total = (long long)q.MT_alloc * q.nchunks * q.G * 4 * 64;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,22 +54,18 @@ __global__ void pack_wsplit_kernel(const WsplitPack q) {
     t /= q.G;
     const int chunk = (int)(t % q.nchunks);
     const int mt = (int)(t / q.nchunks);
-    const int row = mt * 32 + (lane & 31);
+    const int row = lane & 31;
     float u[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int ci = chunk * CK + 8 * (lane >> 5) + j;
-        float val = 0.f;
-        if (row < q.c_out && ci < q.c_in) {
-            const float sc = q.scale ? q.scale[row] : 1.f;
-            const float *wr = q.w + ((long long)row * q.c_in + ci) * q.k;
-            const int k0 = 3 * g;
-            const float w0 = (k0 < q.k) ? wr[k0] * sc : 0.f;
-            const float w1 = (k0 + 1 < q.k) ? wr[k0 + 1] * sc : 0.f;
-            const float w2 = (k0 + 2 < q.k) ? wr[k0 + 2] * sc : 0.f;
-            val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
+        const int cl = 8 * (lane >> 5) + j, cp = cl >> 1, par = cl & 1;
+        float w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int tap = 3 * g + i;
+            w[i] = (tap < q.KT) ? q.wp[(((long long)mt * q.KT + tap) * q.nchunks + chunk) * 512 + (cp >> 2) * 256 + (row + 32 * par) * 4 + (cp & 3)] : 0.f;
         }
-        u[j] = val;
+        u[j] = (xi == 0) ? w[0] : (xi == 1) ? 0.5f * (w[0] + w[1] + w[2]) : (xi == 2) ? 0.5f * (w[0] - w[1] + w[2]) : w[2];
     }
     unsigned d[4][3];
 #pragma unroll
@@ -80,9 +78,9 @@ __global__ void pack_wsplit_kernel(const WsplitPack q) {
     }
 }
 
-int pack_wsplit(const float *w, const float *scale, void *ws, int c_in, int c_out, int k, int MT_alloc, int nchunks, int G, hipStream_t s) {
+int pack_wsplit(const float *wp, void *ws, int KT, int MT_alloc, int nchunks, int G, hipStream_t s) {
     WsplitPack q;
-    q.w = w; q.scale = scale; q.ws = ws; q.c_in = c_in; q.c_out = c_out; q.k = k; q.MT_alloc = MT_alloc; q.nchunks = nchunks; q.G = G;
+    q.wp = wp; q.ws = ws; q.KT = KT; q.MT_alloc = MT_alloc; q.nchunks = nchunks; q.G = G;
     const long long total = (long long)MT_alloc * nchunks * G * 4 * 64;
     hipLaunchKernelGGL(pack_wsplit_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
     VS_CHECK_HIP(hipGetLastError());
