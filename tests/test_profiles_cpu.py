@@ -10,7 +10,7 @@ DOM = "conv_split_kernel<1,8,4,1,6>"
 def test_bench_reads_committed_pmc_summaries():
     import bench
     t = bench.pmc_traffic(DOM)
-    assert t is not None and 0.5e9 < t["bytes_per_launch"] < 3e9 and "profiles/r02_a" in t["source"]   # HBM bytes per launch, dominant instance
+    assert t is not None and 0.5e9 < t["bytes_per_launch"] < 3e9 and "profiles/r02_" in t["source"]   # HBM bytes per launch, dominant instance
     assert bench.pmc_traffic("conv_split_kernel<1, 8, 4, 1, 6>") == t     # the library's spelling (rocprofv3's: blanks after commas)
     m = bench.pmc_mfma_executed(DOM)
     assert m is not None and 800.0 < m["tflops"] < 2500.0 and 0.3 < m["pipe_busy"] <= 1.0
