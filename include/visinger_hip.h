@@ -168,6 +168,20 @@ VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma
                               int64_t g_batch_stride, int g_time_stride, const float *mask, float *y, int64_t B,
                               int64_t C, int64_t T, float eps, void *stream);
 
+/* Training path: the elementwise neighbours of the convs as one forward and one backward launch each, where autograd
+ * through PyTorch-ROCm ops took 10-25 small kernels.
+ *   vs_gate_fwd / vs_gate_bwd: the WaveNet gate (modules/visinger/encoder.py:206-213 fused_add_tanh_sigmoid_multiply + the conditioning
+ *     add of :177-180): acts[b, c, t] = tanh(x_in[b, c, t] + g[b, c]) * sigmoid(x_in[b, H + c, t] + g[b, H + c]).  x_in: [B, 2H, T];
+ *     g: optional per-item bias, row b at g + b * g_bs (the layer's 2H-slice of the cond_layer output); acts / dacts: [B, H, T];
+ *     dx_in: [B, 2H, T] = d loss / d x_in (= d / d g before the sum over t); dg (optional): += sum_t dx_in[b, :, t], row stride dg_bs.
+ *   vs_layernorm_c_bwd: backward of y = LayerNorm_C(a + r) * gamma + beta (rel_transformer.py:33-42; r optional): dx [B, C, T] is the
+ *     gradient w.r.t. a (and r); dgamma / dbeta [C] are ACCUMULATED (+=, float atomics: zero them first).                          */
+VS_API int vs_gate_fwd(const float *x_in, const float *g, int64_t g_bs, float *acts, int64_t B, int64_t H, int64_t T, void *stream);
+VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const float *dacts, float *dx_in, float *dg, int64_t dg_bs,
+                       int64_t B, int64_t H, int64_t T, void *stream);
+VS_API int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const float *dy, float *dx, float *dgamma,
+                              float *dbeta, int64_t B, int64_t C, int64_t T, float eps, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * a13 grouped / strided Conv1d of the scale discriminator (modules/discriminator.py:55-60) and its gradients.
  *     x: [B, c_in, T], w: [c_out, c_in/groups, k], y / gy: [B, c_out, T_out], T_out = (T + 2*pad - k)/stride + 1.

@@ -183,3 +183,44 @@ def test_backward_random_sweep(monkeypatch):
     import backward_fuzz
     monkeypatch.setattr(sys, "argv", ["backward_fuzz.py", "120", "9"])
     backward_fuzz.main()
+
+
+def test_fused_gate_and_layernorm_functions_match_torch_autograd():
+    """visinger_amd.autograd.GateFn / LayerNormFn (csrc/train_ops.hip: one forward + one backward launch each) against PyTorch autograd of
+    the reference expressions (encoder.py:177-180, 206-213; rel_transformer.py:33-42, 305): values and every gradient, odd sizes."""
+    from visinger_amd.autograd import GateFn, LayerNormFn
+    torch.manual_seed(11)
+    for B, H, T, Lyr in ((2, 192, 512, 3), (3, 24, 37, 1), (1, 16, 1030, 2)):
+        x_in = torch.randn(B, 2 * H, T, device="cuda", requires_grad=True)
+        gall = torch.randn(B, 2 * H * Lyr, 1, device="cuda", requires_grad=True)
+        i = Lyr - 1
+        w = torch.randn(B, H, T, device="cuda")
+        acts = GateFn.apply(x_in, gall[:, i * 2 * H:(i + 1) * 2 * H, :])
+        gx, gg = torch.autograd.grad((acts * w).sum(), [x_in, gall])
+        xr, gr = x_in.detach().clone().requires_grad_(True), gall.detach().clone().requires_grad_(True)
+        z = xr + gr[:, i * 2 * H:(i + 1) * 2 * H, :]
+        ref = torch.tanh(z[:, :H]) * torch.sigmoid(z[:, H:])
+        rx, rg = torch.autograd.grad((ref * w).sum(), [xr, gr])
+        assert float((acts - ref).abs().max()) <= 2e-6
+        assert float((gx - rx).abs().max()) <= 2e-6 * (1 + float(rx.abs().max()))
+        assert float((gg - rg).abs().max()) <= 2e-5 * (1 + float(rg.abs().max()))            # sum over T of fp32 terms, atomics
+        acts0 = GateFn.apply(x_in, None)                                                        # no conditioning (gin_channels = 0)
+        assert float((acts0 - torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])).abs().max()) <= 2e-6
+    for B, C, T in ((2, 192, 512), (3, 24, 65), (1, 512, 130)):
+        a = torch.randn(B, C, T, device="cuda", requires_grad=True)
+        r = torch.randn(B, C, T, device="cuda", requires_grad=True)
+        gamma = (1 + 0.2 * torch.randn(C, device="cuda")).requires_grad_(True)
+        beta = (0.1 * torch.randn(C, device="cuda")).requires_grad_(True)
+        w = torch.randn(B, C, T, device="cuda")
+        for res in (r, None):
+            y = LayerNormFn.apply(a, res, gamma, beta, 1e-4)
+            ins = [a, gamma, beta] + ([r] if res is not None else [])
+            got = torch.autograd.grad((y * w).sum(), ins)
+            x = a if res is None else a + r
+            mean = x.mean(1, keepdim=True)
+            var = ((x - mean) ** 2).mean(1, keepdim=True)
+            ref = (x - mean) * torch.rsqrt(var + 1e-4) * gamma.view(1, -1, 1) + beta.view(1, -1, 1)
+            want = torch.autograd.grad((ref * w).sum(), ins)
+            assert float((y - ref).abs().max()) <= 1e-5
+            for gg_, ww_ in zip(got, want):
+                assert float((gg_ - ww_).abs().max()) <= 3e-5 * (1 + float(ww_.abs().max())), (B, C, T, res is None)

@@ -9,7 +9,9 @@ vs_conv_wgrad (csrc/conv_backward.hip), everything else is PyTorch-ROCm autograd
 inference modules; `tests/test_train_gpu.py` checks train-mode forward == eval-mode (fused HIP) forward and the
 gradients against the reference's own autograd (golden vectors).
 """
+import ctypes
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -240,18 +242,81 @@ def training_path(module):
 # module forwards (same reference lines as the inference modules)
 
 
+class GateFn(torch.autograd.Function):
+    """acts = tanh(x_in[:, :H] + g[:, :H]) * sigmoid(x_in[:, H:] + g[:, H:]) (encoder.py:177-180, 206-213): one HIP launch forward
+    (vs_gate_fwd), one backward (vs_gate_bwd: both halves of dx_in and the sum over t for dg), instead of ~15 PyTorch kernels.
+    g: [B, 2H, 1] (a slice of the cond_layer output: any batch stride) or None."""
+
+    @staticmethod
+    def forward(ctx, x_in, g):
+        lib = L.require_gpu()
+        x_in = x_in.contiguous()
+        B, H2, T = x_in.shape
+        acts = torch.empty((B, H2 // 2, T), device=x_in.device, dtype=torch.float32)
+        gp, gbs = (None, 0) if g is None else (ctypes.c_void_p(g.data_ptr()), g.stride(0))
+        L.check(lib.vs_gate_fwd(L.ptr(x_in), gp, gbs, L.ptr(acts), B, H2 // 2, T, L.stream_ptr()))
+        ctx.save_for_backward(x_in, g if g is not None else x_in.new_empty(0))
+        ctx.has_g = g is not None
+        return acts
+
+    @staticmethod
+    def backward(ctx, dacts):
+        lib = L.require_gpu()
+        x_in, g = ctx.saved_tensors
+        B, H2, T = x_in.shape
+        dacts = dacts.contiguous()
+        dx = torch.empty_like(x_in)
+        dg = torch.zeros((B, H2, 1), device=x_in.device, dtype=torch.float32) if (ctx.has_g and ctx.needs_input_grad[1]) else None
+        gp, gbs = (None, 0) if not ctx.has_g else (ctypes.c_void_p(g.data_ptr()), g.stride(0))
+        L.check(lib.vs_gate_bwd(L.ptr(x_in), gp, gbs, L.ptr(dacts), L.ptr(dx), L.ptr(dg), H2, B, H2 // 2, T, L.stream_ptr()))
+        return dx, dg
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm_C(a + r) * gamma + beta (rel_transformer.py:33-42 with the residual add of :305, :314 folded in): forward on
+    vs_layernorm_c_fwd (the inference kernel), backward on vs_layernorm_c_bwd -- two launches instead of ~30 PyTorch kernels."""
+
+    @staticmethod
+    def forward(ctx, a, r, gamma, beta, eps):
+        lib = L.require_gpu()
+        a = a.contiguous()
+        r = None if r is None else r.contiguous()
+        B, C, T = a.shape
+        y = torch.empty_like(a)
+        L.check(lib.vs_layernorm_c_fwd(L.ptr(a), L.ptr(r), L.ptr(gamma.detach().contiguous()), L.ptr(beta.detach().contiguous()), None, 0, 0,
+                                       None, L.ptr(y), B, C, T, eps, L.stream_ptr()))
+        ctx.save_for_backward(a, r if r is not None else a.new_empty(0), gamma)
+        ctx.has_r, ctx.eps = r is not None, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.require_gpu()
+        a, r, gamma = ctx.saved_tensors
+        B, C, T = a.shape
+        dx = torch.empty_like(a)
+        dgb = torch.zeros((2, C), device=a.device, dtype=torch.float32)
+        L.check(lib.vs_layernorm_c_bwd(L.ptr(a), L.ptr(r) if ctx.has_r else None, L.ptr(gamma.detach().contiguous()), L.ptr(dy.contiguous()),
+                                       L.ptr(dx), L.ptr(dgb[0]), L.ptr(dgb[1]), B, C, T, ctx.eps, L.stream_ptr()))
+        return dx, (dx if ctx.has_r else None), dgb[0], dgb[1], None
+
+
 def wavenet(m, x, x_mask, g=None):
     """encoder.py:167-195"""
     H = m.hidden_channels
     output = torch.zeros_like(x)
     if g is not None:
         g = conv(m.cond_layer, g)
+    fused = x.is_cuda and not os.environ.get("VS_NO_TRAIN_FUSED") and (m.p_dropout == 0 or not m.training)
     for i in range(m.n_layers):
         x_in = conv(m.in_layers[i], x)
-        if g is not None:
-            x_in = x_in + g[:, i * 2 * H:(i + 1) * 2 * H, :]
-        acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
-        acts = m.drop(acts)
+        if fused:
+            acts = GateFn.apply(x_in, None if g is None else g[:, i * 2 * H:(i + 1) * 2 * H, :])
+        else:
+            if g is not None:
+                x_in = x_in + g[:, i * 2 * H:(i + 1) * 2 * H, :]
+            acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
+            acts = m.drop(acts)
         rs = conv(m.res_skip_layers[i], acts)
         if i < m.n_layers - 1:
             x = (x + rs[:, :H]) * x_mask
@@ -335,8 +400,12 @@ def generator(m, x, g=None):
     return torch.tanh(conv(m.conv_post, x))
 
 
-def layer_norm(m, x):
-    """rel_transformer.py:33-42"""
+def layer_norm(m, x, r=None):
+    """rel_transformer.py:33-42 on x (+ r: the residual add of the encoder layers folded in)"""
+    if x.is_cuda and x.dim() == 3 and x.shape[1] <= 1024 and not os.environ.get("VS_NO_TRAIN_FUSED"):
+        return LayerNormFn.apply(x, r, m.gamma, m.beta, m.eps)
+    if r is not None:
+        x = x + r
     mean = torch.mean(x, 1, keepdim=True)
     var = torch.mean((x - mean) ** 2, 1, keepdim=True)
     x = (x - mean) * torch.rsqrt(var + m.eps)
@@ -396,7 +465,7 @@ def rel_encoder(m, x, x_mask, g=None):
             x = x + g
         x = x * x_mask
         y = m.drop(attention(m.attn_layers[i], x, fm))
-        x = layer_norm(m.norm_layers_1[i], x + y)
+        x = layer_norm(m.norm_layers_1[i], x, y)
         y = m.drop(ffn(m.ffn_layers[i], x, x_mask))
-        x = layer_norm(m.norm_layers_2[i], x + y)
+        x = layer_norm(m.norm_layers_2[i], x, y)
     return x * x_mask

@@ -1,0 +1,178 @@
+// train_ops.hip -- fused elementwise kernels of the TRAINING path: the neighbours of the convs that the inference
+// path folds into conv epilogues, here as one forward and one backward launch each instead of 10-25 PyTorch elementwise kernels
+// (the GAN step at B=16, T_mel=512 is bound by launch count and small-kernel time):
+//   vs_gate_fwd / vs_gate_bwd            WaveNet gate  acts = tanh(a + g_a) * sigmoid(b + g_b)         (encoder.py:206-213)
+//   vs_layernorm_c_bwd                   channel LayerNorm backward (forward: vs_layernorm_c_fwd)      (rel_transformer.py:33-42)
+// All HBM-bound: every tensor is read once and written once; reductions over channels in registers + one LDS exchange, reductions
+// over (batch, time) as one float atomic per channel and 64-frame block.
+#include "vs_internal.h"
+
+namespace vs {
+
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// x_in [B, 2H, T] (rows c: tanh half, rows H + c: sigmoid half); g: optional per-item bias [B, >= 2H] with row stride g_bs
+__global__ void __launch_bounds__(256) gate_fwd_kernel(const float *__restrict__ x_in, const float *__restrict__ g, long long g_bs,
+                                                       float *__restrict__ acts, int H, int T) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t >= T) return;
+    const float ga = g ? g[(long long)b * g_bs + c] : 0.f, gb = g ? g[(long long)b * g_bs + H + c] : 0.f;
+    const float *pa = x_in + ((long long)b * 2 * H + c) * T + t, *pb = pa + (long long)H * T;
+    float *po = acts + ((long long)b * H + c) * T + t;
+    if (t + 4 <= T && (T & 3) == 0) {
+        const float4 a = *reinterpret_cast<const float4 *>(pa), s = *reinterpret_cast<const float4 *>(pb);
+        float4 o;
+        o.x = tanhf(a.x + ga) * sigm(s.x + gb); o.y = tanhf(a.y + ga) * sigm(s.y + gb);
+        o.z = tanhf(a.z + ga) * sigm(s.z + gb); o.w = tanhf(a.w + ga) * sigm(s.w + gb);
+        *reinterpret_cast<float4 *>(po) = o;
+    } else {
+        for (int i = 0; i < 4 && t + i < T; ++i) po[i] = tanhf(pa[i] + ga) * sigm(pb[i] + gb);
+    }
+}
+
+// dx_in[:, c] = dacts * s * (1 - th^2), dx_in[:, H + c] = dacts * th * s * (1 - s); dg[b, row] += sum_t dx_in (atomic per block)
+__global__ void __launch_bounds__(256) gate_bwd_kernel(const float *__restrict__ x_in, const float *__restrict__ g, long long g_bs,
+                                                       const float *__restrict__ dacts, float *__restrict__ dx_in, float *__restrict__ dg,
+                                                       long long dg_bs, int H, int T) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const float ga = g ? g[(long long)b * g_bs + c] : 0.f, gb = g ? g[(long long)b * g_bs + H + c] : 0.f;
+    float sa = 0.f, sb = 0.f;
+    if (t < T) {
+        const float *pa = x_in + ((long long)b * 2 * H + c) * T + t, *pb = pa + (long long)H * T;
+        const float *pd = dacts + ((long long)b * H + c) * T + t;
+        float *qa = dx_in + ((long long)b * 2 * H + c) * T + t, *qb = qa + (long long)H * T;
+        for (int i = 0; i < 4 && t + i < T; ++i) {
+            const float th = tanhf(pa[i] + ga), s = sigm(pb[i] + gb), d = pd[i];
+            const float da = d * s * (1.f - th * th), db = d * th * s * (1.f - s);
+            qa[i] = da;
+            qb[i] = db;
+            sa += da;
+            sb += db;
+        }
+    }
+    if (dg) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[0][w] = sa; red[1][w] = sb; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(dg + (long long)b * dg_bs + c, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            atomicAdd(dg + (long long)b * dg_bs + H + c, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        }
+    }
+}
+
+// LayerNorm over channels, backward.  x = a (+ r) [B, C, T]; y = xhat * gamma + beta, xhat = (x - mean_c) * rstd.
+//   dxhat = dy * gamma;  dx = rstd * (dxhat - mean_c(dxhat) - xhat * mean_c(dxhat * xhat));  dgamma[c] = sum_{b,t} dy * xhat;  dbeta[c] = sum dy
+// block = G channel groups x 64 frames (as layernorm_c_kernel); each thread keeps its C/G channel values in registers.
+template <int G, int PT>
+__global__ void __launch_bounds__(64 * G) layernorm_c_bwd_kernel(const float *__restrict__ a, const float *__restrict__ r,
+                                                                const float *__restrict__ gamma, const float *__restrict__ dy,
+                                                                float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                int C, int T, float eps) {
+    __shared__ float red[G][64];
+    const int tl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + tl;
+    const bool okt = t < T;
+    const int tc = min(t, T - 1);
+    const long long base = (long long)b * C * T + tc;
+    float x[PT], d[PT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int c = grp + G * i, cc = min(c, C - 1);
+        float v = a[base + (long long)cc * T];
+        if (r) v += r[base + (long long)cc * T];
+        x[i] = (c < C) ? v : 0.f;
+        d[i] = (c < C && okt) ? dy[base + (long long)cc * T] : 0.f;
+        sum += x[i];
+    }
+    auto block_sum = [&](float v) {
+        red[grp][tl] = v;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < G; ++gI) tot += red[gI][tl];
+        __syncthreads();
+        return tot;
+    };
+    const float mean = block_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int c = grp + G * i;
+        const float dd = (c < C) ? x[i] - mean : 0.f;
+        sq += dd * dd;
+    }
+    const float rstd = rsqrtf(block_sum(sq) / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int c = grp + G * i;
+        const float xh = (c < C) ? (x[i] - mean) * rstd : 0.f;
+        const float dxh = (c < C) ? d[i] * gamma[min(c, C - 1)] : 0.f;
+        x[i] = xh;                       // keep xhat
+        s1 += dxh;
+        s2 += dxh * xh;
+    }
+    const float m1 = block_sum(s1) / (float)C, m2 = block_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int c = grp + G * i;
+        if (c < C) {
+            const float dxh = d[i] * gamma[c];
+            if (okt) dx[base + (long long)c * T] = rstd * (dxh - m1 - x[i] * m2);
+            // dgamma / dbeta: reduce over the 64 frames of this block, one atomic per channel
+            float pg = d[i] * x[i], pb = d[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { pg += __shfl_xor(pg, o); pb += __shfl_xor(pb, o); }
+            if (tl == 0) { atomicAdd(dgamma + c, pg); atomicAdd(dbeta + c, pb); }
+        }
+    }
+}
+
+}  // namespace vs
+
+using namespace vs;
+
+extern "C" {
+
+int vs_gate_fwd(const float *x_in, const float *g, int64_t g_bs, float *acts, int64_t B, int64_t H, int64_t T, void *stream) {
+    VS_REQUIRE(x_in && acts && B > 0 && B <= 65535 && H > 0 && H <= 65535 && T > 0, "vs_gate_fwd: bad arguments");
+    dim3 grid((unsigned)ceil_div(T, 1024), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(gate_fwd_kernel, grid, dim3(256), 0, as_stream(stream), x_in, g, (long long)g_bs, acts, (int)H, (int)T);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const float *dacts, float *dx_in, float *dg, int64_t dg_bs, int64_t B,
+                int64_t H, int64_t T, void *stream) {
+    VS_REQUIRE(x_in && dacts && dx_in && B > 0 && B <= 65535 && H > 0 && H <= 65535 && T > 0, "vs_gate_bwd: bad arguments");
+    dim3 grid((unsigned)ceil_div(T, 1024), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(gate_bwd_kernel, grid, dim3(256), 0, as_stream(stream), x_in, g, (long long)g_bs, dacts, dx_in, dg, (long long)dg_bs,
+                       (int)H, (int)T);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const float *dy, float *dx, float *dgamma, float *dbeta,
+                       int64_t B, int64_t C, int64_t T, float eps, void *stream) {
+    VS_REQUIRE(a && gamma && dy && dx && dgamma && dbeta && B > 0 && B <= 65535 && C > 0 && T > 0, "vs_layernorm_c_bwd: bad arguments");
+    hipStream_t s = as_stream(stream);
+    dim3 grid((unsigned)ceil_div(T, 64), (unsigned)B);
+    const int Ci = (int)C, Ti = (int)T;
+    if (C <= 4 * 16) hipLaunchKernelGGL((layernorm_c_bwd_kernel<4, 16>), grid, dim3(256), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
+    else if (C <= 4 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<4, 64>), grid, dim3(256), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
+    else if (C <= 8 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<8, 64>), grid, dim3(512), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
+    else if (C <= 16 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<16, 64>), grid, dim3(1024), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
+    else { set_error("vs_layernorm_c_bwd: C=%lld > 1024 unsupported", (long long)C); return VS_EUNSUPPORTED; }
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+}  // extern "C"
