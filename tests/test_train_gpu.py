@@ -224,3 +224,25 @@ def test_fused_gate_and_layernorm_functions_match_torch_autograd():
             assert float((y - ref).abs().max()) <= 1e-5
             for gg_, ww_ in zip(got, want):
                 assert float((gg_ - ww_).abs().max()) <= 3e-5 * (1 + float(ww_.abs().max())), (B, C, T, res is None)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,d,T,B", [(192, 384, 5, 1, 512, 4), (192, 768, 9, 1, 64, 8), (128, 128, 11, 5, 2048, 2), (64, 64, 3, 3, 1000, 2),
+                                              (96, 200, 7, 1, 516, 2), (32, 64, 11, 1, 8192, 1), (256, 256, 7, 3, 256, 3), (100, 130, 2, 1, 260, 2)])
+def test_wgrad_split_kernel_matches_aten(Cin, Cout, K, d, T, B):
+    """vs_conv_wgrad on the bf16 matrix instruction in the split-bf16 x6 arithmetic (csrc/conv_backward.hip conv_wgrad_split_kernel: 2..12
+    taps, >= 64 output channels): weight gradient vs aten::convolution_backward in fp32 -- both tap layouts (all taps per wave; taps split
+    over wave pairs for K > 8), even and odd tap offsets (the v_alignbyte path), dilations, channel counts off the tile sizes, a ragged
+    last unit."""
+    from visinger_amd.ops import conv_wgrad
+    torch.manual_seed(Cin + Cout + K + T)
+    pad = d * (K - 1) // 2
+    x = torch.randn(B, Cin, T, device="cuda")
+    gy = torch.randn(B, Cout, T, device="cuda")
+    w = torch.zeros(Cout, Cin, K, device="cuda")
+    got = conv_wgrad(gy, x, K, d, pad)
+    _, ref, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [1], [pad], [d], False, [0], 1, [False, True, False])
+    ref64 = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1], [pad], [d], False, [0], 1, [False, True, False])[1]
+    e_got = float((got.double() - ref64).abs().max()), float((ref.double() - ref64).abs().max())
+    scale = float(ref64.abs().max())
+    assert got.shape == ref.shape
+    assert e_got[0] <= 3e-6 * scale + 2.5 * e_got[1], (e_got, scale)        # fp32 class: within the library's own error of the fp64 result

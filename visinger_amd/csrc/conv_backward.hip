@@ -16,9 +16,10 @@
 // The grad-INPUT of a conv is a forward conv with reversed / transposed weights and runs on conv_engine.hip
 // (visinger_amd/autograd.py::conv_backward); a transposed conv's weight gradient is this kernel with the roles of x and gy
 // swapped over the de-interleaved phases of gy.
-#include "vs_internal.h"
+#include "conv_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace vs {
 
@@ -116,6 +117,128 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same reduction on the bf16 matrix instruction in the split-bf16 x6 arithmetic of conv_split.hip (fp32 class), for the convs
+// with 2..12 taps and >= 64 output channels that dominate the weight-gradient time of the training step (WaveNet k = 5, FFN k = 9,
+// the MRF convs: tools/wgrad_breakdown.py measured the kernel above at 24-44 TFLOP/s on them).
+//   D[co][ci] (one accumulator tile per tap) += sum over 16 consecutive positions:  A = gy[co][t .. t+15],  B = x[ci][t + k d - p ..]
+// Both operands are contiguous along the contraction index t in memory, so a fragment is 8 consecutive positions of one row:
+//   * gy: fp32 tile [128 co][64 t] in LDS; a wave (one 32-row co tile) reads its A fragment as two aligned ds_read_b128 and splits
+//     it ONCE per 16-position step for all taps (44 VALU per 6 K MFMAs);
+//   * x: split into bf16 planes while staged, [plane][32 ci][136 positions] row-major along t; a tap's B fragment starts at an
+//     arbitrary position: five ds_read_b32 per plane from the 4-byte-aligned dword below it, and for odd offsets a v_alignbyte per
+//     dword -- no transposition, no per-tap copy of the tile;
+//   * a wave keeps one accumulator tile per tap (up to 12: 192 registers); workgroup = 128 co x 32 ci, 60 KB of LDS, two per CU;
+//   * partial planes per reduction slice as above (deterministic, summed by the caller).
+constexpr int WS_TU = 64;                     // positions per unit
+constexpr int WS_GP = WS_TU + 4;              // gy tile row pitch in floats (272 B = 17 x 16: conflict-free ds_read_b128 down the rows)
+constexpr int WS_XW = WS_TU + WG_MAXSPAN + 8; // staged x positions per row (136)
+constexpr int WS_XP = WS_XW / 2 + 1;          // x plane row pitch in dwords (69: odd)
+constexpr int WS_MAXK = 12;
+
+// KT taps per wave; TS = 1: four co tiles per workgroup (128 rows), every wave all K <= KT taps; TS = 2 (K > 8): two co tiles (64 rows),
+// the two waves of a tile take the taps [0, KT) and [KT, 2 KT) -- 12 accumulator tiles next to the fragments do not fit 256 registers.
+template <int KT, int TS>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradParams p) {
+    constexpr int CO_T = 128 / TS;
+    __shared__ __attribute__((aligned(16))) float Gs[128 * WS_GP];
+    __shared__ unsigned Xp[3 * 32 * WS_XP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lhalf = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * CO_T;
+    const int cot = wave / TS;                       // this wave's 32-row co tile within the workgroup
+    const int tapb = (wave % TS) * KT;               // its first tap
+    f32x16 acc[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int u = blockIdx.z; u < p.units; u += gridDim.z) {
+        const int b = u / p.units_per_item;
+        const int t0 = (u - b * p.units_per_item) * WS_TU;
+        const float *gyb = p.gy + (long long)b * p.Cout * p.Tout;
+        const float *xb = p.x + (long long)b * p.Cin * p.Tin;
+        __syncthreads();                               // previous unit's fragments are consumed
+        // gy tile: CO_T rows x 16 float4 (T_out % 4 == 0, rows 16-byte aligned: host-checked)
+#pragma unroll
+        for (int i = 0; i < 8 / TS; ++i) {
+            const int e = tid + 256 * i;
+            const int row = e >> 4, c4 = (e & 15) * 4;
+            const int co = co0 + row, t = t0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < p.Cout && t < p.Tout) v = *reinterpret_cast<const float4 *>(gyb + (long long)co * p.Tout + t);
+            *reinterpret_cast<float4 *>(Gs + row * WS_GP + c4) = v;
+        }
+        // x tile: 32 rows x 68 position pairs, split exactly into three bf16 planes (one dword per pair and plane)
+        for (int e = tid; e < 32 * (WS_XW / 2); e += 256) {
+            const int row = e / (WS_XW / 2), pr = e - row * (WS_XW / 2);
+            const int ci = ci0 + row, n = t0 - p.pad + 2 * pr;
+            float v0 = 0.f, v1 = 0.f;
+            if (ci < p.Cin) {
+                const float *xr = xb + (long long)ci * p.Tin;
+                if (n >= 0 && n < p.Tin) v0 = xr[n];
+                if (n + 1 >= 0 && n + 1 < p.Tin) v1 = xr[n + 1];
+            }
+            unsigned d[3];
+            split_pair<3>(v0, v1, d);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Xp[(pl * 32 + row) * WS_XP + pr] = d[pl];
+        }
+        __syncthreads();
+        const float *ga = Gs + (cot * 32 + l31) * WS_GP + 8 * lhalf;
+#pragma unroll
+        for (int ks = 0; ks < WS_TU / 16; ++ks) {
+            // A: 8 consecutive positions of this lane's gy row, split once for all taps
+            const float4 g0 = *reinterpret_cast<const float4 *>(ga + 16 * ks), g1 = *reinterpret_cast<const float4 *>(ga + 16 * ks + 4);
+            unsigned a0[3], a1[3], a2[3], a3[3];
+            split_pair<3>(g0.x, g0.y, a0); split_pair<3>(g0.z, g0.w, a1); split_pair<3>(g1.x, g1.y, a2); split_pair<3>(g1.z, g1.w, a3);
+            u32x4 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { af[pl].x = a0[pl]; af[pl].y = a1[pl]; af[pl].z = a2[pl]; af[pl].w = a3[pl]; }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                if (tapb + k < p.K) {                                // (wave-uniform; taps beyond K keep their zero accumulators)
+                    const int e = 16 * ks + 8 * lhalf + (tapb + k) * p.dil;   // first position of the fragment in the staged row
+                    const int q = e >> 1;
+                    const bool odd = (e & 1) != 0;                   // = (tap * dil) & 1: wave-uniform
+                    auto mm = [&](int ta, const u32x4 &bq) __attribute__((always_inline)) {
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ta]), __builtin_bit_cast(bf16x8, bq),
+                                                                        acc[k], 0, 0, 0);
+                    };
+                    // one B plane at a time (4 registers live instead of 12 next to up to 192 accumulators): x_l with gy_h; x_m with
+                    // gy_m, gy_h; x_h with gy_l, gy_m, gy_h -- the six leading cross products, small terms first within a plane
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl) {
+                        const unsigned *xr = Xp + (pl * 32 + l31) * WS_XP + q;
+                        const unsigned d0 = xr[0], d1 = xr[1], d2 = xr[2], d3 = xr[3], d4 = xr[4];
+                        u32x4 bq;
+                        bq.x = odd ? __builtin_amdgcn_alignbyte(d1, d0, 2) : d0;
+                        bq.y = odd ? __builtin_amdgcn_alignbyte(d2, d1, 2) : d1;
+                        bq.z = odd ? __builtin_amdgcn_alignbyte(d3, d2, 2) : d2;
+                        bq.w = odd ? __builtin_amdgcn_alignbyte(d4, d3, 2) : d3;
+                        if (pl == 2) { mm(0, bq); }
+                        else if (pl == 1) { mm(1, bq); mm(0, bq); }
+                        else { mm(2, bq); mm(1, bq); mm(0, bq); }
+                    }
+                }
+            }
+        }
+    }
+    float *plane = p.gw + (long long)blockIdx.z * p.Cout * p.Cin * p.K;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        if (tapb + k < p.K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf, ci = ci0 + l31;
+                if (co < p.Cout && ci < p.Cin) plane[((long long)co * p.Cin + ci) * p.K + tapb + k] = acc[k][r];
+            }
+        }
+    }
+}
+
 }  // namespace vs
 
 using namespace vs;
@@ -128,8 +251,19 @@ static int wgrad_slices(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(units, ceil_div(1024, tiles)));
 }
 
+// the split-bf16 kernel: 2..12 taps, >= 64 output channels, float4-loadable gy rows, enough positions to fill its 64-position units
+static bool wgrad_split_ok(int64_t B, int64_t c_out, int64_t T_out, int k) {
+    return k >= 2 && k <= WS_MAXK && c_out >= 64 && (T_out % 4) == 0 && B * T_out >= 512 && !getenv("VS_NO_WGRAD_SPLIT");
+}
+static int wgrad_split_slices(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out) {
+    const int64_t units = B * ceil_div(T_out, WS_TU);
+    const int64_t tiles = ceil_div(c_in, 32) * ceil_div(c_out, 128);      // (64-row tiles for K > 8: up to twice the workgroups)
+    return (int)std::max<int64_t>(1, std::min<int64_t>(units, ceil_div(512, tiles)));
+}
+
 int vs_conv_wgrad_planes(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out, int k) {
     if (B <= 0 || c_out <= 0 || c_in <= 0 || T_out <= 0 || k < 1) return 0;
+    if (wgrad_split_ok(B, c_out, T_out, k)) return wgrad_split_slices(B, c_out, c_in, T_out);
     return wgrad_slices(B, c_out, c_in, T_out) * (k > WG_MAXTAPS ? 1 : 4);
 }
 
@@ -142,6 +276,17 @@ int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, 
     p.gy = gy; p.x = x; p.gw = gw_planes;
     p.B = (int)B; p.Cout = (int)c_out; p.Cin = (int)c_in; p.Tout = (int)T_out; p.Tin = (int)T_in;
     p.K = k; p.dil = dil; p.pad = pad;
+    if (wgrad_split_ok(B, c_out, T_out, k) && (reinterpret_cast<uintptr_t>(gy) & 15u) == 0) {
+        p.units_per_item = (int)ceil_div(T_out, WS_TU);
+        p.units = p.B * p.units_per_item;
+        dim3 grid((unsigned)ceil_div(c_in, 32), (unsigned)ceil_div(c_out, k <= 8 ? 128 : 64), (unsigned)wgrad_split_slices(B, c_out, c_in, T_out));
+        hipStream_t s = as_stream(stream);
+        if (k <= 4) hipLaunchKernelGGL((conv_wgrad_split_kernel<4, 1>), grid, dim3(256), 0, s, p);
+        else if (k <= 8) hipLaunchKernelGGL((conv_wgrad_split_kernel<8, 1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_wgrad_split_kernel<6, 2>), grid, dim3(256), 0, s, p);
+        VS_CHECK_HIP(hipGetLastError());
+        return VS_OK;
+    }
     p.units_per_item = (int)ceil_div(T_out, WG_TCH);
     p.units = p.B * p.units_per_item;
     dim3 grid((unsigned)ceil_div(c_in, 32), (unsigned)ceil_div(c_out, 32), (unsigned)wgrad_slices(B, c_out, c_in, T_out));

@@ -314,6 +314,11 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
     gy, x = gy.contiguous().float(), x.contiguous().float()
     B, Cout, Tout = gy.shape
     Cin, Tin = x.shape[1], x.shape[2]
+    if k == 1 and pad == 0 and Tin == Tout and Cout * Cin >= 64 * 64 and not os.environ.get("VS_NO_WGRAD_GEMM"):
+        # a 1x1 conv's weight gradient is a plain GEMM [Cout x B*T] . [B*T x Cin]: library territory (hipBLASLt through torch, as the
+        # wide discriminator layers already do); vs_conv_wgrad's 32 x 32 tiles with the positions split over the waves ran it at
+        # 7-9 TFLOP/s (tools/wgrad_breakdown.py: 94 calls, 11.8 ms of the config-3 step)
+        return torch.einsum("bot,bit->oi", gy, x).unsqueeze(2)
     planes = lib.vs_conv_wgrad_planes(B, Cout, Cin, Tout, int(k))
     part = torch.empty((planes, Cout, Cin, k), device=x.device, dtype=torch.float32)
     L.check(lib.vs_conv_wgrad(L.ptr(gy), L.ptr(x), L.ptr(part), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad), L.stream_ptr()))
