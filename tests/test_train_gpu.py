@@ -227,7 +227,7 @@ def test_fused_gate_and_layernorm_functions_match_torch_autograd():
 
 
 @pytest.mark.parametrize("Cin,Cout,K,d,T,B", [(192, 384, 5, 1, 512, 4), (192, 768, 9, 1, 64, 8), (128, 128, 11, 5, 2048, 2), (64, 64, 3, 3, 1000, 2),
-                                              (96, 200, 7, 1, 516, 2), (32, 64, 11, 1, 8192, 1), (256, 256, 7, 3, 256, 3), (100, 130, 2, 1, 260, 2)])
+                                              (96, 200, 7, 1, 516, 2), (32, 64, 11, 1, 8192, 1), (256, 256, 7, 3, 256, 3), (100, 130, 2, 1, 261, 2), (64, 96, 8, 1, 519, 2), (64, 128, 4, 1, 1027, 1), (80, 64, 6, 1, 133, 4)])
 def test_wgrad_split_kernel_matches_aten(Cin, Cout, K, d, T, B):
     """vs_conv_wgrad on the bf16 matrix instruction in the split-bf16 x6 arithmetic (csrc/conv_backward.hip conv_wgrad_split_kernel: 2..12
     taps, >= 64 output channels): weight gradient vs aten::convolution_backward in fp32 -- both tap layouts (all taps per wave; taps split
@@ -237,7 +237,7 @@ def test_wgrad_split_kernel_matches_aten(Cin, Cout, K, d, T, B):
     torch.manual_seed(Cin + Cout + K + T)
     pad = d * (K - 1) // 2
     x = torch.randn(B, Cin, T, device="cuda")
-    gy = torch.randn(B, Cout, T, device="cuda")
+    gy = torch.randn(B, Cout, T + 2 * pad - d * (K - 1), device="cuda")        # (K = 2: an even kernel, T_out = T - 1)
     w = torch.zeros(Cout, Cin, K, device="cuda")
     got = conv_wgrad(gy, x, K, d, pad)
     _, ref, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [1], [pad], [d], False, [0], 1, [False, True, False])

@@ -171,20 +171,33 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
             if (co < p.Cout && t < p.Tout) v = *reinterpret_cast<const float4 *>(gyb + (long long)co * p.Tout + t);
             *reinterpret_cast<float4 *>(Gs + row * WS_GP + c4) = v;
         }
-        // x tile: 32 rows x 68 position pairs, split exactly into three bf16 planes (one dword per pair and plane)
-        for (int e = tid; e < 32 * (WS_XW / 2); e += 256) {
+        // x tile: 32 rows x 68 position pairs, split exactly into three bf16 planes (one dword per pair and plane); all loads of a
+        // thread are issued before the first split (a rolled loop waited for each pair's loads in turn: 9 exposed round trips per unit)
+        constexpr int XPAIRS = 32 * (WS_XW / 2), XIT = (XPAIRS + 255) / 256;
+        float xv[XIT][2];
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            const int e = min(tid + 256 * i, XPAIRS - 1);
             const int row = e / (WS_XW / 2), pr = e - row * (WS_XW / 2);
-            const int ci = ci0 + row, n = t0 - p.pad + 2 * pr;
-            float v0 = 0.f, v1 = 0.f;
-            if (ci < p.Cin) {
-                const float *xr = xb + (long long)ci * p.Tin;
-                if (n >= 0 && n < p.Tin) v0 = xr[n];
-                if (n + 1 >= 0 && n + 1 < p.Tin) v1 = xr[n + 1];
-            }
+            const int ci = min(ci0 + row, p.Cin - 1), n = t0 - p.pad + 2 * pr;
+            const float *xr = xb + (long long)ci * p.Tin;
+            xv[i][0] = xr[min(max(n, 0), p.Tin - 1)];
+            xv[i][1] = xr[min(max(n + 1, 0), p.Tin - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            const int e = tid + 256 * i;
+            const int row = e / (WS_XW / 2), pr = e - row * (WS_XW / 2);
+            const int n = t0 - p.pad + 2 * pr;
+            const bool okr = (ci0 + row < p.Cin);
+            const float v0 = (okr && n >= 0 && n < p.Tin) ? xv[i][0] : 0.f;
+            const float v1 = (okr && n + 1 >= 0 && n + 1 < p.Tin) ? xv[i][1] : 0.f;
             unsigned d[3];
             split_pair<3>(v0, v1, d);
+            if (e < XPAIRS) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) Xp[(pl * 32 + row) * WS_XP + pr] = d[pl];
+                for (int pl = 0; pl < 3; ++pl) Xp[(pl * 32 + row) * WS_XP + pr] = d[pl];
+            }
         }
         __syncthreads();
         const float *ga = Gs + (cot * 32 + l31) * WS_GP + 8 * lhalf;
@@ -197,31 +210,37 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
             u32x4 af[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) { af[pl].x = a0[pl]; af[pl].y = a1[pl]; af[pl].z = a2[pl]; af[pl].w = a3[pl]; }
+            // B: per tap the 3 x 5 dwords that hold its fragment (one tap ahead of the MFMAs), then v_alignbyte for odd offsets
+            unsigned raw[2][3][5];
+            auto load_raw = [&](unsigned (&dst)[3][5], int k) __attribute__((always_inline)) {
+                const int q = (16 * ks + 8 * lhalf + (tapb + k) * p.dil) >> 1;      // 4-byte-aligned dword below the fragment's first position
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned *xr = Xp + (pl * 32 + l31) * WS_XP + q;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) dst[pl][i] = xr[i];
+                }
+            };
+            load_raw(raw[0], 0);
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                if (tapb + k < p.K) {                                // (wave-uniform; taps beyond K keep their zero accumulators)
-                    const int e = 16 * ks + 8 * lhalf + (tapb + k) * p.dil;   // first position of the fragment in the staged row
-                    const int q = e >> 1;
-                    const bool odd = (e & 1) != 0;                   // = (tap * dil) & 1: wave-uniform
-                    auto mm = [&](int ta, const u32x4 &bq) __attribute__((always_inline)) {
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ta]), __builtin_bit_cast(bf16x8, bq),
+                if (k + 1 < KT) load_raw(raw[(k + 1) & 1], k + 1);
+                if (tapb + k < p.K) {                                // (wave-uniform: only the last tap of the second tap-half can be absent)
+                    const bool odd = (((tapb + k) * p.dil) & 1) != 0;             // wave-uniform
+                    u32x4 bf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned(&d)[5] = raw[k & 1][pl];
+                        bf[pl].x = odd ? __builtin_amdgcn_alignbyte(d[1], d[0], 2) : d[0];
+                        bf[pl].y = odd ? __builtin_amdgcn_alignbyte(d[2], d[1], 2) : d[1];
+                        bf[pl].z = odd ? __builtin_amdgcn_alignbyte(d[3], d[2], 2) : d[2];
+                        bf[pl].w = odd ? __builtin_amdgcn_alignbyte(d[4], d[3], 2) : d[3];
+                    }
+                    auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ta]), __builtin_bit_cast(bf16x8, bf[tb]),
                                                                         acc[k], 0, 0, 0);
                     };
-                    // one B plane at a time (4 registers live instead of 12 next to up to 192 accumulators): x_l with gy_h; x_m with
-                    // gy_m, gy_h; x_h with gy_l, gy_m, gy_h -- the six leading cross products, small terms first within a plane
-#pragma unroll
-                    for (int pl = 2; pl >= 0; --pl) {
-                        const unsigned *xr = Xp + (pl * 32 + l31) * WS_XP + q;
-                        const unsigned d0 = xr[0], d1 = xr[1], d2 = xr[2], d3 = xr[3], d4 = xr[4];
-                        u32x4 bq;
-                        bq.x = odd ? __builtin_amdgcn_alignbyte(d1, d0, 2) : d0;
-                        bq.y = odd ? __builtin_amdgcn_alignbyte(d2, d1, 2) : d1;
-                        bq.z = odd ? __builtin_amdgcn_alignbyte(d3, d2, 2) : d2;
-                        bq.w = odd ? __builtin_amdgcn_alignbyte(d4, d3, 2) : d3;
-                        if (pl == 2) { mm(0, bq); }
-                        else if (pl == 1) { mm(1, bq); mm(0, bq); }
-                        else { mm(2, bq); mm(1, bq); mm(0, bq); }
-                    }
+                    mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0);      // smallest terms first
                 }
             }
         }
@@ -279,11 +298,19 @@ int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, 
     if (wgrad_split_ok(B, c_out, T_out, k) && (reinterpret_cast<uintptr_t>(gy) & 15u) == 0) {
         p.units_per_item = (int)ceil_div(T_out, WS_TU);
         p.units = p.B * p.units_per_item;
-        dim3 grid((unsigned)ceil_div(c_in, 32), (unsigned)ceil_div(c_out, k <= 8 ? 128 : 64), (unsigned)wgrad_split_slices(B, c_out, c_in, T_out));
+        dim3 grid((unsigned)ceil_div(c_in, 32), (unsigned)ceil_div(c_out, k < 8 ? 128 : 64), (unsigned)wgrad_split_slices(B, c_out, c_in, T_out));
         hipStream_t s = as_stream(stream);
-        if (k <= 4) hipLaunchKernelGGL((conv_wgrad_split_kernel<4, 1>), grid, dim3(256), 0, s, p);
-        else if (k <= 8) hipLaunchKernelGGL((conv_wgrad_split_kernel<8, 1>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_wgrad_split_kernel<6, 2>), grid, dim3(256), 0, s, p);
+        switch (k) {      // KT = the taps a wave really has: no idle accumulator tiles, registers left for the one-tap-ahead reads
+            case 2: hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_wgrad_split_kernel<3, 1>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_wgrad_split_kernel<4, 1>), grid, dim3(256), 0, s, p); break;
+            case 5: hipLaunchKernelGGL((conv_wgrad_split_kernel<5, 1>), grid, dim3(256), 0, s, p); break;
+            case 6: hipLaunchKernelGGL((conv_wgrad_split_kernel<6, 1>), grid, dim3(256), 0, s, p); break;
+            case 7: hipLaunchKernelGGL((conv_wgrad_split_kernel<7, 1>), grid, dim3(256), 0, s, p); break;
+            case 8: hipLaunchKernelGGL((conv_wgrad_split_kernel<4, 2>), grid, dim3(256), 0, s, p); break;      // (8 tiles + the look-ahead spill)
+            case 9: case 10: hipLaunchKernelGGL((conv_wgrad_split_kernel<5, 2>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_wgrad_split_kernel<6, 2>), grid, dim3(256), 0, s, p); break;
+        }
         VS_CHECK_HIP(hipGetLastError());
         return VS_OK;
     }
