@@ -88,6 +88,23 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
 
     auto acc_row = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lhalf; };
 
+    // The residual input of the epilogue is x itself (decoder.py:101 `x = xt + x`): the same lines this workgroup is about to stage.
+    // Its float4 reads are issued HERE, next to the staging loads, and held in registers (8 * NIT per lane) through both convs:
+    // requested 40 us later they had left L2 and came from memory again (4.0 GB of traffic per launch against 3.2 GB compulsory,
+    // profiles/r02_b_pmc_traffic.json), and the epilogue waited for them.
+    constexpr int E_CW = 32 * NT_W, E_LPR = E_CW / 4, E_RPI = 64 / E_LPR, E_NIT = 8 / E_RPI;
+    const bool fast_tile = p.fast_epi && (n0 + NOUT <= p.T);
+    const bool e_live = (wn * E_CW + (lane % E_LPR) * 4) < NOUT;
+    float4 r4[4][E_NIT];
+    if (fast_tile && e_live && p.res) {
+        const float *const resp0 = p.res + (long long)b * p.res_bs;
+        const long long goff0 = (long long)(wm * 32 + lane / E_LPR) * p.T + n0 + wn * E_CW + (lane % E_LPR) * 4;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+            for (int it = 0; it < E_NIT; ++it) r4[ps][it] = *reinterpret_cast<const float4 *>(resp0 + goff0 + (long long)(8 * ps + it * E_RPI) * p.T);
+    }
+
     // ------------------------------------------------------------------------------------------- phase 1: conv1(lrelu(x))
     f32x16 acc[NT_W];
 #pragma unroll
@@ -269,22 +286,20 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     float *const yb = p.y + (long long)b * p.y_bs;
     const float *const resp = has_res ? p.res + (long long)b * p.res_bs : nullptr;
     const float *const accp = has_acc ? p.acc + (long long)b * p.acc_bs : nullptr;
-    if (p.fast_epi && n0 + NOUT <= p.T) {
-        constexpr int CW = 32 * NT_W, LPR = CW / 4, RPI = 64 / LPR, NIT = 8 / RPI;
+    if (fast_tile) {
+        constexpr int CW = E_CW, LPR = E_LPR, RPI = E_RPI, NIT = E_NIT;
         float *const Lw = smem + wave * 8 * CW;
         const int lrow = lane / LPR, c4 = (lane % LPR) * 4;
         const int ctile = wn * CW + c4;                          // column within the tile
         const bool live = ctile < NOUT;                          // NOUT % 4 == 0: a float4 is all in or all out
         const long long goff0 = (long long)(tile_row0 + lrow) * p.T + n0 + ctile;
-        float4 r4[4][NIT], a4[4][NIT];
+        float4 a4[4][NIT];
+        if (live && has_acc) {
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
+            for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const long long off = goff0 + (long long)(8 * ps + it * RPI) * p.T;
-                if (live && has_res) r4[ps][it] = *reinterpret_cast<const float4 *>(resp + off);
-                if (live && has_acc) a4[ps][it] = *reinterpret_cast<const float4 *>(accp + off);
-            }
+                for (int it = 0; it < NIT; ++it) a4[ps][it] = *reinterpret_cast<const float4 *>(accp + goff0 + (long long)(8 * ps + it * RPI) * p.T);
+        }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
 #pragma unroll
