@@ -183,6 +183,16 @@ VS_API int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma
                               float *dbeta, int64_t B, int64_t C, int64_t T, float eps, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * f2  on-device linear / mel spectrograms (utils/audio/mel_processing.py:15-38: torchaudio Spectrogram / MelSpectrogram, power 2).
+ *     The framed windowed DFT is a strided conv of the reflect-padded waveform with the (cos | -sin) * hann basis and the mel
+ *     projection a 1x1 conv with the HTK filterbank: both run on vs_conv_forward (visinger_amd/audio.py builds the two bases).
+ *     Between them:  p[b, f, t] = y[b, f, t]^2 + y[b, F + f, t]^2   on the transform output y [B, 2F, T] (rows f real, F + f imaginary),
+ *     and for the mel loss on generated audio (tasks/base.py:232-238) its backward  dy[b, f] = 2 y[b, f] dp[b, f],
+ *     dy[b, F + f] = 2 y[b, F + f] dp[b, f].                                                                                      */
+VS_API int vs_spec_power_fwd(const float *y, float *p, int64_t B, int64_t F, int64_t T, void *stream);
+VS_API int vs_spec_power_bwd(const float *y, const float *dp, float *dy, int64_t B, int64_t F, int64_t T, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * a13 grouped / strided Conv1d of the scale discriminator (modules/discriminator.py:55-60) and its gradients.
  *     x: [B, c_in, T], w: [c_out, c_in/groups, k], y / gy: [B, c_out, T_out], T_out = (T + 2*pad - k)/stride + 1.
  *     vs_gconv1d_bwd_weight writes one plane per batch item, gw_planes [B][c_out, c_in/groups, k]; gw = their sum.

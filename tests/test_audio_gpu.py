@@ -1,5 +1,6 @@
-"""SURVEY.md 8f-2 on the device: visinger_amd/audio.py (torch.stft -> rocFFT on the MI355X, the spectrograms that feed the posterior
-encoder and the mel loss of the training step) against the fp64 framed-DFT + HTK-mel oracle.  PARITY UNPINNED w.r.t. the
+"""SURVEY.md 8f-2 on the device: visinger_amd/audio.py (the framed DFT and the mel projection as convs on the HIP MFMA engine + the
+power kernel of csrc/audio_ops.hip: the spectrograms that feed the posterior encoder and the mel loss of the training step) against
+the fp64 framed-DFT + HTK-mel oracle, and against torch.stft (rocFFT) as a second, independent statement.  PARITY UNPINNED w.r.t. the
 reference's torchaudio transforms (utils/audio/mel_processing.py:15-38): torchaudio is absent and nothing in the reference pins
 it; this test catches device-side regressions of the restatement."""
 import numpy as np
@@ -27,3 +28,35 @@ def test_device_spectrograms_match_fp64_oracle(oracle, n_fft, win, hop, n_mels, 
     # the masked mel-L1 of the training step (tasks/base.py:232-238) computed from device spectrograms equals the oracle's
     tgt = torch.from_numpy(mel_ref).float().cuda()
     assert float((mel - tgt).abs().mean()) <= 5e-4
+    # the transforms ran on the conv engine (no transform library on the product path) ...
+    plan = audio._plan(n_fft, win, hop, lin.device)
+    assert plan.fwd.kernel_instance().startswith("conv_"), plan.fwd.kernel_instance()
+    # ... and agree with torch.stft on the device
+    lin2 = audio.stft_spectrogram(wav.cuda(), n_fft, win, hop)
+    assert float((lin - lin2).abs().max()) <= 1e-4 * float(lin2.max())
+    with pytest.raises(RuntimeError):
+        audio.linear_spectrogram(wav, n_fft, win, hop)               # CPU tensors are refused: no CPU path
+
+
+@pytest.mark.parametrize("n_fft,win,hop,n_mels,sr,fmin,fmax,T,B", [(2048, 1200, 300, 128, 24000, 20.0, 12000.0, 27, 4),
+                                                                  (1024, 1024, 256, 80, 22050, 0.0, 11025.0, 32, 16),
+                                                                  (2048, 1200, 256, 128, 22050, 20.0, 11025.0, 130, 2),
+                                                                  (64, 32, 8, 16, 8000, 0.0, 4000.0, 48, 2)])
+def test_mel_loss_gradient_through_the_engine(n_fft, win, hop, n_mels, sr, fmin, fmax, T, B):
+    """The mel-L1 of the training step is taken on GENERATED audio (tasks/base.py:232-238): d loss / d wav through the engine's DFT
+    (grad-input conv with the transposed basis), vs_spec_power_bwd and the mel conv, against autograd through torch.stft; both the
+    short-item (segments laid end to end) and the per-item layout."""
+    from visinger_amd import audio
+    g = torch.Generator().manual_seed(n_fft + hop + T)
+    wav = ((torch.rand(B, T * hop, generator=g) - 0.5) * 0.9).cuda()
+    tgt = torch.randn(B, T, n_mels, generator=g).cuda()
+    grads = []
+    for fn in (audio.mel_spectrogram, audio.stft_mel_spectrogram):
+        w = wav.clone().requires_grad_(True)
+        mel = fn(w, sr, n_fft, win, hop, n_mels, fmin, fmax)
+        loss = (mel - tgt).abs().mean()
+        grads.append((torch.autograd.grad(loss, w)[0], float(loss.detach())))
+    (g1, l1), (g2, l2) = grads
+    assert abs(l1 - l2) <= 1e-5 * max(1.0, abs(l2))
+    assert torch.isfinite(g1).all()
+    assert float((g1 - g2).abs().max()) <= 2e-4 * float(g2.abs().max()), (float((g1 - g2).abs().max()), float(g2.abs().max()))

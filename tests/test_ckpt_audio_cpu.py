@@ -37,16 +37,16 @@ def test_spectrogram_shapes_and_energy():
     torch.manual_seed(0)
     hop, T = 300, 37
     wav = torch.randn(2, T * hop) * 0.1
-    lin = audio.linear_spectrogram(wav, 2048, 1200, hop)
+    lin = audio.stft_spectrogram(wav, 2048, 1200, hop)
     assert lin.shape == (2, T, 1025) and (lin >= 0).all()          # T frames: center padding gives T+1, last dropped
-    mel = audio.mel_spectrogram(wav, 24000, 2048, 1200, hop, 128, 20.0, 12000.0)
+    mel = audio.stft_mel_spectrogram(wav, 24000, 2048, 1200, hop, 128, 20.0, 12000.0)
     assert mel.shape == (2, T, 128) and torch.isfinite(mel).all()
     fb = audio.mel_filterbank(1025, 20.0, 12000.0, 128, 24000)
     assert fb.shape == (1025, 128) and (fb >= 0).all() and (fb.sum(0) > 0).all()
     # a pure tone lands in the bin torch.stft puts it in and in the matching mel band
     t = torch.arange(24000) / 24000.0
     tone = torch.sin(2 * np.pi * 3000.0 * t)[None]
-    lin = audio.linear_spectrogram(tone, 2048, 1200, hop)
+    lin = audio.stft_spectrogram(tone, 2048, 1200, hop)
     assert abs(int(lin[0, 20].argmax()) - round(3000.0 / (24000 / 2048))) <= 1
 
 
@@ -72,23 +72,31 @@ def test_wav_writer_and_bucketing(tmp_path):
 
 
 def test_spectrogram_against_fp64_dft_oracle(oracle):
-    """visinger_amd/audio.py (torch.stft) against the framed-DFT definition in fp64 (oracle/visinger_oracle.py).  Still PARITY UNPINNED
-    w.r.t. the reference's torchaudio transforms (utils/audio/mel_processing.py:15-38; torchaudio is absent): this pins the
-    restatement against its own definition, on CPU here and on the GPU in tests/test_audio_gpu.py."""
+    """The fp64 framed-DFT oracle (oracle/visinger_oracle.py) against torch.stft (visinger_amd/audio.py `stft_spectrogram`: the second
+    statement of the same definition; the product path is the HIP conv engine and runs in tests/test_audio_gpu.py).  Still PARITY
+    UNPINNED w.r.t. the reference's torchaudio transforms (utils/audio/mel_processing.py:15-38; torchaudio is absent): this pins
+    the oracle the GPU test checks the engine against, and the DFT basis the engine multiplies with."""
     from visinger_amd import audio
     torch.manual_seed(3)
     for (n_fft, win, hop, n_mels, sr, fmin, fmax, T) in ((2048, 1200, 300, 128, 24000, 20.0, 12000.0, 21), (64, 32, 8, 16, 8000, 0.0, 4000.0, 40),
                                                          (1024, 1024, 256, 80, 22050, 0.0, 11025.0, 17)):
         wav = (torch.randn(2, T * hop) * 0.3).clamp(-1, 1)
         lin_ref = oracle.linear_spectrogram_f64(wav.numpy(), n_fft, win, hop)
-        lin = audio.linear_spectrogram(wav, n_fft, win, hop).double().numpy()
+        lin = audio.stft_spectrogram(wav, n_fft, win, hop).double().numpy()
         assert lin.shape == lin_ref.shape == (2, T, n_fft // 2 + 1)
         assert np.abs(lin - lin_ref).max() <= 1e-4 * lin_ref.max()
         fb_ref = oracle.mel_filterbank_f64(n_fft // 2 + 1, fmin, fmax, n_mels, sr)
         assert np.abs(audio.mel_filterbank(n_fft // 2 + 1, fmin, fmax, n_mels, sr).double().numpy() - fb_ref).max() <= 5e-5   # fp32 triangles (as torchaudio builds them) vs fp64
         mel_ref = oracle.mel_spectrogram_f64(wav.numpy(), sr, n_fft, win, hop, n_mels, fmin, fmax)
-        mel = audio.mel_spectrogram(wav, sr, n_fft, win, hop, n_mels, fmin, fmax).double().numpy()
+        mel = audio.stft_mel_spectrogram(wav, sr, n_fft, win, hop, n_mels, fmin, fmax).double().numpy()
         assert np.abs(mel - mel_ref).max() <= 2e-3                    # log(x + 1e-3): fp32 bins of ~1e-3 relative to eps
+        # the engine's basis (host-built, fp64 -> fp32) reproduces the oracle's transform: frames x basis in fp64
+        basis = audio.dft_basis(n_fft, win).double().numpy()                        # [2F, win]
+        Fq, o = n_fft // 2 + 1, (n_fft - win) // 2
+        xp = np.pad(wav.numpy().astype(np.float64), ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+        frames = np.stack([xp[:, t * hop + o:t * hop + o + win] for t in range(T)], 1)          # [B, T, win]
+        y = frames @ basis.T
+        assert np.abs(y[..., :Fq] ** 2 + y[..., Fq:] ** 2 - lin_ref).max() <= 1e-6 * lin_ref.max()
 
 
 def test_trainer_learning_rate_follows_the_reference_schedule():
