@@ -259,6 +259,7 @@ def parse_args():
     ap.add_argument("--math", default=None, choices=tuple(MATH),
                     help="arithmetic of the conv engine (include/visinger_hip.h vs_conv_math): split6 = fp32-class split-bf16 "
                          "(default, the headline), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 operands (BASELINE config 5)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="config 3: p_dropout of the transformers (reference config: 0.1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (no GPU work): every rank joins the process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -490,7 +491,7 @@ def train_bench(args, rank, world, dist, dev, barrier):
     from visinger_amd.models.visinger import hop256_hparams
     from visinger_amd.train import VISingerTrainer, synthetic_train_batch
     B, T = args.batch, args.frames
-    hp = hop256_hparams(p_dropout=0.0)
+    hp = hop256_hparams(p_dropout=args.dropout)        # the reference trains with p_dropout 0.1 (config/models/visinger.yaml:9)
     torch.manual_seed(1234)
     tr = VISingerTrainer(64, 117, 131, hp).to(dev).configure().train()
     runner = tr
@@ -513,7 +514,7 @@ def train_bench(args, rank, world, dist, dev, barrier):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[args.math], "data": "synthetic",
             "config": {"workload": f"VISinger GAN training step, B={B}/GPU T_mel={T} segment={tr.segment_size} hop={tr.hop}, reference-size "
-                                   "generator + MPD/MSD, AdamW x2, random-init weights", "baseline_config": 3, "per_gpu_batch": B,
+                                   "generator + MPD/MSD, AdamW x2, random-init weights", "baseline_config": 3, "p_dropout": args.dropout, "per_gpu_batch": B,
                        "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)"},
             "generated_samples_per_s": B * world * tr.segment_size * tr.hop * args.steps / dt,
             "losses_last_step": logs}), flush=True)

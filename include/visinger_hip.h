@@ -182,6 +182,27 @@ VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const fl
 VS_API int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const float *dy, float *dx, float *dgamma,
                               float *dbeta, int64_t B, int64_t C, int64_t T, float eps, void *stream);
 
+/* Training-mode attention core (rel_transformer.py:148-179 incl. the relative terms of :181-243 and the dropout of :173), streaming:
+ * no [T, T] tensor in either direction.  q / k / v / out / dout / dq / dk / dv: [B, n_heads * k_channels, T] (batch strides given, 0 =
+ * dense); rel_k / rel_v: [n_heads_rel, 2 * window + 1, k_channels] (window_size < 0: none); mask: [B, T] or NULL (scores of masked
+ * (query, key) pairs are filled with -1e4 as the reference does; their gradient is zero).  Exact-fp32 MFMA; heads of <= 128 channels.
+ *   forward:  out, and lse [2][B, n_heads, T] = per query the maximum score m and log sum_k exp(score - m) (saved for the backward; kept
+ *             apart because a fully masked row has m = -1e4, where fp32 m + log(sum) would round the log away);
+ *   dropout:  p_drop on the probabilities, mask = a counter-based hash of (seed, batch * head, query, key): pass the same seed to the
+ *             backward.  Not torch's random stream (the reference's own masks are not reproducible across devices either);
+ *   backward: dq, dk, dv; d rel_k / d rel_v as PARTIAL sums drel_*_part [B * n_heads * ceil(T / 32)][2 * window + 1][k_channels] that the
+ *             caller reduces over the leading axis (per head, or over all heads when the tables are shared) -- deterministic, no atomics;
+ *             work: B * n_heads * T * (3 + 4 * window) floats of scratch (row sums D, per-query relative dots).                       */
+VS_API int vs_relattn_train_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                                const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, float *lse, int64_t B,
+                                int n_heads, int k_channels, int64_t T, int window_size, int n_heads_rel, float p_drop, uint64_t seed,
+                                void *stream);
+VS_API int vs_relattn_train_bwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                                const float *rel_v, const float *mask, const float *out, const float *dout, int64_t out_batch_stride,
+                                const float *lse, float *dq, float *dk, float *dv, int64_t grad_batch_stride, float *work,
+                                float *drel_k_part, float *drel_v_part, int64_t B, int n_heads, int k_channels, int64_t T, int window_size,
+                                int n_heads_rel, float p_drop, uint64_t seed, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * f2  on-device linear / mel spectrograms (utils/audio/mel_processing.py:15-38: torchaudio Spectrogram / MelSpectrogram, power 2).
  *     The framed windowed DFT is a strided conv of the reflect-padded waveform with the (cos | -sin) * hann basis and the mel

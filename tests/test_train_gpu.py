@@ -246,3 +246,124 @@ def test_wgrad_split_kernel_matches_aten(Cin, Cout, K, d, T, B):
     scale = float(ref64.abs().max())
     assert got.shape == ref.shape
     assert e_got[0] <= 3e-6 * scale + 2.5 * e_got[1], (e_got, scale)        # fp32 class: within the library's own error of the fp64 result
+
+
+def _attn_core_torch(q, k, v, rel_k, rel_v, mask, nh, w, keep=None):
+    """rel_transformer.py:148-179 + 181-243 with plain torch ops on [B, nh, T, T] (fp64): the definition the streaming kernels are
+    checked against.  keep: dropout factor per (b, h, query, key) (0 or 1 / (1 - p)), or None."""
+    B, C, T = q.shape
+    dk = C // nh
+    qh, kh, vh = (t.view(B, nh, dk, T).transpose(2, 3) for t in (q, k, v))
+    scale = 1.0 / np.sqrt(dk)
+    scores = torch.matmul(qh, kh.transpose(-2, -1)) * scale
+    i = torch.arange(T, device=q.device)
+    if rel_k is not None:
+        idx = i[None, :] - i[:, None] + w                                  # [T(query), T(key)]
+        band = (idx >= 0) & (idx <= 2 * w)
+        qr = torch.matmul(qh, rel_k.unsqueeze(0).transpose(-2, -1)) * scale      # [B, nh, T, R]
+        scores = scores + torch.where(band, qr.gather(-1, idx.clamp(0, 2 * w).expand(B, nh, T, T)), torch.zeros_like(scores))
+    if mask is not None:
+        am = mask.view(B, 1, T, 1) * mask.view(B, 1, 1, T)
+        scores = scores.masked_fill(am == 0, -1e4)
+    p = torch.softmax(scores, -1)
+    if keep is not None:
+        p = p * keep
+    out = torch.matmul(p, vh)
+    if rel_k is not None:
+        pw = torch.stack([torch.where((i + r - w >= 0) & (i + r - w < T), p.gather(-1, (i + r - w).clamp(0, T - 1).view(1, 1, T, 1).expand(B, nh, T, 1))[..., 0],
+                                      torch.zeros_like(p[..., 0])) for r in range(2 * w + 1)], -1)           # [B, nh, T, R]
+        out = out + torch.matmul(pw, rel_v.unsqueeze(0))
+    return out.transpose(2, 3).reshape(B, C, T)
+
+
+def _hash_keep(seed, B, nh, T, p_drop, device):
+    """csrc/attention_train.hip drop_factor(), restated on int64 tensors"""
+    M = 0xFFFFFFFF
+    lo, hi = seed & M, (seed >> 32) & M
+    qi = torch.arange(T, dtype=torch.int64, device=device).view(1, T, 1)
+    ki = torch.arange(T, dtype=torch.int64, device=device).view(1, 1, T)
+    bh = torch.arange(B * nh, dtype=torch.int64, device=device).view(B * nh, 1, 1)
+    x = (qi * T + ki) & M
+    x = x ^ lo
+    x = (x * 0x9E3779B1) & M
+    x = x ^ (x >> 16)
+    x = (x + bh * 0x85EBCA6B + hi) & M
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & M
+    x = x ^ (x >> 16)
+    thr = int(p_drop * 4294967296.0)
+    return ((x >= thr).double() / (1.0 - p_drop)).view(B, nh, T, T)
+
+
+@pytest.mark.parametrize("B,nh,dk,T,w,nh_rel,p_drop", [(2, 2, 96, 100, 4, 1, 0.0), (3, 2, 96, 64, 4, 1, 0.0), (1, 4, 32, 33, 4, 4, 0.0),
+                                                       (2, 2, 48, 70, 2, 1, 0.0), (1, 1, 128, 257, 7, 1, 0.0), (2, 2, 64, 40, None, 1, 0.0),
+                                                       (2, 2, 96, 512, 4, 1, 0.0), (2, 2, 96, 100, 4, 1, 0.1), (1, 2, 32, 37, 4, 2, 0.5),
+                                                       (2, 3, 16, 5, 4, 1, 0.0)])
+def test_training_attention_kernels_match_torch_autograd(B, nh, dk, T, w, nh_rel, p_drop):
+    """csrc/attention_train.hip (forward with log-sum-exp, backward for dQ + d rel_k + d rel_v, backward for dK / dV; exact-fp32 MFMA,
+    streaming, dropout by a counter-based hash) against the [T, T] definition of rel_transformer.py:148-179 / 181-243 in fp64 with
+    torch autograd: outputs and every gradient; lengths off the 32-tile, head widths off the 32-channel tile, ragged masks with an
+    all-padding item, per-head and shared relative tables, no window, dropout with the kernel's own mask restated on the host."""
+    from visinger_amd.autograd import AttnCoreFn
+    g = torch.Generator().manual_seed(B * 1000 + nh * 100 + dk + T)
+    C = nh * dk
+    q, k, v = (torch.randn(B, C, T, generator=g).cuda().requires_grad_(True) for _ in range(3))
+    R = 2 * w + 1 if w is not None else 0
+    rel_k = (torch.randn(nh_rel, R, dk, generator=g) * dk ** -0.5).cuda().requires_grad_(True) if w is not None else None
+    rel_v = (torch.randn(nh_rel, R, dk, generator=g) * dk ** -0.5).cuda().requires_grad_(True) if w is not None else None
+    mask = torch.ones(B, T)
+    if B > 1:
+        mask[1, (2 * T) // 3:] = 0
+    if B > 2:
+        mask[2] = 0                                                       # all padding: uniform rows, as the reference's -1e4 fill gives
+    mask = mask.cuda()
+    gout = torch.randn(B, C, T, generator=g).cuda()
+    torch.manual_seed(77)
+    state = torch.get_rng_state()
+    out = AttnCoreFn.apply(q, k, v, rel_k, rel_v, mask, nh, w if w is not None else -1, p_drop)
+    leaves = [t for t in (q, k, v, rel_k, rel_v) if t is not None]
+    grads = torch.autograd.grad(out, leaves, gout)
+    keep = None
+    if p_drop > 0:
+        torch.set_rng_state(state)
+        seed = int(torch.empty((), dtype=torch.int64).random_())          # the draw AttnCoreFn.forward made
+        keep = _hash_keep(seed, B, nh, T, p_drop, "cuda")
+        assert abs(float((keep > 0).double().mean()) - (1 - p_drop)) < 0.03
+    dl = [t.detach().double().requires_grad_(True) for t in leaves]
+    it = iter(dl)
+    qd, kd, vd = next(it), next(it), next(it)
+    rkd, rvd = (next(it), next(it)) if w is not None else (None, None)
+    ref = _attn_core_torch(qd, kd, vd, rkd, rvd, mask.double(), nh, w, keep)
+    rgrads = torch.autograd.grad(ref, dl, gout.double())
+    err = float((out.detach().double() - ref.detach()).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
+    for name, a, b in zip(("dq", "dk", "dv", "drel_k", "drel_v"), grads, rgrads):
+        e = float((a.double() - b).abs().max())
+        assert e <= 3e-5 * max(1.0, float(b.abs().max())), (name, e, float(b.abs().max()))
+
+
+def test_training_transformer_layer_uses_the_streaming_attention(monkeypatch):
+    """autograd.attention routes the training-mode core through AttnCoreFn: a relative encoder's output and parameter gradients are those of
+    the PyTorch [T, T] version of the same function (VS_NO_TRAIN_ATTN) with dropout off."""
+    from visinger_amd import autograd as A
+    from visinger_amd.modules.rel_transformer import RelativeEncoder
+    torch.manual_seed(5)
+    enc = RelativeEncoder(192, 768, 2, 2, kernel_size=9, p_dropout=0.0, window_size=4).cuda().train()
+    x = torch.randn(2, 192, 90).cuda()
+    mask = torch.ones(2, 1, 90).cuda()
+    mask[1, :, 61:] = 0
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("VS_NO_TRAIN_ATTN", "1")
+        xi = x.clone().requires_grad_(True)
+        y = A.rel_encoder(enc, xi, mask)
+        ps = [p for p in enc.parameters() if p.requires_grad]
+        gs = torch.autograd.grad((y * torch.linspace(-1, 1, 90, device="cuda")).sum(), [xi] + ps, allow_unused=True)
+        res.append((y.detach(), gs))
+    (y1, g1), (y2, g2) = res
+    assert float((y1 - y2).abs().max()) <= 2e-5 * float(y2.abs().max())
+    for a, b in zip(g1, g2):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6

@@ -12,7 +12,7 @@ from visinger_amd.models.visinger import hop256_hparams  # noqa: E402
 from visinger_amd.train import VISingerTrainer, synthetic_train_batch  # noqa: E402
 
 B, T = int(os.environ.get("TB_B", 16)), int(os.environ.get("TB_T", 512))
-hp = hop256_hparams(p_dropout=0.0)
+hp = hop256_hparams(p_dropout=float(os.environ.get("TB_DROPOUT", 0.1)))      # config/models/visinger.yaml:9
 torch.manual_seed(1234)
 tr = VISingerTrainer(64, 117, 131, hp).cuda().configure().train()
 batch = synthetic_train_batch(B, T, T // 8, tr.hop, 64, hp["num_linear_bins"], 1234, "cuda")

@@ -81,6 +81,10 @@ def lib():
     L.vs_gate_fwd.argtypes = [_f32p, _f32p, i64, _f32p, i64, i64, i64, vp]
     L.vs_gate_bwd.argtypes = [_f32p, _f32p, i64, _f32p, _f32p, _f32p, i64, i64, i64, i64, vp]
     L.vs_layernorm_c_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, i64, i64, i64, ctypes.c_float, vp]
+    u64, cf = ctypes.c_uint64, ctypes.c_float
+    L.vs_relattn_train_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, _f32p, i64, ci, ci, i64, ci, ci, cf, u64, vp]
+    L.vs_relattn_train_bwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64,
+                                       _f32p, _f32p, _f32p, i64, ci, ci, i64, ci, ci, cf, u64, vp]
     L.vs_spec_power_fwd.argtypes = [_f32p, _f32p, i64, i64, i64, vp]
     L.vs_spec_power_bwd.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, vp]
     L.vs_expand_states.argtypes = [_f32p, vp, _f32p, i64, i64, i64, i64, ci, ci, vp]

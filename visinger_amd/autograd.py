@@ -412,12 +412,70 @@ def layer_norm(m, x, r=None):
     return x * m.gamma.view(1, -1, 1) + m.beta.view(1, -1, 1)
 
 
+class AttnCoreFn(torch.autograd.Function):
+    """The attention core of rel_transformer.py:148-179 (scores + relative-key bias, -1e4 mask fill, softmax, dropout, P.V + relative-value
+    term) on the streaming HIP kernels of csrc/attention_train.hip: forward keeps only the output and the softmax statistics of each query, the
+    backward recomputes probabilities tile by tile -- no [B, h, T, T] tensor in either direction (the PyTorch version of this function
+    below held five of them per layer).  q / k / v: [B, nh * dk, T]; rel_k / rel_v: [nh_rel, 2w+1, dk] or None; mask [B, T] or None.
+    The dropout mask is a hash of (seed, batch * head, query, key); the seed is drawn from torch's CPU generator (no device sync)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, rel_k, rel_v, mask, nh, w, p_drop):
+        lib = L.require_gpu()
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, C, T = q.shape
+        dk = C // nh
+        has_rel = rel_k is not None
+        rk = rel_k.detach().contiguous() if has_rel else None
+        rv = rel_v.detach().contiguous() if has_rel else None
+        mk = None if mask is None else mask.contiguous()
+        seed = int(torch.empty((), dtype=torch.int64).random_()) if p_drop > 0 else 0
+        out = torch.empty_like(q)
+        lse = torch.empty((2, B, nh, T), device=q.device, dtype=torch.float32)        # row maximum, log of the row sum
+        L.check(lib.vs_relattn_train_fwd(L.ptr(q), L.ptr(k), L.ptr(v), 0, L.ptr(rk), L.ptr(rv), L.ptr(mk), L.ptr(out), 0, L.ptr(lse), B, nh, dk, T,
+                                         w if has_rel else -1, rk.shape[0] if has_rel else 1, float(p_drop), seed, L.stream_ptr()))
+        ctx.save_for_backward(q, k, v, rk if has_rel else q.new_empty(0), rv if has_rel else q.new_empty(0),
+                              mk if mk is not None else q.new_empty(0), out, lse)
+        ctx.cfg = (nh, w, float(p_drop), seed, has_rel, mk is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.require_gpu()
+        q, k, v, rk, rv, mk, out, lse = ctx.saved_tensors
+        nh, w, p_drop, seed, has_rel, has_mask = ctx.cfg
+        B, C, T = q.shape
+        dk = C // nh
+        dout = dout.contiguous().float()
+        dq, dkk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        R = 2 * w + 1 if has_rel else 0
+        nt = -(-T // 32)
+        work = torch.empty((B * nh * T * (1 + 2 * R),), device=q.device, dtype=torch.float32)
+        pk = torch.empty((B, nh, nt, R, dk), device=q.device, dtype=torch.float32) if has_rel else None
+        pv = torch.empty_like(pk) if has_rel else None
+        L.check(lib.vs_relattn_train_bwd(L.ptr(q), L.ptr(k), L.ptr(v), 0, L.ptr(rk) if has_rel else None, L.ptr(rv) if has_rel else None,
+                                         L.ptr(mk) if has_mask else None, L.ptr(out), L.ptr(dout), 0, L.ptr(lse), L.ptr(dq), L.ptr(dkk), L.ptr(dv),
+                                         0, L.ptr(work), L.ptr(pk), L.ptr(pv), B, nh, dk, T, w if has_rel else -1, rk.shape[0] if has_rel else 1,
+                                         p_drop, seed, L.stream_ptr()))
+        drk = drv = None
+        if has_rel:
+            dims = (0, 1, 2) if rk.shape[0] == 1 else (0, 2)
+            drk = pk.sum(dims).view(rk.shape)
+            drv = pv.sum(dims).view(rv.shape)
+        return dq, dkk, dv, drk, drv, None, None, None, None
+
+
 def attention(m, x, frame_mask):
-    """rel_transformer.py:138-179: q/k/v/o convs on the HIP engine, the [T, T] core as differentiable torch ops.  The
-    relative terms are gathered from the (2w+1)-wide tables with the index map j - i + w (what the reference's
-    pad/reshape skew implements) instead of materialising the skewed copies."""
+    """rel_transformer.py:138-179: q/k/v/o convs on the HIP engine; the core on the streaming kernels of csrc/attention_train.hip
+    (`AttnCoreFn`), or -- heads wider than 128 channels, windows wider than 7, VS_NO_TRAIN_ATTN -- as differentiable torch ops with the
+    relative terms laid onto the band through strided views (what the reference's pad / reshape skew implements)."""
     B, C, T = x.shape
     nh, dk, w = m.n_heads, m.k_channels, m.window_size
+    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not os.environ.get("VS_NO_TRAIN_ATTN"):
+        out = AttnCoreFn.apply(conv(m.conv_q, x), conv(m.conv_k, x), conv(m.conv_v, x), m.emb_rel_k if w is not None else None,
+                               m.emb_rel_v if w is not None else None, frame_mask, nh, w if w is not None else -1,
+                               m.drop.p if m.training else 0.0)
+        return conv(m.conv_o, out)
     q = conv(m.conv_q, x).view(B, nh, dk, T).transpose(2, 3)
     k = conv(m.conv_k, x).view(B, nh, dk, T).transpose(2, 3)
     v = conv(m.conv_v, x).view(B, nh, dk, T).transpose(2, 3)
