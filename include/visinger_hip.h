@@ -76,6 +76,9 @@ enum vs_out_mode {
 /* flags for vs_conv_create */
 #define VS_CONV_FLIP_IN 1u  /* read input channels in reversed order  (folds flow.py:88-95 Flip into the weights) */
 #define VS_CONV_FLIP_OUT 2u /* write output rows in reversed order (within each half for PAIRED)                 */
+#define VS_CONV_ADJOINT 4u  /* VS_CONV1D only: vs_conv_set_weights is handed the weight of the FORWARD conv this handle is the grad-input
+                               of, [c_in, c_out, k] of THIS handle, and packs its adjoint w'[co, ci, t] = w[ci, co, k - 1 - t] (channel
+                               transpose + tap reversal by index arithmetic: no flipped copy per training step); g must be NULL      */
 
 VS_API int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int dilation_or_stride, int padding,
                           unsigned flags);
@@ -175,7 +178,9 @@ VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma
  *     g: optional per-item bias, row b at g + b * g_bs (the layer's 2H-slice of the cond_layer output); acts / dacts: [B, H, T];
  *     dx_in: [B, 2H, T] = d loss / d x_in (= d / d g before the sum over t); dg (optional): += sum_t dx_in[b, :, t], row stride dg_bs.
  *   vs_layernorm_c_bwd: backward of y = LayerNorm_C(a + r) * gamma + beta (rel_transformer.py:33-42; r optional): dx [B, C, T] is the
- *     gradient w.r.t. a (and r); dgamma / dbeta [C] are ACCUMULATED (+=, float atomics: zero them first).                          */
+ *     gradient w.r.t. a (and r); dgamma / dbeta are PER-ITEM partial sums: row b of a zero-initialised [B, 2, C] buffer holds
+ *     (dgamma_b, dbeta_b) -- pass dgamma = buf, dbeta = buf + C -- accumulated with float atomics over the item's 64-frame blocks
+ *     only (one [C] row for the whole batch serialised 128 workgroups on every address); the caller sums over b.                */
 VS_API int vs_gate_fwd(const float *x_in, const float *g, int64_t g_bs, float *acts, int64_t B, int64_t H, int64_t T, void *stream);
 VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const float *dacts, float *dx_in, float *dg, int64_t dg_bs,
                        int64_t B, int64_t H, int64_t T, void *stream);

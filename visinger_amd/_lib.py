@@ -17,7 +17,7 @@ IN_NONE, IN_LRELU, IN_MASK, IN_LRELU_MASK = 0, 1, 2, 3
 OUT_NONE, OUT_TANH, OUT_RELU = 0, 1, 2
 PAIR_GATE, PAIR_COUPLING_FWD, PAIR_COUPLING_INV = 0, 1, 2
 MODE_LINEAR, MODE_COUPLING_MEAN_FWD, MODE_COUPLING_MEAN_INV = 0, 1, 2
-FLIP_IN, FLIP_OUT = 1, 2
+FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 # enum vs_conv_math
 MATH_F32, MATH_BF16, MATH_SPLIT6 = 0, 1, 6
 

@@ -75,8 +75,9 @@ def conv_backward(m, x, w, gy, need_x, need_w):
         if need_x:
             pb = d * (K - 1) - p
             assert pb >= 0, "conv backward-data: padding larger than the receptive field is not supported"
-            op = _bwd_op(m, "dx", L.CONV1D, Cout, Cin, K, d, pb, 0)
-            op.set_weights(w.detach().flip(2).transpose(0, 1).contiguous(), None, None, force=True)
+            # (the handle packs the adjoint -- channel transpose + tap reversal -- of the forward weight by index arithmetic)
+            op = _bwd_op(m, "dxa", L.CONV1D, Cout, Cin, K, d, pb, L.CONV_ADJOINT)
+            op.set_weights(w.detach().contiguous(), None, None, force=True)
             gx = op.forward(gy)
         if need_w:
             gw = conv_wgrad(gy, x, K, d, p)
@@ -170,8 +171,8 @@ class StridedConv1dFn(torch.autograd.Function):
         gyF = gyF.view(1, Cout, N * Hq)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            op = _cached_op(holder, ("dx", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, 0)
-            op.set_weights(w2.flip(2).transpose(0, 1).contiguous(), None, None, force=True)
+            op = _cached_op(holder, ("dxa", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, L.CONV_ADJOINT)
+            op.set_weights(w2, None, None, force=True)
             gXF = op.forward(gyF)[:, :, :N * Hq]                                                # [1, s*C, N*Hq]
             gX = gXF.reshape(stride * C, N, Hq).permute(1, 0, 2)                                # [N, s*C, Hq]
             if stride > 1:
@@ -295,9 +296,11 @@ class LayerNormFn(torch.autograd.Function):
         a, r, gamma = ctx.saved_tensors
         B, C, T = a.shape
         dx = torch.empty_like(a)
-        dgb = torch.zeros((2, C), device=a.device, dtype=torch.float32)
+        dgb = torch.zeros((B, 2, C), device=a.device, dtype=torch.float32)          # per-item partial sums (see vs_layernorm_c_bwd)
         L.check(lib.vs_layernorm_c_bwd(L.ptr(a), L.ptr(r) if ctx.has_r else None, L.ptr(gamma.detach().contiguous()), L.ptr(dy.contiguous()),
-                                       L.ptr(dx), L.ptr(dgb[0]), L.ptr(dgb[1]), B, C, T, ctx.eps, L.stream_ptr()))
+                                       L.ptr(dx), ctypes.c_void_p(dgb.data_ptr()),
+                                       ctypes.c_void_p(dgb.data_ptr() + 4 * C), B, C, T, ctx.eps, L.stream_ptr()))
+        dgb = dgb.sum(0)
         return dx, (dx if ctx.has_r else None), dgb[0], dgb[1], None
 
 

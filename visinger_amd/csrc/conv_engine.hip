@@ -835,7 +835,8 @@ __global__ void pack_conv_kernel(const PackParams q) {
         if (q.kind == VS_CONV1D) {
             if (m < q.c_out) {
                 const int row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
-                val = q.w[((long long)row * q.c_in + ci) * q.k + tap];
+                val = (q.flags & VS_CONV_ADJOINT) ? q.w[((long long)ci * q.c_out + row) * q.k + (q.k - 1 - tap)]
+                                                  : q.w[((long long)row * q.c_in + ci) * q.k + tap];
                 if (q.scale) val *= q.scale[row];
             }
         } else if (q.kind == VS_CONV1D_PAIRED) {
@@ -884,11 +885,13 @@ __global__ void pack_wino_kernel(const PackParams q, int G, int nchunks) {
         if (q.flags & VS_CONV_FLIP_IN) ci = q.c_in - 1 - ci;
         const int row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
         const float sc = q.scale ? q.scale[row] : 1.f;
-        const float *wr = q.w + ((long long)row * q.c_in + ci) * q.k;
+        const bool adj = (q.flags & VS_CONV_ADJOINT) != 0;     // w'[row, ci, t] = w[ci, row, k - 1 - t]
+        const float *wr = q.w + (adj ? ((long long)ci * q.c_out + row) * q.k + (q.k - 1) : ((long long)row * q.c_in + ci) * q.k);
+        const int ws = adj ? -1 : 1;
         const int k0 = 3 * g;
-        const float w0 = (k0 < q.k) ? wr[k0] * sc : 0.f;
-        const float w1 = (k0 + 1 < q.k) ? wr[k0 + 1] * sc : 0.f;
-        const float w2 = (k0 + 2 < q.k) ? wr[k0 + 2] * sc : 0.f;
+        const float w0 = (k0 < q.k) ? wr[ws * k0] * sc : 0.f;
+        const float w1 = (k0 + 1 < q.k) ? wr[ws * (k0 + 1)] * sc : 0.f;
+        const float w2 = (k0 + 2 < q.k) ? wr[ws * (k0 + 2)] * sc : 0.f;
         if (q.wino_tail1 && k0 + 1 == q.k) val = (xi == 0) ? w0 : (xi == 3) ? -w0 : 0.f;       // single last tap: direct form
         else if (q.wino_tail1 && k0 + 2 == q.k) val = (xi == 0) ? w0 : (xi == 1) ? (w0 + w1) : (xi == 3) ? w1 : 0.f;   // two: F(2,2)
         else val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
@@ -1138,6 +1141,9 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     VS_REQUIRE(kind >= VS_CONV1D && kind <= VS_CONV1D_PAIRED, "vs_conv_create: unknown kind %d", kind);
     VS_REQUIRE(c_in > 0 && c_out > 0 && k > 0 && dil > 0 && pad >= 0, "vs_conv_create: bad dims");
     VS_REQUIRE(kind != VS_CONV1D_PAIRED || (c_out % 2 == 0), "vs_conv_create: PAIRED needs even c_out");
+    VS_REQUIRE((flags & ~(VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT | VS_CONV_ADJOINT)) == 0, "vs_conv_create: unknown flags %u", flags);
+    VS_REQUIRE(!(flags & VS_CONV_ADJOINT) || (kind == VS_CONV1D && !(flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT))),
+               "vs_conv_create: VS_CONV_ADJOINT goes with a plain VS_CONV1D");
     vs_conv *h = new (std::nothrow) vs_conv();
     if (!h) { set_error("out of host memory"); return VS_ENOMEM; }
     h->kind = kind; h->c_in = c_in; h->c_out = c_out; h->k = k; h->dil = dil; h->pad = pad; h->flags = flags;
@@ -1176,7 +1182,7 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
     // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
-    h->wsplit = h->wino_groups > 0 && (h->MT % 2) == 0 && flags == 0 && wsplit_instance(dil, h->wino_groups) &&
+    h->wsplit = h->wino_groups > 0 && (h->MT % 2) == 0 && (flags & ~VS_CONV_ADJOINT) == 0 && wsplit_instance(dil, h->wino_groups) &&
                 (k >= 9 || getenv("VS_WSPLIT_FORCE"));      // (where it pays: see vs_conv_forward)
     // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
     // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
@@ -1219,6 +1225,7 @@ int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T) {
 
 int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const float *bias, void *stream) {
     VS_REQUIRE(h && w, "vs_conv_set_weights: NULL handle or weight");
+    VS_REQUIRE(!(h->flags & VS_CONV_ADJOINT) || !g, "vs_conv_set_weights: an ADJOINT handle takes the plain forward weight (g must be NULL)");
     hipStream_t s = as_stream(stream);
     const size_t n = (size_t)h->MT_alloc * h->KT * h->CP * 64;
     VS_TRY(h->wp.reserve(n * sizeof(float)));
@@ -1248,7 +1255,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)ceil_div((long long)nw, 256)), dim3(256), 0, s, qw, h->wino_groups,
                            h->nchunks);
     }
-    if (h->kind == VS_CONV1D && h->c_out <= 4) {
+    if (h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & VS_CONV_ADJOINT)) {
         const long long cols = (long long)h->c_in * h->k;
         VS_TRY(h->weff.reserve((size_t)h->c_out * cols * sizeof(float)));
         hipLaunchKernelGGL(fold_weights_kernel, dim3((unsigned)ceil_div(h->c_out * cols, 256)), dim3(256), 0, s, w, scale,
@@ -1343,7 +1350,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // (the VALU kernel reduces over c_in * k serially per thread: right for conv_post 32 -> 1 and the pitch head 192 -> 2, which
     // stream a long input once; the discriminators' 1024 -> 1 conv_post over a few thousand positions needs the parallelism of
     // the MFMA tiles even at 1 valid row in 32)
-    if (h->kind == VS_CONV1D && h->c_out <= 4 && h->c_in * h->k <= 2048 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT)) && !p.split_row &&
+    if (h->kind == VS_CONV1D && h->c_out <= 4 && h->c_in * h->k <= 2048 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT | VS_CONV_ADJOINT)) && !p.split_row &&
         !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {
         SmallParams q;
         q.x = p.x; q.x_bs = p.x_bs; q.w = h->weff.as<float>(); q.bias = h->has_bias ? h->beff.as<float>() : nullptr;

@@ -4,7 +4,7 @@
 //   vs_gate_fwd / vs_gate_bwd            WaveNet gate  acts = tanh(a + g_a) * sigmoid(b + g_b)         (encoder.py:206-213)
 //   vs_layernorm_c_bwd                   channel LayerNorm backward (forward: vs_layernorm_c_fwd)      (rel_transformer.py:33-42)
 // All HBM-bound: every tensor is read once and written once; reductions over channels in registers + one LDS exchange, reductions
-// over (batch, time) as one float atomic per channel and 64-frame block.
+// over (batch, time) as one float atomic per channel and 64-frame block (LayerNorm: into one row per batch item, summed by the caller).
 #include "vs_internal.h"
 
 namespace vs {
@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(64 * G) layernorm_c_bwd_kernel(const float *__
             float pg = d[i] * x[i], pb = d[i];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { pg += __shfl_xor(pg, o); pb += __shfl_xor(pb, o); }
-            if (tl == 0) { atomicAdd(dgamma + c, pg); atomicAdd(dbeta + c, pb); }
+            // per batch ITEM: all (T / 64) x B workgroups adding into one [C] row serialised on the same addresses (119 us per call at
+            // B = 16, T = 512: 128-way contention per channel); the caller sums the B rows
+            if (tl == 0) { atomicAdd(dgamma + (long long)b * 2 * C + c, pg); atomicAdd(dbeta + (long long)b * 2 * C + c, pb); }
         }
     }
 }

@@ -155,6 +155,14 @@ class MultiPeriodDiscriminator(nn.Module):
             [DiscriminatorP(period, use_spectral_norm=use_spectral_norm) for period in self.PERIODS])
 
     def forward(self, y, y_hat):
+        if y.shape == y_hat.shape and not y_hat.requires_grad and not y.requires_grad:
+            # the discriminator pass (both inputs detached, tasks/visinger.py:80-86): real and generated waveforms as ONE batch of 2B --
+            # no op of either discriminator mixes batch items, so every output is bit-identical to the two separate passes, at half the
+            # launches and half the weight re-packs of a step that is bound by both
+            B = y.shape[0]
+            both = [disc(torch.cat([y, y_hat], 0)) for disc in self.discriminators]
+            return ([o[:B] for o, _ in both], [o[B:] for o, _ in both],
+                    [[f[:B] for f in fm] for _, fm in both], [[f[B:] for f in fm] for _, fm in both])
         real, fake = zip(*((disc(y), disc(y_hat)) for disc in self.discriminators))      # ((logit, fmap), ...) per input
         return [r[0] for r in real], [f[0] for f in fake], [r[1] for r in real], [f[1] for f in fake]
 
