@@ -187,6 +187,20 @@ VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const fl
 VS_API int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const float *dy, float *dx, float *dgamma,
                               float *dbeta, int64_t B, int64_t C, int64_t T, float eps, void *stream);
 
+/* Layout kernels of a strided dense conv run as the stride-1 conv of its input phases (the period / scale discriminators' stride-3 / stride-1
+ * convs on vs_conv_forward, modules/discriminator.py:20-24, 55-60):
+ *   vs_phase_stack:   x [N, C, T] (element strides sn, sc, st: any view) -> xf [stride * C][cols], cols >= N * Hq:
+ *                     xf[r * C + c][n * Hq + j] = x[n][c][j * stride + r - pad], zero outside [0, T) and in the columns past the last
+ *                     item -- N items end to end as ONE sequence;
+ *   vs_phase_items:   to_sequence = 1: items src [N, C, Tv] -> dst [C][ld] at column n * Hq + j (zeros for Tv <= j < Hq);
+ *                     to_sequence = 0: the inverse, sequence src [C][ld] -> items dst [N, C, Tv];
+ *   vs_phase_unstack: the adjoint of vs_phase_stack, gxf [stride * C][ld] -> gx [N, C, T].                                              */
+VS_API int vs_phase_stack(const float *x, int64_t sn, int64_t sc, int64_t st, float *xf, int64_t N, int64_t C, int64_t T, int stride, int pad,
+                          int64_t Hq, int64_t cols, void *stream);
+VS_API int vs_phase_items(const float *src, float *dst, int64_t N, int64_t C, int64_t Tv, int64_t Hq, int64_t ld, int to_sequence, void *stream);
+VS_API int vs_phase_unstack(const float *gxf, int64_t ld, float *gx, int64_t N, int64_t C, int64_t T, int stride, int pad, int64_t Hq,
+                            void *stream);
+
 /* Training-mode attention core (rel_transformer.py:148-179 incl. the relative terms of :181-243 and the dropout of :173), streaming:
  * no [T, T] tensor in either direction.  q / k / v / out / dout / dq / dk / dv: [B, n_heads * k_channels, T] (batch strides given, 0 =
  * dense); rel_k / rel_v: [n_heads_rel, 2 * window + 1, k_channels] (window_size < 0: none); mask: [B, T] or NULL (scores of masked

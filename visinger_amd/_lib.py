@@ -85,6 +85,9 @@ def lib():
     L.vs_relattn_train_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, _f32p, i64, ci, ci, i64, ci, ci, cf, u64, vp]
     L.vs_relattn_train_bwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64,
                                        _f32p, _f32p, _f32p, i64, ci, ci, i64, ci, ci, cf, u64, vp]
+    L.vs_phase_stack.argtypes = [_f32p, i64, i64, i64, _f32p, i64, i64, i64, ci, ci, i64, i64, vp]
+    L.vs_phase_items.argtypes = [_f32p, _f32p, i64, i64, i64, i64, i64, ci, vp]
+    L.vs_phase_unstack.argtypes = [_f32p, i64, _f32p, i64, i64, i64, ci, ci, i64, vp]
     L.vs_spec_power_fwd.argtypes = [_f32p, _f32p, i64, i64, i64, vp]
     L.vs_spec_power_bwd.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, vp]
     L.vs_expand_states.argtypes = [_f32p, vp, _f32p, i64, i64, i64, i64, ci, ci, vp]

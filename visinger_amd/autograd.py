@@ -119,14 +119,6 @@ def _phase_geometry(T, K, stride, pad):
     return Tout, Q, Tout + Q - 1
 
 
-def _phase_stack(x, stride, pad, Hq):
-    """x [B, C, T] -> [B, stride*C, Hq]: channel r*C + c holds the phase-r samples xpad[c, j*stride + r] of the zero-padded x"""
-    B, C, T = x.shape
-    right = Hq * stride - T - pad
-    xp = F.pad(x, (pad, max(right, 0)))[:, :, :Hq * stride]
-    return xp.view(B, C, Hq, stride).permute(0, 3, 1, 2).reshape(B, stride * C, Hq).contiguous()
-
-
 def _phase_weights(w, stride, Q):
     """w [Cout, C, K] -> [Cout, stride*C, Q] with w2[co, r*C + c, q] = w[co, c, q*stride + r] (zero beyond K)"""
     Cout, C, K = w.shape
@@ -135,58 +127,58 @@ def _phase_weights(w, stride, Q):
 
 class StridedConv1dFn(torch.autograd.Function):
     """y = conv1d(x, w, b, stride, padding) (dilation 1, dense) on the HIP conv engine: a stride-s conv is the stride-1 conv of the
-    s de-interleaved phases of the padded input stacked as s*C channels with ceil(K/s) taps (`_phase_stack`); its gradients are
-    the engine's grad-input / vs_conv_wgrad on that form, un-stacked.
+    s de-interleaved phases of the padded input stacked as s*C channels with ceil(K/s) taps; its gradients are the engine's
+    grad-input conv (the same handle kind with VS_CONV_ADJOINT weights) / vs_conv_wgrad on that form.
 
     The period discriminators present hundreds of SHORT items (B*p columns of 10-300 positions): the engine tiles time per item
-    (256 columns), so the N explicitly padded items are laid end to end as ONE sequence [1, s*C, N*Hq] -- the zero padding
-    between them is already part of each item, outputs at positions that straddle two items are discarded (and enter the
-    gradients as zeros).  `holder` caches the engine handles."""
+    (256 columns), so the N explicitly padded items are laid end to end as ONE sequence [1, s*C, N*Hq (+ Q-1 zero columns)] -- the
+    zero padding between them is already part of each item, outputs at positions that straddle two items are discarded (and enter
+    the gradients as zeros).  The layout changes are one launch each (vs_phase_stack from any view of x, vs_phase_items,
+    vs_phase_unstack) where pad / view / permute / contiguous / zeros took 3-5.  The result is returned as the [N, Cout, Tout] VIEW of
+    the engine's output sequence (the leaky_relu that follows every layer but the last writes it out contiguously).
+    `holder` caches the engine handles."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, holder):
-        x, w = x.contiguous().float(), w.contiguous().float()
+        lib = L.require_gpu()
+        x, w = x.float(), w.contiguous().float()
         N, C, T = x.shape
         Cout, _, K = w.shape
         Tout, Q, Hq = _phase_geometry(T, K, stride, pad)
-        X = _phase_stack(x, stride, pad, Hq) if stride > 1 else F.pad(x, (pad, pad))            # [N, s*C, Hq]
-        XF = X.permute(1, 0, 2).reshape(1, stride * C, N * Hq).contiguous()                    # items end to end
+        Lf = N * Hq
+        XF = torch.empty((1, stride * C, Lf + Q - 1), device=x.device, dtype=torch.float32)
+        L.check(lib.vs_phase_stack(ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), x.stride(2), L.ptr(XF), N, C, T, stride, pad, Hq,
+                                   Lf + Q - 1, L.stream_ptr()))
         w2 = _phase_weights(w, stride, Q) if stride > 1 else w
         op = _cached_op(holder, ("fwd", C, Cout, K, stride), L.CONV1D, stride * C, Cout, Q, 1, 0, 0)
         op.set_weights(w2.detach(), None, None if b is None else b.detach(), force=True)
-        yF = op.forward(XF)                                                                     # [1, Cout, N*Hq - Q + 1]
-        y = F.pad(yF, (0, Q - 1)).view(Cout, N, Hq)[:, :, :Tout].permute(1, 0, 2).contiguous()
+        yF = op.forward(XF)                                                                     # [1, Cout, N*Hq]
         ctx.save_for_backward(XF, w2)
         ctx.cfg = (N, C, T, K, stride, pad, Q, Hq, Tout, b is not None, holder)
-        return y
+        return yF.view(Cout, N, Hq)[:, :, :Tout].permute(1, 0, 2)
 
     @staticmethod
     def backward(ctx, gy):
+        lib = L.require_gpu()
         XF, w2 = ctx.saved_tensors
         N, C, T, K, stride, pad, Q, Hq, Tout, has_bias, holder = ctx.cfg
         Cout = w2.shape[0]
+        Lf = N * Hq
         gy = gy.contiguous().float()
-        gyF = torch.zeros((Cout, N, Hq), device=gy.device, dtype=torch.float32)
-        gyF[:, :, :Tout] = gy.permute(1, 0, 2)
-        gyF = gyF.view(1, Cout, N * Hq)
+        gyF = torch.empty((1, Cout, Lf), device=gy.device, dtype=torch.float32)
+        L.check(lib.vs_phase_items(L.ptr(gy), L.ptr(gyF), N, Cout, Tout, Hq, Lf, 1, L.stream_ptr()))
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             op = _cached_op(holder, ("dxa", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, L.CONV_ADJOINT)
             op.set_weights(w2, None, None, force=True)
-            gXF = op.forward(gyF)[:, :, :N * Hq]                                                # [1, s*C, N*Hq]
-            gX = gXF.reshape(stride * C, N, Hq).permute(1, 0, 2)                                # [N, s*C, Hq]
-            if stride > 1:
-                gxp = gX.reshape(N, stride, C, Hq).permute(0, 2, 3, 1).reshape(N, C, Hq * stride)
-            else:
-                gxp = gX
-            short = pad + T - gxp.shape[2]
-            gx = (F.pad(gxp, (0, short)) if short > 0 else gxp)[:, :, pad:pad + T].contiguous()
+            gXF = op.forward(gyF)                                                               # [1, s*C, N*Hq + Q - 1]
+            gx = torch.empty((N, C, T), device=gy.device, dtype=torch.float32)
+            L.check(lib.vs_phase_unstack(L.ptr(gXF), Lf + Q - 1, L.ptr(gx), N, C, T, stride, pad, Hq, L.stream_ptr()))
         if ctx.needs_input_grad[1]:
             if Cout * stride * C >= 256 * 256 or Q > 16:       # (vs_conv_wgrad covers up to 16 taps)
                 # wide layers (512 / 1024 channels): per tap a plain [Cout x P] x [P x s*C] GEMM over the folded sequence --
                 # library GEMM territory (rocBLAS); vs_conv_wgrad's 32 x 32 tiles re-read both operands once per tile pair
-                Lf = N * Hq
-                g2 = torch.stack([gyF[0][:, :Lf - q] @ XF[0][:, q:].t() for q in range(Q)], dim=2)
+                g2 = torch.stack([gyF[0] @ XF[0][:, q:q + Lf].t() for q in range(Q)], dim=2)
             else:
                 g2 = conv_wgrad(gyF, XF, Q, 1, 0)                                               # [Cout, s*C, Q]
             gw = g2.view(Cout, stride, C, Q).permute(0, 2, 3, 1).reshape(Cout, C, Q * stride)[:, :, :K].contiguous() if stride > 1 else g2

@@ -3,6 +3,9 @@
 // (the GAN step at B=16, T_mel=512 is bound by launch count and small-kernel time):
 //   vs_gate_fwd / vs_gate_bwd            WaveNet gate  acts = tanh(a + g_a) * sigmoid(b + g_b)         (encoder.py:206-213)
 //   vs_layernorm_c_bwd                   channel LayerNorm backward (forward: vs_layernorm_c_fwd)      (rel_transformer.py:33-42)
+//   vs_phase_stack / vs_phase_items / vs_phase_unstack   layout kernels of a strided conv as a stride-1 conv over its input phases
+//                                        (discriminators, modules/discriminator.py:20-24: one launch each where pad / view / permute /
+//                                        contiguous / zeros took 3-5)
 // All HBM-bound: every tensor is read once and written once; reductions over channels in registers + one LDS exchange, reductions
 // over (batch, time) as one float atomic per channel and 64-frame block (LayerNorm: into one row per batch item, summed by the caller).
 #include "vs_internal.h"
@@ -138,6 +141,45 @@ __global__ void __launch_bounds__(64 * G) layernorm_c_bwd_kernel(const float *__
     }
 }
 
+
+// ---- a stride-s conv as the stride-1 conv of its s input phases (autograd.StridedConv1dFn): N items, padded by `pad` zeros on the left and
+// as many as needed on the right, de-interleaved into s * C channels of Hq positions and laid END TO END as one sequence of N * Hq columns
+//   XF[r * C + c][n * Hq + j] = xpad[n][c][j * s + r] = x[n][c][j * s + r - pad]   (0 outside [0, T))
+// x is read through its strides (a permuted / sliced view needs no contiguous copy first).
+__global__ void __launch_bounds__(256) phase_stack_kernel(const float *__restrict__ x, long long sn, long long sc, long long st,
+                                                          float *__restrict__ xf, int N, int C, int T, int s, int pad, int Hq, long long cols) {
+    const long long col = (long long)blockIdx.x * 256 + threadIdx.x;     // cols >= N * Hq: the columns past the last item are zeros
+    if (col >= cols) return;
+    const int row = blockIdx.y;                 // r * C + c
+    const int r = row / C, c = row - r * C;
+    const int n = (int)(col / Hq), j = (int)(col - (long long)n * Hq);
+    const int t = j * s + r - pad;
+    xf[(long long)row * cols + col] = (n < N && t >= 0 && t < T) ? x[n * sn + c * sc + t * st] : 0.f;
+}
+
+// items [N, C, Tv] -> one sequence [C][N * Hq], the Hq - Tv trailing positions of every item zero (output gradients on their way into the
+// grad-input conv / the weight-gradient kernel), and back: sequence [C][ld] -> items [N, C, Tv]
+__global__ void __launch_bounds__(256) phase_items_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int C, int Tv, int Hq,
+                                                          long long ld, int to_sequence) {
+    const long long cols = (long long)N * Hq;
+    const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const int c = blockIdx.y;
+    const int n = (int)(col / Hq), j = (int)(col - (long long)n * Hq);
+    if (to_sequence) dst[(long long)c * ld + col] = (j < Tv) ? src[((long long)n * C + c) * Tv + j] : 0.f;
+    else if (j < Tv) dst[((long long)n * C + c) * Tv + j] = src[(long long)c * ld + col];
+}
+
+// the adjoint of phase_stack: gx[n][c][t] = gXF[r * C + c][n * Hq + j] with (j, r) = divmod(t + pad, s)   (row stride ld of gXF)
+__global__ void __launch_bounds__(256) phase_unstack_kernel(const float *__restrict__ gxf, long long ld, float *__restrict__ gx, int N, int C,
+                                                            int T, int s, int pad, int Hq) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int j = (t + pad) / s, r = (t + pad) - j * s;
+    gx[((long long)n * C + c) * T + t] = (j < Hq) ? gxf[(long long)(r * C + c) * ld + (long long)n * Hq + j] : 0.f;
+}
+
 }  // namespace vs
 
 using namespace vs;
@@ -173,6 +215,37 @@ int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const
     else if (C <= 8 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<8, 64>), grid, dim3(512), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
     else if (C <= 16 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<16, 64>), grid, dim3(1024), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
     else { set_error("vs_layernorm_c_bwd: C=%lld > 1024 unsupported", (long long)C); return VS_EUNSUPPORTED; }
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_phase_stack(const float *x, int64_t sn, int64_t sc, int64_t st, float *xf, int64_t N, int64_t C, int64_t T, int stride, int pad,
+                   int64_t Hq, int64_t cols, void *stream) {
+    VS_REQUIRE(x && xf && N > 0 && C > 0 && T > 0 && stride > 0 && pad >= 0 && Hq > 0 && (int64_t)stride * C <= 65535 && cols >= N * Hq &&
+               cols < (1ll << 31), "vs_phase_stack: bad arguments");
+    dim3 grid((unsigned)ceil_div(cols, 256), (unsigned)(stride * C));
+    hipLaunchKernelGGL(phase_stack_kernel, grid, dim3(256), 0, as_stream(stream), x, (long long)sn, (long long)sc, (long long)st, xf, (int)N,
+                       (int)C, (int)T, stride, pad, (int)Hq, (long long)cols);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_phase_items(const float *src, float *dst, int64_t N, int64_t C, int64_t Tv, int64_t Hq, int64_t ld, int to_sequence, void *stream) {
+    VS_REQUIRE(src && dst && N > 0 && C > 0 && C <= 65535 && Tv > 0 && Hq >= Tv && ld >= N * Hq - (to_sequence ? 0 : Hq - Tv) &&
+               N * Hq < (1ll << 31), "vs_phase_items: bad arguments");
+    dim3 grid((unsigned)ceil_div(N * Hq, 256), (unsigned)C);
+    hipLaunchKernelGGL(phase_items_kernel, grid, dim3(256), 0, as_stream(stream), src, dst, (int)N, (int)C, (int)Tv, (int)Hq, (long long)ld,
+                       to_sequence);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_phase_unstack(const float *gxf, int64_t ld, float *gx, int64_t N, int64_t C, int64_t T, int stride, int pad, int64_t Hq, void *stream) {
+    VS_REQUIRE(gxf && gx && N > 0 && N <= 65535 && C > 0 && C <= 65535 && T > 0 && stride > 0 && pad >= 0 && Hq > 0 && ld >= N * Hq,
+               "vs_phase_unstack: bad arguments");
+    dim3 grid((unsigned)ceil_div(T, 256), (unsigned)C, (unsigned)N);
+    hipLaunchKernelGGL(phase_unstack_kernel, grid, dim3(256), 0, as_stream(stream), gxf, (long long)ld, gx, (int)N, (int)C, (int)T, stride, pad,
+                       (int)Hq);
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
 }
