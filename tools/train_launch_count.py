@@ -27,8 +27,11 @@ kern = [e for e in ev if e.device_type == torch.autograd.DeviceType.CUDA]
 cpu = [e for e in ev if e.device_type == torch.autograd.DeviceType.CPU]
 print(f"kernel launches: {sum(e.count for e in kern)}, device time {sum(e.device_time_total for e in kern) / 1e3:.1f} ms")
 print("--- kernels by count")
-for e in sorted(kern, key=lambda e: -e.count)[:45]:
+for e in sorted(kern, key=lambda e: -e.count)[:30]:
+    print(f"{e.count:6d} {e.device_time_total / 1e3:8.2f} ms  {e.key[:110]}")
+print("--- kernels by device time")
+for e in sorted(kern, key=lambda e: -e.device_time_total)[:40]:
     print(f"{e.count:6d} {e.device_time_total / 1e3:8.2f} ms  {e.key[:110]}")
 print("--- host ops by count")
-for e in sorted(cpu, key=lambda e: -e.count)[:45]:
+for e in sorted(cpu, key=lambda e: -e.count)[:25]:
     print(f"{e.count:6d} {e.cpu_time_total / 1e3:8.2f} ms (self {e.self_cpu_time_total / 1e3:7.2f})  {e.key[:90]}")

@@ -417,47 +417,87 @@ class AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, rel_k, rel_v, mask, nh, w, p_drop):
         lib = L.require_gpu()
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        B, C, T = q.shape
+        packed = k is None                  # q is the [B, 3C, T] output of the fused q|k|v projection: rows [0, C) q, [C, 2C) k, [2C, 3C) v
+        if packed:
+            qkv = q.contiguous()
+            B, C3, T = qkv.shape
+            C = C3 // 3
+            q, k, v = (ctypes.c_void_p(qkv.data_ptr() + 4 * i * C * T) for i in range(3))
+            bs = C3 * T
+        else:
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+            B, C, T = q.shape
+            bs = 0
         dk = C // nh
         has_rel = rel_k is not None
         rk = rel_k.detach().contiguous() if has_rel else None
         rv = rel_v.detach().contiguous() if has_rel else None
         mk = None if mask is None else mask.contiguous()
         seed = int(torch.empty((), dtype=torch.int64).random_()) if p_drop > 0 else 0
-        out = torch.empty_like(q)
-        lse = torch.empty((2, B, nh, T), device=q.device, dtype=torch.float32)        # row maximum, log of the row sum
-        L.check(lib.vs_relattn_train_fwd(L.ptr(q), L.ptr(k), L.ptr(v), 0, L.ptr(rk), L.ptr(rv), L.ptr(mk), L.ptr(out), 0, L.ptr(lse), B, nh, dk, T,
+        dev = qkv.device if packed else q.device
+        out = torch.empty((B, C, T), device=dev, dtype=torch.float32)
+        lse = torch.empty((2, B, nh, T), device=dev, dtype=torch.float32)        # row maximum, log of the row sum
+        qp, kp, vp = (q, k, v) if packed else (L.ptr(q), L.ptr(k), L.ptr(v))
+        L.check(lib.vs_relattn_train_fwd(qp, kp, vp, bs, L.ptr(rk), L.ptr(rv), L.ptr(mk), L.ptr(out), 0, L.ptr(lse), B, nh, dk, T,
                                          w if has_rel else -1, rk.shape[0] if has_rel else 1, float(p_drop), seed, L.stream_ptr()))
-        ctx.save_for_backward(q, k, v, rk if has_rel else q.new_empty(0), rv if has_rel else q.new_empty(0),
-                              mk if mk is not None else q.new_empty(0), out, lse)
-        ctx.cfg = (nh, w, float(p_drop), seed, has_rel, mk is not None)
+        none = out.new_empty(0)
+        ctx.save_for_backward(*((qkv, none, none) if packed else (q, k, v)), rk if has_rel else none, rv if has_rel else none,
+                              mk if mk is not None else none, out, lse)
+        ctx.cfg = (nh, w, float(p_drop), seed, has_rel, mk is not None, packed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = L.require_gpu()
         q, k, v, rk, rv, mk, out, lse = ctx.saved_tensors
-        nh, w, p_drop, seed, has_rel, has_mask = ctx.cfg
-        B, C, T = q.shape
+        nh, w, p_drop, seed, has_rel, has_mask, packed = ctx.cfg
+        B, C, T = out.shape
         dk = C // nh
         dout = dout.contiguous().float()
-        dq, dkk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        if packed:
+            dqkv = torch.empty_like(q)
+            qp, kp, vp = (ctypes.c_void_p(q.data_ptr() + 4 * i * C * T) for i in range(3))
+            dqp, dkp, dvp = (ctypes.c_void_p(dqkv.data_ptr() + 4 * i * C * T) for i in range(3))
+            bs = 3 * C * T
+        else:
+            dq, dkk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+            qp, kp, vp, dqp, dkp, dvp, bs = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(dq), L.ptr(dkk), L.ptr(dv), 0
         R = 2 * w + 1 if has_rel else 0
         nt = -(-T // 32)
         work = torch.empty((B * nh * T * (1 + 2 * R),), device=q.device, dtype=torch.float32)
         pk = torch.empty((B, nh, nt, R, dk), device=q.device, dtype=torch.float32) if has_rel else None
         pv = torch.empty_like(pk) if has_rel else None
-        L.check(lib.vs_relattn_train_bwd(L.ptr(q), L.ptr(k), L.ptr(v), 0, L.ptr(rk) if has_rel else None, L.ptr(rv) if has_rel else None,
-                                         L.ptr(mk) if has_mask else None, L.ptr(out), L.ptr(dout), 0, L.ptr(lse), L.ptr(dq), L.ptr(dkk), L.ptr(dv),
-                                         0, L.ptr(work), L.ptr(pk), L.ptr(pv), B, nh, dk, T, w if has_rel else -1, rk.shape[0] if has_rel else 1,
+        L.check(lib.vs_relattn_train_bwd(qp, kp, vp, bs, L.ptr(rk) if has_rel else None, L.ptr(rv) if has_rel else None,
+                                         L.ptr(mk) if has_mask else None, L.ptr(out), L.ptr(dout), 0, L.ptr(lse), dqp, dkp, dvp,
+                                         bs, L.ptr(work), L.ptr(pk), L.ptr(pv), B, nh, dk, T, w if has_rel else -1, rk.shape[0] if has_rel else 1,
                                          p_drop, seed, L.stream_ptr()))
         drk = drv = None
         if has_rel:
             dims = (0, 1, 2) if rk.shape[0] == 1 else (0, 2)
             drk = pk.sum(dims).view(rk.shape)
             drv = pv.sum(dims).view(rv.shape)
+        if packed:
+            return dqkv, None, None, drk, drv, None, None, None, None
         return dq, dkk, dv, drk, drv, None, None, None, None
+
+
+class _ConvHolder:
+    """What HipConvFn / conv_backward need from a conv module, for a conv that is not a module of its own: the fused q | k | v projection of
+    an attention layer (three 1x1 convs of the same input as ONE launch forward, one grad-input conv and one weight-gradient launch)."""
+    _kind = L.CONV1D
+
+    def __init__(self, c_in, c_out, k=1, dilation=1, padding=0):
+        self.in_channels, self.out_channels = c_in, c_out
+        self.kernel_size, self.dilation, self.padding, self.stride = (k,), (dilation,), (padding,), (1,)
+
+    def _op(self, bind=False):
+        ops = self.__dict__.setdefault("_hip_ops", {})
+        if "fwd" not in ops:
+            ops["fwd"] = ConvOp(L.CONV1D, self.in_channels, self.out_channels, self.kernel_size[0], self.dilation[0], self.padding[0], 0)
+        math = self.__dict__.get("_hip_math")
+        if math is not None and ops["fwd"].math != math:
+            ops["fwd"].set_math(math)
+        return ops["fwd"]
 
 
 def attention(m, x, frame_mask):
@@ -467,9 +507,23 @@ def attention(m, x, frame_mask):
     B, C, T = x.shape
     nh, dk, w = m.n_heads, m.k_channels, m.window_size
     if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not os.environ.get("VS_NO_TRAIN_ATTN"):
-        out = AttnCoreFn.apply(conv(m.conv_q, x), conv(m.conv_k, x), conv(m.conv_v, x), m.emb_rel_k if w is not None else None,
-                               m.emb_rel_v if w is not None else None, frame_mask, nh, w if w is not None else -1,
-                               m.drop.p if m.training else 0.0)
+        rel_k, rel_v = (m.emb_rel_k, m.emb_rel_v) if w is not None else (None, None)
+        pd = m.drop.p if m.training else 0.0
+        plain = all(not hasattr(c, "weight_g") and c.bias is not None and c.kernel_size[0] == 1 for c in (m.conv_q, m.conv_k, m.conv_v))
+        if plain and not os.environ.get("VS_NO_FUSED_QKV"):
+            # q | k | v as one [3C, C_in] projection (rel_transformer.py:120-122 are three nn.Conv1d(channels, channels, 1) of the same x)
+            holder = m.__dict__.get("_hip_qkv")
+            if holder is None:
+                holder = m.__dict__["_hip_qkv"] = _ConvHolder(m.conv_q.in_channels, 3 * C)
+            arith = m.conv_q.__dict__.get("_hip_math")
+            if arith is not None:
+                holder.__dict__["_hip_math"] = arith
+            wqkv = torch.cat([m.conv_q.weight, m.conv_k.weight, m.conv_v.weight], 0)
+            bqkv = torch.cat([m.conv_q.bias, m.conv_k.bias, m.conv_v.bias], 0)
+            out = AttnCoreFn.apply(HipConvFn.apply(x, wqkv, bqkv, holder), None, None, rel_k, rel_v, frame_mask, nh, w if w is not None else -1, pd)
+        else:
+            out = AttnCoreFn.apply(conv(m.conv_q, x), conv(m.conv_k, x), conv(m.conv_v, x), rel_k, rel_v, frame_mask, nh,
+                                   w if w is not None else -1, pd)
         return conv(m.conv_o, out)
     q = conv(m.conv_q, x).view(B, nh, dk, T).transpose(2, 3)
     k = conv(m.conv_k, x).view(B, nh, dk, T).transpose(2, 3)

@@ -1458,7 +1458,8 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         const long long ncol = ceil_div(p.N, 256) * p.B;
         if (cfg == 0 && ncol * ceil_div(h->MT, 4) < 256) cfg = 3;
         if (cfg == 3 && ncol * ceil_div(h->MT, 2) < 256 && (long long)p.N * p.B <= 65536) cfg = 2;
-        if (cfg == 2 && ncol * h->MT < 128 && h->kind != VS_CONV_TRANSPOSE1D) cfg = 6;     // 128-column tiles: twice the workgroups again
+        static const long long t6 = getenv("VS_SMALL_GRID_T6") ? atoll(getenv("VS_SMALL_GRID_T6")) : 512;
+        if (cfg == 2 && ncol * h->MT < t6 && h->kind != VS_CONV_TRANSPOSE1D) cfg = 6;     // 128-column tiles: twice the workgroups again
     }
     if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
     if (h->math) p.wp = h->ws.as<float>();
