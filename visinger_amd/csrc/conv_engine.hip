@@ -796,36 +796,24 @@ struct PackParams {
     int wino_tail1;      // pack_wino_kernel: the single tap of the last group in the direct form (k = 7 specialised instances)
 };
 
-__global__ void pack_conv_kernel(const PackParams q) {
-    const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (long long)q.MT_alloc * 32) {   // bias over virtual rows
-        const int m = (int)e;
-        float bv = 0.f;
-        int row = -1;
-        if (q.kind == VS_CONV1D) {
-            if (m < q.c_out) row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
-        } else if (q.kind == VS_CONV1D_PAIRED) {
-            const int pair = m >> 6, which = (m >> 5) & 1, c = pair * 32 + (m & 31);
-            if (c < q.Hh) row = which * q.Hh + ((q.flags & VS_CONV_FLIP_OUT) ? q.Hh - 1 - c : c);
-        } else {
-            const int phase = m / q.c_out;
-            if (phase < q.up) row = m - phase * q.c_out;
-        }
-        if (row >= 0 && q.bias) bv = q.bias[row];
-        q.biasp[m] = bv;
+// bias of virtual row m (rows past the real ones: 0)
+__device__ __forceinline__ float packed_bias(const PackParams &q, int m) {
+    int row = -1;
+    if (q.kind == VS_CONV1D) {
+        if (m < q.c_out) row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
+    } else if (q.kind == VS_CONV1D_PAIRED) {
+        const int pair = m >> 6, which = (m >> 5) & 1, c = pair * 32 + (m & 31);
+        if (c < q.Hh) row = which * q.Hh + ((q.flags & VS_CONV_FLIP_OUT) ? q.Hh - 1 - c : c);
+    } else {
+        const int phase = m / q.c_out;
+        if (phase < q.up) row = m - phase * q.c_out;
     }
-    if (e >= total) return;
-    // Wp[m_tile][tap][chunk][quad(2)][64 lanes][4]: lane l of quad qd holds channel pairs chunk*8 + qd*4 + (0..3)
-    const int sub = (int)(e & 3);
-    const int lane = (int)((e >> 2) & 63);
-    const int quad = (int)((e >> 8) & 1);
-    long long t = e >> 9;
-    const int nchunks = q.CP / (CK / 2);
-    const int chunk = (int)(t % nchunks);
-    t /= nchunks;
-    const int tap = (int)(t % q.KT);
-    const int mt = (int)(t / q.KT);
+    return (row >= 0 && q.bias) ? q.bias[row] : 0.f;
+}
+
+// The value of fragment element Wp[m_tile][tap][chunk][quad(2)][64 lanes][4]: lane l of quad qd holds channel pairs
+// chunk*8 + qd*4 + (0..3), i.e. row m_tile*32 + (l & 31), (logical) input channel 2 * pair + (l >> 5)
+__device__ __forceinline__ float packed_weight(const PackParams &q, int mt, int tap, int chunk, int quad, int lane, int sub) {
     const int cp = chunk * (CK / 2) + quad * 4 + sub;
     const int m = mt * 32 + (lane & 31);
     int ci = cp * 2 + (lane >> 5);
@@ -858,7 +846,66 @@ __global__ void pack_conv_kernel(const PackParams q) {
             }
         }
     }
-    q.wp[e] = val;
+    return val;
+}
+
+__global__ void pack_conv_kernel(const PackParams q) {
+    const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (long long)q.MT_alloc * 32) q.biasp[e] = packed_bias(q, (int)e);   // bias over virtual rows
+    if (e >= total) return;
+    const int sub = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const int quad = (int)((e >> 8) & 1);
+    long long t = e >> 9;
+    const int nchunks = q.CP / (CK / 2);
+    const int chunk = (int)(t % nchunks);
+    t /= nchunks;
+    const int tap = (int)(t % q.KT);
+    const int mt = (int)(t / q.KT);
+    q.wp[e] = packed_weight(q, mt, tap, chunk, quad, lane, sub);
+}
+
+// The same pack for the bf16-pipe engine in ONE launch: thread (cell = (m_tile, tap, chunk), lane) produces the eight values of its bf16
+// fragment (pack_split_kernel's mapping: row lane & 31, channels chunk*16 + 8*(lane >> 5) + j), writes them to the fp32 fragment buffer
+// Wp (kept: vs_conv_set_math and the lazy F(2,3) transforms are built from it) and, split into planes, to Ws.  A training step re-packs
+// every conv's weight twice (forward and grad-input handles): two launches per pack were 1 400 of its 7 000.
+__global__ void pack_conv_split_kernel(const PackParams q, void *ws, int npl) {
+    const int nchunks = q.CP / (CK / 2);
+    const long long total = (long long)q.MT_alloc * q.KT * nchunks * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (long long)q.MT_alloc * 32) q.biasp[e] = packed_bias(q, (int)e);
+    if (e >= total) return;
+    const int lane = (int)(e & 63);
+    const long long cell = e >> 6;
+    const int chunk = (int)(cell % nchunks);
+    const int tap = (int)((cell / nchunks) % q.KT);
+    const int mt = (int)(cell / ((long long)nchunks * q.KT));
+    const int row = lane & 31, kg = lane >> 5;
+    float *const wpc = q.wp + cell * 512;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cl = 8 * kg + j, cp = cl >> 1, par = cl & 1;
+        v[j] = packed_weight(q, mt, tap, chunk, cp >> 2, row + 32 * par, cp & 3);
+        wpc[(cp >> 2) * 256 + (row + 32 * par) * 4 + (cp & 3)] = v[j];
+    }
+    u32x4 *dst = reinterpret_cast<u32x4 *>(ws) + cell * npl * 64 + lane;
+    if (npl == 1) {
+        unsigned d[4][1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split_pair<1>(v[2 * t], v[2 * t + 1], d[t]);
+        u32x4 o; o.x = d[0][0]; o.y = d[1][0]; o.z = d[2][0]; o.w = d[3][0];
+        dst[0] = o;
+    } else {
+        unsigned d[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split_pair<3>(v[2 * t], v[2 * t + 1], d[t]);
+        for (int pl = 0; pl < npl; ++pl) {
+            u32x4 o; o.x = d[0][pl]; o.y = d[1][pl]; o.z = d[2][pl]; o.w = d[3][pl];
+            dst[pl * 64] = o;
+        }
+    }
 }
 
 // Winograd F(2,3) weight transform + fragment packing for conv_wino_kernel:
@@ -878,20 +925,19 @@ __global__ void pack_wino_kernel(const PackParams q, int G, int nchunks) {
     t /= G;
     const int chunk = (int)(t % nchunks);
     const int mt = (int)(t / nchunks);
-    const int m = mt * 32 + (lane & 31);
-    int ci = chunk * CK + half * 8 + cp4 * 2 + (lane >> 5);
+    const int ci = chunk * CK + half * 8 + cp4 * 2 + (lane >> 5);
+    // built from the fp32 fragment buffer Wp (q.w), which already holds flips / weight-norm scale / adjoint and zeros in the padding:
+    // the transform is made by the first launch that needs it (the bf16-pipe engine and the training path never do)
+    auto wv = [&](int tap) -> float {
+        const int cp = ci >> 1;
+        return q.w[((((long long)mt * q.KT + tap) * nchunks + (cp >> 3)) * 2 + ((cp & 7) >> 2)) * 256 + ((ci & 1) * 32 + (lane & 31)) * 4 + (cp & 3)];
+    };
     float val = 0.f;
-    if (m < q.c_out && ci < q.c_in) {
-        if (q.flags & VS_CONV_FLIP_IN) ci = q.c_in - 1 - ci;
-        const int row = (q.flags & VS_CONV_FLIP_OUT) ? q.c_out - 1 - m : m;
-        const float sc = q.scale ? q.scale[row] : 1.f;
-        const bool adj = (q.flags & VS_CONV_ADJOINT) != 0;     // w'[row, ci, t] = w[ci, row, k - 1 - t]
-        const float *wr = q.w + (adj ? ((long long)ci * q.c_out + row) * q.k + (q.k - 1) : ((long long)row * q.c_in + ci) * q.k);
-        const int ws = adj ? -1 : 1;
+    {
         const int k0 = 3 * g;
-        const float w0 = (k0 < q.k) ? wr[ws * k0] * sc : 0.f;
-        const float w1 = (k0 + 1 < q.k) ? wr[ws * (k0 + 1)] * sc : 0.f;
-        const float w2 = (k0 + 2 < q.k) ? wr[ws * (k0 + 2)] * sc : 0.f;
+        const float w0 = (k0 < q.k) ? wv(k0) : 0.f;
+        const float w1 = (k0 + 1 < q.k) ? wv(k0 + 1) : 0.f;
+        const float w2 = (k0 + 2 < q.k) ? wv(k0 + 2) : 0.f;
         if (q.wino_tail1 && k0 + 1 == q.k) val = (xi == 0) ? w0 : (xi == 3) ? -w0 : 0.f;       // single last tap: direct form
         else if (q.wino_tail1 && k0 + 2 == q.k) val = (xi == 0) ? w0 : (xi == 1) ? (w0 + w1) : (xi == 3) ? w1 : 0.f;   // two: F(2,2)
         else val = (xi == 0) ? w0 : (xi == 1) ? 0.5f * (w0 + w1 + w2) : (xi == 2) ? 0.5f * (w0 - w1 + w2) : w2;
@@ -1244,17 +1290,17 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     q.w = w; q.scale = scale; q.bias = bias; q.wp = h->wp.as<float>(); q.biasp = h->biasp.as<float>();
     q.kind = h->kind; q.c_in = h->c_in; q.c_out = h->c_out; q.k = h->k; q.up = h->dil; q.pad = h->pad; q.dmin = h->dmin;
     q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags; q.wino_tail1 = 0;
-    const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
-    if (h->wino_groups) {
-        const size_t nw = (size_t)h->MT_alloc * h->nchunks * h->wino_groups * 2 * 16 * 64;
-        VS_TRY(h->wpw.reserve(nw * sizeof(float)));
-        PackParams qw = q;
-        qw.wp = h->wpw.as<float>();
-        qw.wino_tail1 = (h->wino_k7 || h->wino_k11) ? 1 : 0;
-        hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)ceil_div((long long)nw, 256)), dim3(256), 0, s, qw, h->wino_groups,
-                           h->nchunks);
+    if (h->math) {
+        // bf16-pipe arithmetic: fp32 fragments + bf16 planes in one launch
+        const int npl = split_planes(h->math);
+        VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * npl * 64 * 16));
+        const long long total = std::max<long long>((long long)h->MT_alloc * h->KT * h->nchunks * 64, (long long)h->MT_alloc * 32);
+        hipLaunchKernelGGL(pack_conv_split_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, h->ws.p, npl);
+    } else {
+        const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
+        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
     }
+    h->wino_packed = false;        // (the F(2,3) transform of the fp32 engine is rebuilt from Wp by the first launch that uses it)
     if (h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & VS_CONV_ADJOINT)) {
         const long long cols = (long long)h->c_in * h->k;
         VS_TRY(h->weff.reserve((size_t)h->c_out * cols * sizeof(float)));
@@ -1267,7 +1313,6 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         }
     }
     VS_CHECK_HIP(hipGetLastError());
-    if (h->math) VS_TRY(pack_split_planes(h, s));
     h->wsplit_packed = false;      // (the F(2,3) transform of the split engine is rebuilt from Wp by the first launch that uses it)
     h->weights_set = true;
     return VS_OK;
@@ -1410,6 +1455,17 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9 || h->wino_k7);
     if (!h->math && h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
         ConvParams q = p;
+        if (!h->wino_packed) {
+            const size_t nw = (size_t)h->MT_alloc * h->nchunks * h->wino_groups * 2 * 16 * 64;
+            VS_TRY(h->wpw.reserve(nw * sizeof(float)));
+            PackParams qw;
+            memset(&qw, 0, sizeof(qw));
+            qw.w = h->wp.as<float>(); qw.wp = h->wpw.as<float>(); qw.k = h->k; qw.KT = h->KT; qw.MT_alloc = h->MT_alloc;
+            qw.wino_tail1 = (h->wino_k7 || h->wino_k11) ? 1 : 0;
+            hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)ceil_div((long long)nw, 256)), dim3(256), 0, s, qw, h->wino_groups, h->nchunks);
+            VS_CHECK_HIP(hipGetLastError());
+            h->wino_packed = true;
+        }
         q.wp = h->wpw.as<float>();
         q.KT = h->wino_groups;
         q.lo = -h->pad;

@@ -79,7 +79,8 @@ struct vs_conv {
     int M, MT, MT_alloc, KT, CP, nchunks, off0, tstep, lo, span, dmin, Hh;
     bool weights_set = false;
     vs::DevBuf wp, biasp, scale, weff, beff;   // weff/beff: unpacked effective weights (c_out <= 4 VALU path)
-    vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), when wino_groups > 0
+    vs::DevBuf wpw;                            // Winograd-domain fragments (conv_wino_kernel), built from wp by the first launch that uses them
+    bool wino_packed = false;                  // wpw holds the transform of the current weight version
     int wino_groups = 0;                       // ceil(k / 3) if the conv is eligible for the F(2,3) path, else 0
     bool wino_k7 = false;                      // k = 7 on an even tile count: the TG = 3 instances (direct-form last tap)
     bool wino_k11 = false;                     // k = 11: the TG = 4 instances (F(2,2) last group, 2-slot ring)
