@@ -401,7 +401,8 @@ def main():
         step_tflops = step_flops / (dt / args.steps) / 1e12
         kern_ms = sum(v["ms"] for v in prof.values())
         if name.startswith(("conv_split_kernel", "respair_split_kernel")):
-            terms = int(name.rstrip(">").split(",")[-1])        # last template argument of both kernels: cross products per fp32 product
+            targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
+            terms = int([a for a in targs if a.isdigit()][-1])        # last integer template argument of both kernels: cross products per fp32 product
             peak = BF16_MFMA_PEAK_TFLOPS / terms
             peak_name = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
                          f"this arithmetic for fp32-class results" if terms > 1 else "dense bf16 MFMA peak")
