@@ -260,6 +260,8 @@ def parse_args():
                     help="arithmetic of the conv engine (include/visinger_hip.h vs_conv_math): split6 = fp32-class split-bf16 "
                          "(default, the headline), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 operands (BASELINE config 5)")
     ap.add_argument("--dropout", type=float, default=0.1, help="config 3: p_dropout of the transformers (reference config: 0.1)")
+    ap.add_argument("--storage", default=None, choices=("f32", "bf16"),
+                    help="element type of the generator's wide-stage activations in HBM (bf16 only with --math bf16; default: bf16 for --config 5)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (no GPU work): every rank joins the process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -269,6 +271,10 @@ def parse_args():
     args.hidden = args.hidden if args.hidden is not None else preset.get("hidden", 192)
     if args.math is None:
         args.math = "bf16" if preset.get("math") == "bf16" else "split6"
+    if args.storage is None:
+        args.storage = "bf16" if (args.config == 5 and args.math == "bf16") else "f32"
+    if args.storage == "bf16" and args.math != "bf16":
+        raise SystemExit("--storage bf16 needs --math bf16")
     return args
 
 
@@ -350,6 +356,9 @@ def main():
 
     model, hp = build_model(hop=args.hop, hidden=args.hidden)
     model = model.to(dev)
+    if args.storage == "bf16":
+        from visinger_amd.modules.hipconv import set_activation_storage
+        set_activation_storage(model, torch.bfloat16)
     # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
     gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", ragged=args.ragged, hidden=args.hidden)
     text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
@@ -402,7 +411,8 @@ def main():
         kern_ms = sum(v["ms"] for v in prof.values())
         if name.startswith(("conv_split_kernel", "respair_split_kernel")):
             targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
-            terms = int([a for a in targs if a.isdigit()][-1])        # last integer template argument of both kernels: cross products per fp32 product
+            ints = [int(a) for a in targs if a.isdigit()]
+            terms = ints[4] if name.startswith("conv_split_kernel") else ints[-1]     # cross products per fp32 product (5th / last template argument)
             peak = BF16_MFMA_PEAK_TFLOPS / terms
             peak_name = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
                          f"this arithmetic for fp32-class results" if terms > 1 else "dense bf16 MFMA peak")
@@ -454,7 +464,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE[args.math],
+            "dtype": DTYPE[args.math] if args.storage == "f32" else "bf16 operands, f32 accumulate (bf16-resident activations in the generator's >= 128-channel stages, f32 elsewhere)",
             "data": "synthetic",
             "config": {"workload": workload + f"B={B}/GPU T_mel={T} hop={HOP} hidden={args.hidden} fp32 tensors, random-init weights",
                        "baseline_config": args.config or "headline (north_star: B=32, T_mel=1024, hop 256)",

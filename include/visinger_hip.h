@@ -98,6 +98,13 @@ enum vs_conv_math { VS_MATH_F32 = 0, VS_MATH_BF16 = 1, VS_MATH_SPLIT6 = 6 };
 VS_API int vs_conv_set_math(vs_conv_t *h, int math, void *stream);
 VS_API int vs_conv_get_math(const vs_conv_t *h);
 
+/* Element type of a conv launch's activation tensors.  VS_DTYPE_BF16 = bf16-RESIDENT activations (BASELINE.json config 5: "bf16
+ * activations"): with VS_MATH_BF16 every product rounds its operands to bf16 anyway, and on the bf16 matrix pipe the 128- / 256-channel
+ * convs are HBM-bound with fp32 tensors (x + residual + y at 4.3-4.6 TB/s).  Plain VS_CONV1D / VS_CONV_TRANSPOSE1D launches in
+ * VS_MATH_BF16 with VS_OUT_LINEAR outputs and no split_row; all strides stay in ELEMENTS; mask and bias_b stay fp32; y is rounded to
+ * nearest even once, after residual / accumulate / scale / activation in fp32.                                                  */
+enum vs_dtype { VS_DTYPE_F32 = 0, VS_DTYPE_BF16 = 1 };
+
 /* One output destination of a conv launch.  Strides are in floats; row stride is always the time length. */
 typedef struct vs_conv_out {
     float *y;            /* [B, rows, T_out] with batch stride y_bs                                              */
@@ -115,11 +122,13 @@ typedef struct vs_conv_io {
     int64_t x_bs;
     int64_t B, T;
     int in_act;          /* enum vs_in_act, applied while staging x into LDS                                     */
+    int x_dtype;         /* enum vs_dtype of x (ABI 3; occupies what was padding: 0 = fp32 as before)            */
     const float *mask;   /* [B, T] frame mask for VS_IN_MASK / out_mask / coupling modes (NULL if unused)        */
     const float *bias_b; /* optional per-item bias [B, c_out] (conditioning), row stride bias_b_bs               */
     int64_t bias_b_bs;
     int split_row;       /* rows [0, split_row) go to out[0], rows [split_row, c_out) to out[1] (row - split_row);
                             0 or >= c_out: everything goes to out[0]                                             */
+    int y_dtype;         /* enum vs_dtype of out[0].y / res / acc (ABI 3; was padding)                           */
     vs_conv_out_t out[2];
     int pair_mode;       /* PAIRED only: enum vs_pair_mode; result rows = c_out/2, written through out[0]
                             (res = x1 for the coupling modes)                                                    */

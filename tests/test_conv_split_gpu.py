@@ -261,3 +261,62 @@ def test_split6_attention_is_fp32_class(oracle, dk, nh, T, ws, share):
     e32 = float((ref32.cpu().double() - ref64).abs().max())
     print(f"attention dk={dk} T={T}: max err vs fp64 split6 {e6:.2e}, fp32 MFMA {e32:.2e}")
     assert e6 <= 2e-5 and e6 <= 3.0 * e32 + 2e-6
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,k,d_or_u,T,B", [(L.CONV1D, 256, 256, 7, 3, 1024, 2), (L.CONV1D, 128, 128, 11, 5, 700, 1), (L.CONV1D, 512, 256, 3, 1, 261, 2),
+                                                       (L.CONV1D, 200, 136, 7, 1, 33, 3), (L.CONV1D, 64, 128, 3, 1, 4096, 1), (L.CONV1D, 40, 96, 5, 2, 1000, 1),
+                                                       (L.CONV_TRANSPOSE1D, 512, 256, 16, 8, 96, 2), (L.CONV_TRANSPOSE1D, 128, 64, 4, 2, 515, 1),
+                                                       (L.CONV1D, 192, 512, 7, 1, 40, 1)])
+def test_bf16_resident_tensors_are_the_bf16_arithmetic_on_rounded_tensors(kind, Cin, Cout, k, d_or_u, T, B):
+    """vs_dtype (include/visinger_hip.h): bf16-RESIDENT x / y / res / acc in the plain-bf16 arithmetic.  That arithmetic rounds every conv
+    operand to bf16 while staging, so a launch on a bf16 tensor must equal -- BIT FOR BIT -- the launch on the same values held in fp32,
+    and a bf16 output must be the round-to-nearest-even of the fp32 output (residual / accumulate / scale / ReLU applied in fp32 before the
+    one rounding): the 128-row tile shape these tensors are supported on (>= 96 output rows), interior and ragged tiles (vector and element-wise epilogues), both sequence
+    ends, transposed convs, input leaky-relu / mask, per-item bias."""
+    from visinger_amd.ops import ConvOp
+    g = torch.Generator().manual_seed(Cin + Cout * 3 + k + T)
+    tr = kind == L.CONV_TRANSPOSE1D
+    pad = (k - d_or_u) // 2 if tr else d_or_u * (k - 1) // 2
+    op = ConvOp(kind, Cin, Cout, k, d_or_u, pad).set_math(L.MATH_BF16)
+    w = torch.randn((Cin, Cout, k) if tr else (Cout, Cin, k), generator=g) / np.sqrt(Cin * k / (d_or_u if tr else 1))
+    op.set_weights(w.cuda(), None, torch.randn(Cout, generator=g).cuda())
+    xb = torch.randn(B, Cin, T, generator=g).cuda().bfloat16()
+    Tout = op.out_len(T)
+    mask = torch.ones(B, T)
+    mask[-1, (2 * T) // 3:] = 0
+    mask = mask.cuda()
+    cond = torch.randn(B, Cout, generator=g).cuda()
+    resb = torch.randn(B, Cout, Tout, generator=g).cuda().bfloat16()
+    accb = torch.randn(B, Cout, Tout, generator=g).cuda().bfloat16()
+    variants = [dict(in_act=L.IN_LRELU), dict(in_act=L.IN_LRELU_MASK, mask=mask, bias_b=cond)]
+    if not tr:
+        variants += [dict(in_act=L.IN_LRELU, res=True), dict(in_act=L.IN_LRELU, res=True, acc=True, scale=1.0 / 3, out_act=L.OUT_RELU),
+                     dict(in_act=L.IN_LRELU_MASK, mask=mask, res=True, out_mask=True)]
+    for kw in variants:
+        kw = dict(kw)
+        use_res, use_acc = kw.pop("res", False), kw.pop("acc", False)
+        ref = op.forward(xb.float(), res=resb.float() if use_res else None, acc=accb.float() if use_acc else None, **kw)     # fp32 tensors
+        assert op.kernel_instance().startswith("conv_split_kernel<1, ")      # (short launches take smaller tiles; same sums, same order)
+        if not use_res:
+            y1 = op.forward(xb, **kw)                                                                                        # bf16 in, fp32 out
+            assert y1.dtype == torch.float32 and torch.equal(y1, ref), (kw, float((y1 - ref).abs().max()))
+            assert op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 1>", op.kernel_instance()
+        y3 = op.forward(xb, res=resb if use_res else None, acc=accb if use_acc else None, y_dtype=torch.bfloat16, **kw)        # bf16 in / out
+        assert y3.dtype == torch.bfloat16 and torch.equal(y3, ref.bfloat16()), (kw, float((y3.float() - ref).abs().max()))
+        assert op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 3>", op.kernel_instance()
+        if not use_res:
+            y2 = op.forward(xb.float(), y_dtype=torch.bfloat16, **kw)                                                        # fp32 in, bf16 out
+            assert torch.equal(y2, ref.bfloat16()) and op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 2>"
+    # loud refusals: another arithmetic, mismatched residual type, a conv of fewer than 96 rows (no bf16-tensor instance of its tile shape)
+    if not tr:
+        small = ConvOp(kind, Cin, 64, k, d_or_u, pad).set_math(L.MATH_BF16)
+        small.set_weights(w[:64].contiguous().cuda(), None, None)
+        with pytest.raises(L.VisingerHipError):
+            small.forward(xb)
+    op6 = ConvOp(kind, Cin, Cout, k, d_or_u, pad).set_math(L.MATH_SPLIT6)
+    op6.set_weights(w.cuda(), None, None)
+    with pytest.raises(L.VisingerHipError):
+        op6.forward(xb)
+    if not tr:
+        with pytest.raises(L.VisingerHipError):
+            op.forward(xb, res=resb.float(), y_dtype=torch.bfloat16)

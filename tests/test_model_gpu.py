@@ -317,3 +317,38 @@ def test_full_size_model_end_to_end_vs_oracle(oracle, hop):
         wav = m(text.cuda(), pitch.cuda(), dur.cuda(), mel2ph.cuda(), spk_id=spk.cuda(), infer=True, noise=noise.cuda())["wav_out"]
     assert wav.shape == (B, T * hop)
     assert maxerr(wav, ref["wav_out"]) <= 1e-4
+
+
+def test_generator_with_bf16_resident_activations(oracle, capsys):
+    """BASELINE config 5 ("bf16 activations"): the generator with the activations of its >= 128-channel stages held as bf16 tensors
+    (hipconv.set_activation_storage + L.MATH_BF16) against the fp64 oracle and against the same arithmetic on fp32 tensors: the extra
+    error of the bf16 residual stream stays within a small multiple of the arithmetic's own, and the waveform stays within the stated
+    bf16 tolerance of the config-5 test (rms 2e-2 of the signal rms)."""
+    from visinger_amd.modules.hipconv import set_activation_storage, set_conv_math
+    from visinger_amd.modules.visinger.decoder import Generator
+    B, T = 2, 24
+    gen = Generator(192, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 2, 2], 512, [16, 16, 4, 4], gin_channels=256)
+    sdg = _rand_sd(gen, 21)
+    gen = gen.cuda().eval()
+    r = np.random.default_rng(257)
+    z = r.standard_normal((B, 192, T)).astype(np.float32)
+    g = r.standard_normal((B, 256, 1)).astype(np.float32)
+    wav_ref = oracle.generator(sdg, z, g, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
+                               upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4])
+    set_activation_storage(gen, torch.bfloat16)
+    with pytest.raises(L.VisingerHipError):            # not with the fp32-class arithmetic
+        with torch.no_grad():
+            gen(cu(z), g=cu(g))
+    set_conv_math(gen, L.MATH_BF16)
+    with torch.no_grad():
+        wav_b = gen(cu(z), g=cu(g))
+        set_activation_storage(gen, None)
+        wav_f = gen(cu(z), g=cu(g))
+    set_conv_math(gen, None)
+    assert wav_b.dtype == torch.float32 and wav_b.shape == wav_f.shape and bool(torch.isfinite(wav_b).all())
+    rms = float(np.sqrt((wav_ref ** 2).mean()))
+    eb = float(np.sqrt(((wav_b.double().cpu().numpy() - wav_ref) ** 2).mean()))
+    ef = float(np.sqrt(((wav_f.double().cpu().numpy() - wav_ref) ** 2).mean()))
+    with capsys.disabled():
+        print(f"\n   bf16 arithmetic, waveform rms error vs fp64 / signal rms: fp32 tensors {ef / rms:.2e}, bf16-resident wide stages {eb / rms:.2e}")
+    assert eb <= 2e-2 * rms and eb <= 4 * ef + 1e-6

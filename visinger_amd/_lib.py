@@ -20,6 +20,7 @@ MODE_LINEAR, MODE_COUPLING_MEAN_FWD, MODE_COUPLING_MEAN_INV = 0, 1, 2
 FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 # enum vs_conv_math
 MATH_F32, MATH_BF16, MATH_SPLIT6 = 0, 1, 6
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _f32p = ctypes.c_void_p
 
@@ -33,8 +34,8 @@ class ConvOut(ctypes.Structure):
 
 class ConvIO(ctypes.Structure):
     _fields_ = [("x", _f32p), ("x_bs", ctypes.c_int64), ("B", ctypes.c_int64), ("T", ctypes.c_int64),
-                ("in_act", ctypes.c_int), ("mask", _f32p), ("bias_b", _f32p), ("bias_b_bs", ctypes.c_int64),
-                ("split_row", ctypes.c_int), ("out", ConvOut * 2), ("pair_mode", ctypes.c_int),
+                ("in_act", ctypes.c_int), ("x_dtype", ctypes.c_int), ("mask", _f32p), ("bias_b", _f32p), ("bias_b_bs", ctypes.c_int64),
+                ("split_row", ctypes.c_int), ("y_dtype", ctypes.c_int), ("out", ConvOut * 2), ("pair_mode", ctypes.c_int),
                 ("logdet", _f32p)]
 
 
@@ -130,6 +131,16 @@ def require_gpu():
 def stream_ptr():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def act_ptr(t):
+    """(device pointer, vs_dtype) of a contiguous fp32 or bf16 activation tensor (None -> (NULL, fp32))."""
+    if t is None:
+        return None, DTYPE_F32
+    import torch
+    if not (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous()):
+        raise VisingerHipError(f"expected a contiguous fp32 / bf16 tensor on the GPU, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    return ctypes.c_void_p(t.data_ptr()), (DTYPE_BF16 if t.dtype == torch.bfloat16 else DTYPE_F32)
 
 
 def ptr(t):

@@ -45,6 +45,7 @@ struct ConvParams {
     int up, upK, uppad, dmin;   // transposed: stride, kernel, padding, min delta
     int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
     int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
+    int x_bf16, y_bf16;         // bf16-RESIDENT tensors (plain-bf16 arithmetic only): x / (y, res, acc) hold bf16 elements; strides in elements
     int dbg;                    // perturbation experiments (VS_WINO_DBG: 1 = no weight-fragment loads, 2 = no staging), 0 in production
     unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
 };
@@ -82,6 +83,13 @@ __device__ __forceinline__ unsigned rne_bf16(float v) {       // bf16 bits in th
     const unsigned u = f2u(v);
     return u + 0x7fffu + ((u >> 16) & 1u);
 }
+// four consecutive bf16 elements <-> float4 (bf16-resident tensors)
+__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
+    return make_float4(u2f(u.x << 16), u2f(u.x & 0xffff0000u), u2f(u.y << 16), u2f(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 f4_to_bf4(float4 v) {
+    return make_uint2(pack_hi(rne_bf16(v.x), rne_bf16(v.y)), pack_hi(rne_bf16(v.z), rne_bf16(v.w)));
+}
 // planes of a pair of values -> one packed dword per plane
 template <int NPL>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NPL]) {
@@ -111,7 +119,7 @@ struct vs_split_pack {            // re-pack of the fp32 fragment-order weights 
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);
 // cfg: tile shape as chosen by vs_conv_forward for the direct engine (0: 128 rows, 1/3: 64, 2: 32 x 256, 6: 32 x 128; 4/5: paired); span = receptive span
-int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);
+int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);   // (p.x_bf16 / p.y_bf16: terms = 1, cfg 0 / 2 / 3 / 6)
 
 
 // conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)

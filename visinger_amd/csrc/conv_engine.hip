@@ -1147,7 +1147,7 @@ extern "C" {
 
 const char *vs_last_error(void) { return g_err; }
 const char *vs_last_kernel_name(void) { return g_last_kernel; }
-int vs_abi_version(void) { return 2; }
+int vs_abi_version(void) { return 3; }
 
 int vs_device_info(char *buf, size_t n) {
     int cnt = 0;
@@ -1350,6 +1350,15 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     p.upK = h->k; p.uppad = h->pad; p.dmin = h->dmin;
     const int rows_out = (h->kind == VS_CONV1D_PAIRED) ? h->Hh : h->c_out;
     p.split_row = (io->split_row > 0 && io->split_row < rows_out && h->kind != VS_CONV1D_PAIRED) ? io->split_row : 0;
+    VS_REQUIRE((io->x_dtype == VS_DTYPE_F32 || io->x_dtype == VS_DTYPE_BF16) && (io->y_dtype == VS_DTYPE_F32 || io->y_dtype == VS_DTYPE_BF16),
+               "vs_conv_forward: unknown element type");
+    p.x_bf16 = io->x_dtype == VS_DTYPE_BF16;
+    p.y_bf16 = io->y_dtype == VS_DTYPE_BF16;
+    if (p.x_bf16 || p.y_bf16) {
+        VS_REQUIRE(h->math == VS_MATH_BF16, "vs_conv_forward: bf16-resident tensors need the plain-bf16 arithmetic (VS_MATH_BF16)");
+        VS_REQUIRE(h->kind != VS_CONV1D_PAIRED && !p.split_row && (io->out[0].mode == VS_OUT_LINEAR || !p.y_bf16),
+                   "vs_conv_forward: bf16-resident tensors go with plain LINEAR launches (no PAIRED kind, no split_row)");
+    }
     bool need_mask = (io->in_act >= VS_IN_MASK);
     bool need_out_mask = false;      // a mask indexed by OUTPUT position: only defined where T_out == T (never for a transposed conv)
     VS_REQUIRE(io->in_act >= VS_IN_NONE && io->in_act <= VS_IN_LRELU_MASK, "vs_conv_forward: bad in_act");
@@ -1396,6 +1405,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // stream a long input once; the discriminators' 1024 -> 1 conv_post over a few thousand positions needs the parallelism of
     // the MFMA tiles even at 1 valid row in 32)
     if (h->kind == VS_CONV1D && h->c_out <= 4 && h->c_in * h->k <= 2048 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT | VS_CONV_ADJOINT)) && !p.split_row &&
+        !p.x_bf16 && !p.y_bf16 &&
         !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {
         SmallParams q;
         q.x = p.x; q.x_bs = p.x_bs; q.w = h->weff.as<float>(); q.bias = h->has_bias ? h->beff.as<float>() : nullptr;
@@ -1510,7 +1520,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // the chip idle while each workgroup runs its full K loop -- the launch lasts as long as ONE workgroup.  On the bf16-pipe
     // engine take 64-row (then 32-row) tiles until the grid covers the CUs: the same kernel family, 2x / 4x the workgroups, each
     // with half / a quarter of the MFMAs per wave (B=1, T_mel=1024 synthesis latency: DESIGN.md 4.2).
-    if (h->math && !getenv("VS_NO_SMALL_GRID")) {
+    if (h->math && !getenv("VS_NO_SMALL_GRID") && !p.x_bf16 && !p.y_bf16) {      // (bf16-resident tensors: the 128-row instance only)
         const long long ncol = ceil_div(p.N, 256) * p.B;
         if (cfg == 0 && ncol * ceil_div(h->MT, 4) < 256) cfg = 3;
         if (cfg == 3 && ncol * ceil_div(h->MT, 2) < 256 && (long long)p.N * p.B <= 65536) cfg = 2;
@@ -1519,6 +1529,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     }
     if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
     if (h->math) p.wp = h->ws.as<float>();
+    if (h->math) { if (const char *e = getenv("VS_SPLIT_DBG")) p.dbg = atoi(e); }
     auto launch = [&](const ConvParams &q) -> int {
         if (h->math) return launch_split(q, cfg, h->math, h->span, s);
         switch (cfg) {

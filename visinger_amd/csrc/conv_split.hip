@@ -26,265 +26,37 @@
 
 namespace vs {
 
+// Timing-only perturbations of the main loop (results are garbage): build with -DVS_SPLIT_PERTURB and set VS_SPLIT_DBG to a sum of
+// 1 = no weight-fragment loads after the first steps, 2 = no activation loads after the prologue, 4 = no split + LDS write of the next
+// chunk, 8 = no B-fragment reads.  Compiled out by default: a run-time test per column tile in the hot loop cost 1.6 % of the headline.
+#ifdef VS_SPLIT_PERTURB
+#define PERTURB(bit) ((p.dbg & (bit)) != 0)
+#else
+#define PERTURB(bit) false
+#endif
+
 int split_planes(int terms) { return terms == 1 ? 1 : (terms == 3 ? 2 : 3); }
 
 template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams p) {
-    static_assert(WAVES_M * WAVES_N == 4, "four waves: a wave stages four consecutive channels of a 16-channel chunk");
-    constexpr int NPL = (TERMS == 1) ? 1 : (TERMS == 3 ? 2 : 3);
-    constexpr int BN = 32 * NT_W * WAVES_N;
-    constexpr int MAXW = BN + MAX_SPAN;
-    constexpr int CIT = (MAXW + 63) / 64;        // column iterations per staged row
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool XB = false;
+#define VS_EPILOGUE_INC "conv_epilogue.inc"
+#include "conv_split_body.inc"
+#undef VS_EPILOGUE_INC
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave % WAVES_M;
-    const int wn = wave / WAVES_M;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.x * BN;
-    const int mt0 = (blockIdx.y * WAVES_M + wm) * MT_W;
-    const int W = p.W;
-    const int PLSZ = 2 * W * 4;                  // dwords per plane: [k-group][column][4 dwords = 8 bf16]
-    unsigned *const lbuf0 = reinterpret_cast<unsigned *>(smem);
-    unsigned *const lbuf1 = lbuf0 + NPL * PLSZ;
-    const float *const xb = p.x + (long long)b * p.x_bs;
-    const float *const maskb = p.mask ? p.mask + (long long)b * p.Tin : nullptr;
-
-    // ---- tap range of this wave (polyphase transposed conv), as in conv_mfma_kernel ----
-    int tap_b = 0, tap_e = p.KT;
-    if (p.kind == VS_CONV_TRANSPOSE1D && (p.c_out & 31) == 0) {
-        int lo_t = p.KT, hi_t = 0;
-#pragma unroll
-        for (int i = 0; i < MT_W; ++i) {
-            const int phase = ((mt0 + i) * 32) / p.c_out;
-            if (phase < p.up) {
-                const int num_lo = -(phase + p.uppad);
-                const int dlo = (num_lo >= 0) ? (num_lo + p.up - 1) / p.up : -((-num_lo) / p.up);
-                const int num_hi = p.upK - 1 - phase - p.uppad;
-                const int dhi = (num_hi >= 0) ? num_hi / p.up : -((-num_hi + p.up - 1) / p.up);
-                lo_t = min(lo_t, dlo - p.dmin);
-                hi_t = max(hi_t, dhi - p.dmin + 1);
-            }
-        }
-        tap_b = max(0, lo_t);
-        tap_e = min(p.KT, hi_t);
-        if (tap_e <= tap_b) { tap_b = 0; tap_e = 1; }     // padding-only wave: keeps its seat at the chunk barriers
-    }
-
-    // accumulators start from the bias (+ per-item conditioning bias) of their row
-    const float *const bbias = p.bias_b ? p.bias_b + (long long)b * p.bias_b_bs : nullptr;
-    f32x16 acc[MT_W][NT_W];
-#pragma unroll
-    for (int i = 0; i < MT_W; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rt = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int m = (mt0 + i) * 32 + rt;
-            float bv = p.biasp[m];
-            if (bbias) {
-                int row;
-                if constexpr (MT_W == 2) {
-                    row = (i & 1) * p.Hh + min((mt0 >> 1) * 32 + rt, p.Hh - 1);
-                } else {
-                    const int mc = min(m, p.M - 1);
-                    row = (p.kind == VS_CONV_TRANSPOSE1D) ? mc % p.c_out : mc;
-                }
-                bv += bbias[row];
-            }
-#pragma unroll
-            for (int j = 0; j < NT_W; ++j) acc[i][j][r] = bv;
-        }
-
-    // ---- staging: wave w owns channels 4w .. 4w+3 of every chunk (k-group w/2, dwords (w&1)*2 .. +1 of the 16-B cell) ----
-    float st[4][CIT];
-    float mk[CIT];
-    const int in_act = p.in_act;
-    const __amdgpu_buffer_rsrc_t xsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.Cin * p.Tin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t msrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(maskb ? maskb : xb), 0, p.Tin * 4, 0x00020000);
-    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
-        const int nbase = n0 + p.lo + lane;
-        if (in_act >= VS_IN_MASK) {
-#pragma unroll
-            for (int i = 0; i < CIT; ++i)
-                mk[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msrc, nbase * 4 + i * 256, 0, 0));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ci = min(chunk * CK + 4 * wave + j, p.Cin - 1);
-            const int voff = (ci * p.Tin + nbase) * 4;
-#pragma unroll
-            for (int i = 0; i < CIT; ++i)
-                st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
-        }
-    };
-    const bool time_edge = (n0 + p.lo < 0) || (n0 + p.lo + W > p.Tin);
-    auto stage_store = [&](unsigned *buf, int chunk) __attribute__((always_inline)) {
-        auto run = [&](auto edge_tag, auto act_tag) __attribute__((always_inline)) {
-            constexpr bool EDGE = decltype(edge_tag)::value;
-            constexpr int ACT = decltype(act_tag)::value;
-            unsigned *const dst0 = buf + ((wave >> 1) * W + lane) * 4 + (wave & 1) * 2;
-#pragma unroll
-            for (int i = 0; i < CIT; ++i) {
-                const int col = lane + 64 * i;
-                const int n = n0 + p.lo + col;
-                const bool okn = (n >= 0) && (n < p.Tin);
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = st[j][i];
-                    if constexpr (EDGE) v[j] = (okn && (chunk * CK + 4 * wave + j < p.Cin)) ? v[j] : 0.f;
-                    if constexpr (ACT == VS_IN_LRELU || ACT == VS_IN_LRELU_MASK) v[j] = fmaxf(v[j], 0.1f * v[j]);
-                    if constexpr (ACT >= VS_IN_MASK) v[j] *= mk[i];
-                }
-                unsigned d0[NPL], d1[NPL];
-                split_pair<NPL>(v[0], v[1], d0);
-                split_pair<NPL>(v[2], v[3], d1);
-                if (64 * (i + 1) <= BN || col < W) {
-#pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl)
-                        *reinterpret_cast<uint2 *>(dst0 + pl * PLSZ + i * 256) = make_uint2(d0[pl], d1[pl]);
-                }
-            }
-        };
-        const bool edge = time_edge || (chunk * CK + CK > p.Cin);
-        if (edge) {
-            if (in_act == VS_IN_NONE) run(std::true_type{}, std::integral_constant<int, VS_IN_NONE>{});
-            else if (in_act == VS_IN_LRELU) run(std::true_type{}, std::integral_constant<int, VS_IN_LRELU>{});
-            else if (in_act == VS_IN_MASK) run(std::true_type{}, std::integral_constant<int, VS_IN_MASK>{});
-            else run(std::true_type{}, std::integral_constant<int, VS_IN_LRELU_MASK>{});
-        } else {
-            if (in_act == VS_IN_NONE) run(std::false_type{}, std::integral_constant<int, VS_IN_NONE>{});
-            else if (in_act == VS_IN_LRELU) run(std::false_type{}, std::integral_constant<int, VS_IN_LRELU>{});
-            else if (in_act == VS_IN_MASK) run(std::false_type{}, std::integral_constant<int, VS_IN_MASK>{});
-            else run(std::false_type{}, std::integral_constant<int, VS_IN_LRELU_MASK>{});
-        }
-    };
-
-    const int lhalf = lane >> 5;
-    const int l31 = lane & 31;
-
-    // ---------------------------------------------------------------------------------------------- main loop
-    // Steps s = (chunk, tap).  A fragments of step s+1 (NPL 16-byte loads per row tile, L2/L1-resident) are requested at the
-    // start of step s into the other of two NAMED register sets; activations as in conv_mfma_kernel: chunk c+2 is requested
-    // at the first tap of chunk c and lives in registers, chunk c+1 is split and written to the other LDS buffer there.
-    //
-    // The A loads are inline asm with HAND-COUNTED vmcnt waits.  Left to hipcc, the wait in front of a step's first MFMA is
-    // vmcnt(0) (its scoreboard goes flat across the conditional staging block and the back edge), which also waits for the
-    // fragments requested a few instructions earlier for the NEXT step and for the activation loads of chunk c+2: one exposed
-    // L2 round trip per step and one HBM round trip per chunk -- at bf16 MFMA speed that was 40 % of the kernel.  vmcnt counts
-    // loads in issue order, so "fragments of THIS step have landed" is vmcnt(n) with n = everything issued after them: the
-    // activation loads of the previous step (if it staged), this step's A prefetch, this step's activation loads (if it
-    // stages).  (hipcc's own waits for its buffer loads do not know about the asm loads and are therefore merely stricter.)
-    // The count assumes no other vector-memory instruction in the loop: csrc/build.py fails the build if an instance of this
-    // kernel uses scratch (a spill would be one).
-    const int ntaps = tap_e - tap_b;
-    const int nsteps = p.nchunks * ntaps;
-    const u32x4 *wbase[MT_W];
-#pragma unroll
-    for (int i = 0; i < MT_W; ++i)
-        wbase[i] = reinterpret_cast<const u32x4 *>(p.wp) + (long long)(mt0 + i) * p.KT * p.nchunks * (NPL * 64) + lane;
-    u32x4 a0[MT_W][NPL], a1[MT_W][NPL];
-    auto load_a = [&](u32x4 (&dst)[MT_W][NPL], int chunk, int tap) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < MT_W; ++i) {
-            const u32x4 *src = wbase[i] + ((long long)tap * p.nchunks + chunk) * (NPL * 64);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst[i][0]) : "v"(src) : "memory");
-            if constexpr (NPL > 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=&v"(dst[i][1]) : "v"(src) : "memory");
-            if constexpr (NPL > 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=&v"(dst[i][2]) : "v"(src) : "memory");
-        }
-    };
-    constexpr int NA = MT_W * NPL;                              // A loads per step
-    const int NY = ((in_act >= VS_IN_MASK) ? 5 : 4) * CIT;       // activation (+ mask) loads of one stage_load
-    // wait until at most n vector-memory loads are outstanding (n < 64), then pin the fragment registers behind the wait
-    auto wait_a = [&](u32x4 (&a)[MT_W][NPL], int n) __attribute__((always_inline)) {
-        if (n >= NA + 2 * NY && NA + 2 * 5 * CIT < 64) {
-            if (NY == 4 * CIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 8 * CIT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 10 * CIT < 64 ? NA + 10 * CIT : 0) : "memory");
-        } else if (n >= NA + NY) {
-            if (NY == 4 * CIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 4 * CIT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + 5 * CIT) : "memory");
-        } else if (n >= NA) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int i = 0; i < MT_W; ++i)
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) asm volatile("" : "+v"(a[i][pl]));
-    };
-    int pc = 0, pt = tap_b;      // (chunk, tap) of the step after the current one
-    auto advance = [&]() __attribute__((always_inline)) { if (++pt == tap_e) { pt = tap_b; ++pc; } };
-    if (nsteps > 0) { load_a(a0, pc, pt); advance(); }
-
-    stamp(p, 0);
-    stage_load(0);
-    stage_store(lbuf0, 0);          // (hipcc waits vmcnt(0) for the staged registers: covers a0 as well)
-    if (p.nchunks > 1) stage_load(1);
-    __syncthreads();
-    stamp(p, 1);
-
-    int chunk = 0, tap = tap_b, s = 0;
-    int ny_prev = (p.nchunks > 1) ? NY : 0;      // activation loads issued after the A loads of the current step
-    auto step = [&](u32x4 (&acur)[MT_W][NPL], u32x4 (&apre)[MT_W][NPL]) __attribute__((always_inline)) {
-        const unsigned *cur = (chunk & 1) ? lbuf1 : lbuf0;
-        const bool more = (chunk + 1 < p.nchunks);
-        const bool first = (tap == tap_b);
-        if (first && more) stage_store((chunk & 1) ? lbuf0 : lbuf1, chunk + 1);
-        int young = ny_prev;
-        if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); young += NA; }
-        ny_prev = 0;
-        if (first && chunk + 2 < p.nchunks) { stage_load(chunk + 2); young += NY; ny_prev = NY; }
-        const unsigned *xs = cur + (lhalf * W + wn * (NT_W * 32) + l31 - p.lo + (p.off0 + tap * p.tstep)) * 4;
-        u32x4 bf[NPL], bn[NPL];
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ);
-        wait_a(acur, young);
-#pragma unroll
-        for (int j = 0; j < NT_W; ++j) {
-            if (j + 1 < NT_W) {
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) bn[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ + (j + 1) * 128);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MT_W; ++i) {
-                auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[i][ta]),
-                                                                        __builtin_bit_cast(bf16x8, bf[tb]), acc[i][j], 0, 0, 0);
-                };
-                // smallest terms first
-                if constexpr (TERMS == 6) { mm(1, 1); mm(2, 0); mm(0, 2); }
-                if constexpr (TERMS >= 3) { mm(1, 0); mm(0, 1); }
-                mm(0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) bf[pl] = bn[pl];
-        }
-        if (++tap == tap_e) {
-            __syncthreads();
-            tap = tap_b;
-            ++chunk;
-        }
-        ++s;
-    };
-    while (s < nsteps) {
-        step(a0, a1);
-        if (s < nsteps) step(a1, a0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of the asm loads may be in flight past here
-
-    stamp(p, 2);
-#include "conv_epilogue.inc"
-    if (p.stamps) {
-        __builtin_amdgcn_s_waitcnt(0);
-        stamp(p, 3);
-    }
+// bf16-RESIDENT tensors (plain-bf16 arithmetic only, BASELINE config 5): IO bit 0 -- x holds bf16 elements (widened on the way into LDS:
+// every product of this arithmetic rounds its operands to bf16 anyway), bit 1 -- y / res / acc do (rounded to nearest even once, after
+// residual / accumulate / scale / activation in fp32).  A kernel template of its own over the same body: generalising the fp32 instances
+// in place changed their register allocation (see conv_epilogue_bf16.inc).
+template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS, int IO>
+__global__ void __launch_bounds__(256, 2) conv_split_kernel_bf16io(const ConvParams p) {
+    static_assert(TERMS == 1 && IO >= 1 && IO <= 3, "bf16-resident tensors go with the plain-bf16 arithmetic");
+    constexpr bool XB = (IO & 1) != 0;
+    constexpr bool EPI_YB = (IO & 2) != 0;
+#define VS_EPILOGUE_INC "conv_epilogue_bf16.inc"
+#include "conv_split_body.inc"
+#undef VS_EPILOGUE_INC
 }
 
 // Ws[m_tile][tap][chunk][plane][64 lanes][8 bf16] from the fp32 fragment-order weights Wp[m_tile][tap][chunk][quad(2)][64][4]
@@ -329,12 +101,15 @@ int pack_split(const vs_split_pack &q, hipStream_t s) {
     return VS_OK;
 }
 
-template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
+template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS, int IO = 0>
 static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int BM_TILES = MT_W * WAVES_M;
     constexpr int NPL = (TERMS == 1) ? 1 : (TERMS == 3 ? 2 : 3);
-    auto kern = conv_split_kernel<MT_W, NT_W, WAVES_M, WAVES_N, TERMS>;
+    auto kern = [] {
+        if constexpr (IO == 0) return conv_split_kernel<MT_W, NT_W, WAVES_M, WAVES_N, TERMS>;
+        else return conv_split_kernel_bf16io<MT_W, NT_W, WAVES_M, WAVES_N, TERMS, IO>;
+    }();
     p.W = BN + span;
     const size_t lds = std::max<size_t>((size_t)2 * NPL * 2 * p.W * 16, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
     static bool attr_set = false;
@@ -345,7 +120,8 @@ static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, BM_TILES), (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("conv_split_kernel<%d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS);
+    if (IO) set_last_kernel("conv_split_kernel_bf16io<%d, %d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS, IO);
+    else set_last_kernel("conv_split_kernel<%d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS);
     return VS_OK;
 }
 
@@ -362,7 +138,20 @@ static int launch_split_terms(const ConvParams &p, int cfg, int span, hipStream_
     }
 }
 
+// bf16-resident tensors: the 128 x 256 tile of the plain-bf16 arithmetic (the convs of the >= 128-channel stages; the 64- and 32-row
+// instances of this variant spill 20 bytes per lane, which the hand-counted vmcnt waits of the main loop cannot tolerate)
+template <int IO>
+static int launch_split_io(const ConvParams &p, int cfg, int span, hipStream_t s) {
+    if (cfg != 0) { set_error("launch_split: bf16-resident tensors are supported by the 128-row tile shape only (>= 96 output rows)"); return VS_EUNSUPPORTED; }
+    return launch_split_cfg<1, 8, 4, 1, 1, IO>(p, span, s);
+}
+
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s) {
+    const int io = (p.x_bf16 ? 1 : 0) | (p.y_bf16 ? 2 : 0);
+    if (io) {
+        if (terms != 1) { set_error("launch_split: bf16-resident tensors need the plain-bf16 arithmetic (VS_MATH_BF16)"); return VS_EUNSUPPORTED; }
+        return io == 1 ? launch_split_io<1>(p, cfg, span, s) : io == 2 ? launch_split_io<2>(p, cfg, span, s) : launch_split_io<3>(p, cfg, span, s);
+    }
     if (terms == 6) return launch_split_terms<6>(p, cfg, span, s);
     if (terms == 1) return launch_split_terms<1>(p, cfg, span, s);
     set_error("launch_split: unsupported term count %d", terms);

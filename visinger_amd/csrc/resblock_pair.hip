@@ -305,6 +305,7 @@ int vs_respair_supported(const vs_conv_t *c1, const vs_conv_t *c2) {
 }
 
 int vs_respair_forward(vs_conv_t *c1, vs_conv_t *c2, const vs_conv_io_t *io, void *stream) {
+    VS_REQUIRE(!io || (io->x_dtype == VS_DTYPE_F32 && io->y_dtype == VS_DTYPE_F32), "vs_respair_forward: fp32 tensors only");
     VS_REQUIRE(c1 && c2 && io, "vs_respair_forward: NULL argument");
     VS_REQUIRE(vs_respair_supported(c1, c2), "vs_respair_forward: unsupported pair of convs");
     VS_REQUIRE(c1->weights_set && c2->weights_set, "vs_respair_forward: weights not set");

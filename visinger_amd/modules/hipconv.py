@@ -94,6 +94,20 @@ def set_conv_math(module, math):
     return module
 
 
+def set_activation_storage(module, dtype):
+    """bf16-RESIDENT activations (torch.bfloat16; None / torch.float32 restores fp32 tensors) for the modules under `module` that
+    support them: the generator keeps the activations of its wide stages (>= 128 channels) as bf16 tensors between its convs --
+    BASELINE.json's long-form configuration ("bf16 activations"), only together with L.MATH_BF16 (the arithmetic that rounds every
+    conv operand to bf16 anyway).  On the bf16 matrix pipe those convs are HBM-bound with fp32 tensors."""
+    for m in module.modules():
+        if dtype is None or dtype == torch.float32:
+            m.__dict__.pop("_hip_storage", None)
+        else:
+            assert dtype == torch.bfloat16, dtype
+            m.__dict__["_hip_storage"] = dtype
+    return module
+
+
 def repack_weights(module):
     """Drop every packed-weight cache under `module`: the next forward re-folds and re-packs from the live parameters.  The
     cache key (data_ptr, in-place version) of visinger_amd.ops.ConvOp.set_weights follows optimizer steps, ``load_state_dict``

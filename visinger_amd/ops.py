@@ -153,17 +153,21 @@ class ConvOp:
     def forward(self, x, *, B=None, T=None, x_bs=0, in_act=L.IN_NONE, mask=None, bias_b=None, bias_b_bs=0,
                 y=None, y_bs=0, res=None, res_bs=0, acc=None, acc_bs=0, scale=1.0, out_act=L.OUT_NONE, out_mask=False,
                 mode=L.MODE_LINEAR, split_row=0, out1=None, pair_mode=L.PAIR_GATE, logdet=None,
-                x_ptr=None, y_ptr=None, res_ptr=None, acc_ptr=None):
+                x_ptr=None, y_ptr=None, res_ptr=None, acc_ptr=None, y_dtype=None):
         """Launch.  x: [B, c_in, T] (or pass x_ptr/x_bs/B/T for a channel window of a larger tensor).
-        Returns y (allocated [B, rows_out, T_out] when not given)."""
+        Returns y (allocated [B, rows_out, T_out] when not given; y_dtype = torch.bfloat16 for a bf16-RESIDENT output).
+        x / y / res / acc may be bf16 tensors in the plain-bf16 arithmetic (vs_dtype in include/visinger_hip.h); res and acc follow y."""
         if B is None:
             B, _, T = x.shape
         Tout = self.out_len(T)
         if y is None and y_ptr is None:
             rows = split_row if split_row else self.rows_out
-            y = torch.empty((B, rows, Tout), device=x.device, dtype=torch.float32)
+            y = torch.empty((B, rows, Tout), device=x.device, dtype=y_dtype or torch.float32)
         io = L.ConvIO()
-        io.x = x_ptr if x_ptr is not None else L.ptr(x)
+        if x_ptr is not None:
+            io.x = x_ptr
+        else:
+            io.x, io.x_dtype = L.act_ptr(x)
         io.x_bs, io.B, io.T = x_bs, B, T
         io.in_act = in_act
         io.mask = L.ptr(mask)
@@ -171,9 +175,20 @@ class ConvOp:
         io.bias_b_bs = bias_b_bs
         io.split_row = split_row
         o = io.out[0]
-        o.y = y_ptr if y_ptr is not None else L.ptr(y)
-        o.res = res_ptr if res_ptr is not None else L.ptr(res)
-        o.acc = acc_ptr if acc_ptr is not None else L.ptr(acc)
+        if y_ptr is not None:
+            o.y = y_ptr
+            o.res = res_ptr if res_ptr is not None else L.ptr(res)
+            o.acc = acc_ptr if acc_ptr is not None else L.ptr(acc)
+        else:
+            o.y, io.y_dtype = L.act_ptr(y)
+            for name, t, tp in (("res", res, res_ptr), ("acc", acc, acc_ptr)):
+                if tp is not None:
+                    setattr(o, name, tp)
+                else:
+                    q, dt = L.act_ptr(t)
+                    if t is not None and dt != io.y_dtype:
+                        raise L.VisingerHipError(f"ConvOp.forward: {name} is {t.dtype}, y is {y.dtype}")
+                    setattr(o, name, q)
         o.y_bs, o.res_bs, o.acc_bs = y_bs, res_bs, acc_bs
         o.scale, o.out_act, o.out_mask, o.mode = scale, out_act, int(bool(out_mask)), mode
         if out1 is not None:
@@ -193,7 +208,7 @@ class ConvOp:
             e1.record()
             self._last_kernel = self.last_kernel()
             passes = 1 + (res is not None or res_ptr is not None) + (acc is not None or acc_ptr is not None)
-            nb = 4.0 * B * (self.c_in * T + passes * self.rows_out * Tout)      # x once, residual / accumulate inputs once, y once
+            nb = B * ((2.0 if io.x_dtype else 4.0) * self.c_in * T + (2.0 if io.y_dtype else 4.0) * passes * self.rows_out * Tout)   # x once, residual / accumulate inputs once, y once
             PROFILER.records.append((self._last_kernel, self.algorithmic_flops(B, T), nb, e0, e1))
         else:
             L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
