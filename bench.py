@@ -261,7 +261,7 @@ def parse_args():
                          "(default, the headline), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 operands (BASELINE config 5)")
     ap.add_argument("--dropout", type=float, default=0.1, help="config 3: p_dropout of the transformers (reference config: 0.1)")
     ap.add_argument("--storage", default=None, choices=("f32", "bf16"),
-                    help="element type of the generator's wide-stage activations in HBM (bf16 only with --math bf16; default: bf16 for --config 5)")
+                    help="element type of the generator's activations in HBM (bf16 only with --math bf16; default: bf16 for --config 5)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (no GPU work): every rank joins the process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -464,7 +464,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE[args.math] if args.storage == "f32" else "bf16 operands, f32 accumulate (bf16-resident activations in the generator's >= 128-channel stages, f32 elsewhere)",
+            "dtype": DTYPE[args.math] if args.storage == "f32" else "bf16 operands, f32 accumulate (bf16-resident activations between the generator's convs, f32 tensors elsewhere)",
             "data": "synthetic",
             "config": {"workload": workload + f"B={B}/GPU T_mel={T} hop={HOP} hidden={args.hidden} fp32 tensors, random-init weights",
                        "baseline_config": args.config or "headline (north_star: B=32, T_mel=1024, hop 256)",

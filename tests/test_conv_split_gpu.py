@@ -266,7 +266,8 @@ def test_split6_attention_is_fp32_class(oracle, dk, nh, T, ws, share):
 @pytest.mark.parametrize("kind,Cin,Cout,k,d_or_u,T,B", [(L.CONV1D, 256, 256, 7, 3, 1024, 2), (L.CONV1D, 128, 128, 11, 5, 700, 1), (L.CONV1D, 512, 256, 3, 1, 261, 2),
                                                        (L.CONV1D, 200, 136, 7, 1, 33, 3), (L.CONV1D, 64, 128, 3, 1, 4096, 1), (L.CONV1D, 40, 96, 5, 2, 1000, 1),
                                                        (L.CONV_TRANSPOSE1D, 512, 256, 16, 8, 96, 2), (L.CONV_TRANSPOSE1D, 128, 64, 4, 2, 515, 1),
-                                                       (L.CONV1D, 192, 512, 7, 1, 40, 1)])
+                                                       (L.CONV1D, 192, 512, 7, 1, 40, 1), (L.CONV1D, 64, 64, 11, 3, 900, 2), (L.CONV1D, 32, 32, 7, 1, 2050, 1),
+                                                       (L.CONV_TRANSPOSE1D, 64, 32, 4, 2, 600, 2)])
 def test_bf16_resident_tensors_are_the_bf16_arithmetic_on_rounded_tensors(kind, Cin, Cout, k, d_or_u, T, B):
     """vs_dtype (include/visinger_hip.h): bf16-RESIDENT x / y / res / acc in the plain-bf16 arithmetic.  That arithmetic rounds every conv
     operand to bf16 while staging, so a launch on a bf16 tensor must equal -- BIT FOR BIT -- the launch on the same values held in fp32,
@@ -297,22 +298,21 @@ def test_bf16_resident_tensors_are_the_bf16_arithmetic_on_rounded_tensors(kind, 
         use_res, use_acc = kw.pop("res", False), kw.pop("acc", False)
         ref = op.forward(xb.float(), res=resb.float() if use_res else None, acc=accb.float() if use_acc else None, **kw)     # fp32 tensors
         assert op.kernel_instance().startswith("conv_split_kernel<1, ")      # (short launches take smaller tiles; same sums, same order)
-        if not use_res:
+        wide = (d_or_u * Cout if tr else Cout) >= 96          # 128-row tiles: every combination; narrower: bf16 in AND out only
+        if not use_res and not wide:
+            with pytest.raises(L.VisingerHipError):
+                op.forward(xb, **kw)
+        if not use_res and wide:
             y1 = op.forward(xb, **kw)                                                                                        # bf16 in, fp32 out
             assert y1.dtype == torch.float32 and torch.equal(y1, ref), (kw, float((y1 - ref).abs().max()))
             assert op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 1>", op.kernel_instance()
         y3 = op.forward(xb, res=resb if use_res else None, acc=accb if use_acc else None, y_dtype=torch.bfloat16, **kw)        # bf16 in / out
         assert y3.dtype == torch.bfloat16 and torch.equal(y3, ref.bfloat16()), (kw, float((y3.float() - ref).abs().max()))
-        assert op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 3>", op.kernel_instance()
-        if not use_res:
+        assert op.kernel_instance().startswith("conv_split_kernel_bf16io<1, ") and op.kernel_instance().endswith(", 1, 3>"), op.kernel_instance()
+        if not use_res and wide:
             y2 = op.forward(xb.float(), y_dtype=torch.bfloat16, **kw)                                                        # fp32 in, bf16 out
             assert torch.equal(y2, ref.bfloat16()) and op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 2>"
-    # loud refusals: another arithmetic, mismatched residual type, a conv of fewer than 96 rows (no bf16-tensor instance of its tile shape)
-    if not tr:
-        small = ConvOp(kind, Cin, 64, k, d_or_u, pad).set_math(L.MATH_BF16)
-        small.set_weights(w[:64].contiguous().cuda(), None, None)
-        with pytest.raises(L.VisingerHipError):
-            small.forward(xb)
+    # loud refusals: another arithmetic, mismatched residual type (and above: fp32 <-> bf16 conversions on tiles of fewer than 96 rows)
     op6 = ConvOp(kind, Cin, Cout, k, d_or_u, pad).set_math(L.MATH_SPLIT6)
     op6.set_weights(w.cuda(), None, None)
     with pytest.raises(L.VisingerHipError):
@@ -320,3 +320,35 @@ def test_bf16_resident_tensors_are_the_bf16_arithmetic_on_rounded_tensors(kind, 
     if not tr:
         with pytest.raises(L.VisingerHipError):
             op.forward(xb, res=resb.float(), y_dtype=torch.bfloat16)
+
+
+@pytest.mark.parametrize("C,k,d,T,B", [(32, 3, 1, 4096, 2), (32, 7, 3, 3000, 1), (32, 11, 5, 1030, 2), (64, 3, 3, 2048, 1), (64, 7, 1, 777, 2), (64, 11, 5, 4100, 1)])
+def test_fused_pair_and_conv_post_on_bf16_resident_tensors(C, k, d, T, B):
+    """The fused residual pair (decoder.py:92-101) and the 32 -> 1 output conv (decoder.py:55-57) on bf16-RESIDENT tensors in the plain-bf16
+    arithmetic: bit for bit the launch on the same values held in fp32, the pair's output rounded to nearest even once (x staged from
+    bf16, residual and MRF accumulator read as bf16, interior and ragged tiles, vector and element-wise epilogues)."""
+    from visinger_amd.ops import ConvOp, respair_forward, respair_supported
+    g = torch.Generator().manual_seed(C * 7 + k + d + T)
+    ops_ = []
+    for dd in (d, 1):
+        op = ConvOp(L.CONV1D, C, C, k, dd, dd * (k - 1) // 2).set_math(L.MATH_BF16)
+        op.set_weights((torch.randn(C, C, k, generator=g) / np.sqrt(C * k)).cuda(), None, torch.randn(C, generator=g).cuda())
+        ops_.append(op)
+    assert respair_supported(ops_[0], ops_[1])
+    xb = torch.randn(B, C, T, generator=g).cuda().bfloat16()
+    accb = torch.randn(B, C, T, generator=g).cuda().bfloat16()
+    for use_acc, scale in ((False, 1.0), (True, 1.0 / 3)):
+        ref = respair_forward(ops_[0], ops_[1], xb.float(), torch.empty(B, C, T, device="cuda"), res=xb.float(),
+                              acc=accb.float() if use_acc else None, scale=scale)
+        assert ops_[0].kernel_instance() in ("respair_split_kernel<2, 1, 4, 1>", "respair_split_kernel<2, 2, 2, 1>")
+        y = respair_forward(ops_[0], ops_[1], xb, torch.empty_like(xb), res=xb, acc=accb if use_acc else None, scale=scale)
+        assert ops_[0].kernel_instance().endswith(", 1, true>"), ops_[0].kernel_instance()
+        assert y.dtype == torch.bfloat16 and torch.equal(y, ref.bfloat16()), float((y.float() - ref).abs().max())
+    with pytest.raises(L.VisingerHipError):
+        respair_forward(ops_[0], ops_[1], xb, torch.empty(B, C, T, device="cuda"), res=xb)          # y fp32, x bf16
+    if C == 32:
+        post = ConvOp(L.CONV1D, 32, 1, 7, 1, 3).set_math(L.MATH_BF16)
+        post.set_weights((torch.randn(1, 32, 7, generator=g) / 15).cuda(), None, None)
+        w32 = post.forward(xb.float(), in_act=L.IN_LRELU, out_act=L.OUT_TANH)
+        wb = post.forward(xb, in_act=L.IN_LRELU, out_act=L.OUT_TANH)
+        assert wb.dtype == torch.float32 and post.kernel_instance().startswith("conv_small_kernel") and torch.equal(wb, w32)

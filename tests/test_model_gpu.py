@@ -320,7 +320,7 @@ def test_full_size_model_end_to_end_vs_oracle(oracle, hop):
 
 
 def test_generator_with_bf16_resident_activations(oracle, capsys):
-    """BASELINE config 5 ("bf16 activations"): the generator with the activations of its >= 128-channel stages held as bf16 tensors
+    """BASELINE config 5 ("bf16 activations"): the generator with every tensor between conv_pre and conv_post held as bf16
     (hipconv.set_activation_storage + L.MATH_BF16) against the fp64 oracle and against the same arithmetic on fp32 tensors: the extra
     error of the bf16 residual stream stays within a small multiple of the arithmetic's own, and the waveform stays within the stated
     bf16 tolerance of the config-5 test (rms 2e-2 of the signal rms)."""
@@ -350,5 +350,5 @@ def test_generator_with_bf16_resident_activations(oracle, capsys):
     eb = float(np.sqrt(((wav_b.double().cpu().numpy() - wav_ref) ** 2).mean()))
     ef = float(np.sqrt(((wav_f.double().cpu().numpy() - wav_ref) ** 2).mean()))
     with capsys.disabled():
-        print(f"\n   bf16 arithmetic, waveform rms error vs fp64 / signal rms: fp32 tensors {ef / rms:.2e}, bf16-resident wide stages {eb / rms:.2e}")
+        print(f"\n   bf16 arithmetic, waveform rms error vs fp64 / signal rms: fp32 tensors {ef / rms:.2e}, bf16-resident activations {eb / rms:.2e}")
     assert eb <= 2e-2 * rms and eb <= 4 * ef + 1e-6

@@ -963,6 +963,7 @@ struct SmallParams {
     long long y_bs;
     int B, Cin, Cout, Tin, Tout, K, dil, pad, in_act, out_act, out_mask;
     float scale;
+    int x_bf16;          // x holds bf16 elements (bf16-resident activations: the generator's last stage in BASELINE config 5); x_bs in elements
 };
 
 // KT > 0: compile-time taps KT and padding PAD (PAD <= 4, KT-1-PAD <= 4), dilation 1, T % 4 == 0, 16-B aligned rows: each thread
@@ -976,6 +977,8 @@ __global__ void __launch_bounds__(256) conv_small_kernel(const SmallParams p) {
     const int n0 = (blockIdx.x * 256 + threadIdx.x) * NQ;
     if (n0 >= p.Tout) return;
     const float *xb = p.x + (long long)b * p.x_bs;
+    const unsigned short *xh = reinterpret_cast<const unsigned short *>(p.x) + (long long)b * p.x_bs;     // the same rows as bf16 elements
+    const bool xbf = p.x_bf16 != 0;
     const float *mb = p.mask ? p.mask + (long long)b * p.Tin : nullptr;
     const bool act_lrelu = (p.in_act == VS_IN_LRELU || p.in_act == VS_IN_LRELU_MASK);
     const bool act_mask = (p.in_act >= VS_IN_MASK);
@@ -1001,8 +1004,17 @@ __global__ void __launch_bounds__(256) conv_small_kernel(const SmallParams p) {
         for (int i = 0; i < 4; ++i) { mw[i] = okl ? mw[i] : 0.f; mw[8 + i] = okr ? mw[8 + i] : 0.f; }
         for (int ci = 0; ci < p.Cin; ++ci) {
             const float *xr = xb + (long long)ci * p.Tin;
-            const float4 a = *reinterpret_cast<const float4 *>(xr + nl), c4 = *reinterpret_cast<const float4 *>(xr + n0),
-                         d = *reinterpret_cast<const float4 *>(xr + nr);
+            float4 a, c4, d;
+            if (xbf) {
+                const unsigned short *xq = xh + (long long)ci * p.Tin;
+                a = bf4_to_f4(*reinterpret_cast<const uint2 *>(xq + nl));
+                c4 = bf4_to_f4(*reinterpret_cast<const uint2 *>(xq + n0));
+                d = bf4_to_f4(*reinterpret_cast<const uint2 *>(xq + nr));
+            } else {
+                a = *reinterpret_cast<const float4 *>(xr + nl);
+                c4 = *reinterpret_cast<const float4 *>(xr + n0);
+                d = *reinterpret_cast<const float4 *>(xr + nr);
+            }
             float xw[12] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w, d.x, d.y, d.z, d.w};
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
@@ -1030,7 +1042,7 @@ __global__ void __launch_bounds__(256) conv_small_kernel(const SmallParams p) {
                 for (int q = 0; q < NQ; ++q) {
                     const int n = n0 + q + off;
                     const bool ok = (n >= 0 && n < p.Tin);
-                    float v = ok ? xr[n] : 0.f;
+                    float v = ok ? (xbf ? u2f((unsigned)(xh + (long long)ci * p.Tin)[n] << 16) : xr[n]) : 0.f;
                     if (act_lrelu) v = lrelu(v);
                     if (act_mask) v *= ok ? mb[n] : 0.f;
                     xv[q] = v;
@@ -1405,7 +1417,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // stream a long input once; the discriminators' 1024 -> 1 conv_post over a few thousand positions needs the parallelism of
     // the MFMA tiles even at 1 valid row in 32)
     if (h->kind == VS_CONV1D && h->c_out <= 4 && h->c_in * h->k <= 2048 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT | VS_CONV_ADJOINT)) && !p.split_row &&
-        !p.x_bf16 && !p.y_bf16 &&
+        !p.y_bf16 &&
         !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {
         SmallParams q;
         q.x = p.x; q.x_bs = p.x_bs; q.w = h->weff.as<float>(); q.bias = h->has_bias ? h->beff.as<float>() : nullptr;
@@ -1413,6 +1425,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         q.B = p.B; q.Cin = h->c_in; q.Cout = h->c_out; q.Tin = p.Tin; q.Tout = p.Tout; q.K = h->k; q.dil = h->dil;
         q.pad = h->pad; q.in_act = p.in_act; q.out_act = p.out[0].out_act; q.out_mask = p.out[0].out_mask;
         q.scale = p.out[0].scale;
+        q.x_bf16 = p.x_bf16;
         dim3 grid((unsigned)ceil_div(p.Tout, 256 * 4), (unsigned)p.B);
         auto al16 = [](const void *q2) { return (reinterpret_cast<uintptr_t>(q2) & 15u) == 0; };
         const bool vec_ok = (p.Tin % 4 == 0) && (Tout == io->T) && al16(q.x) && (q.x_bs % 4 == 0) && (!q.mask || al16(q.mask));

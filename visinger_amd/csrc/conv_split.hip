@@ -138,12 +138,17 @@ static int launch_split_terms(const ConvParams &p, int cfg, int span, hipStream_
     }
 }
 
-// bf16-resident tensors: the 128 x 256 tile of the plain-bf16 arithmetic (the convs of the >= 128-channel stages; the 64- and 32-row
-// instances of this variant spill 20 bytes per lane, which the hand-counted vmcnt waits of the main loop cannot tolerate)
+// bf16-resident tensors: the 128 x 256 tile of the plain-bf16 arithmetic in every combination, the 64- and 32-row tiles for bf16 in AND out
+// (their mixed variants spill 20 bytes per lane, which the hand-counted vmcnt waits of the main loop cannot tolerate)
 template <int IO>
 static int launch_split_io(const ConvParams &p, int cfg, int span, hipStream_t s) {
-    if (cfg != 0) { set_error("launch_split: bf16-resident tensors are supported by the 128-row tile shape only (>= 96 output rows)"); return VS_EUNSUPPORTED; }
-    return launch_split_cfg<1, 8, 4, 1, 1, IO>(p, span, s);
+    if (cfg == 0) return launch_split_cfg<1, 8, 4, 1, 1, IO>(p, span, s);
+    if constexpr (IO == 3) {       // bf16 in AND out: the narrow stages' own convs (transposed 64 -> 32, unfused pairs); these variants do not spill
+        if (cfg == 1 || cfg == 3) return launch_split_cfg<1, 4, 2, 2, 1, 3>(p, span, s);
+        if (cfg == 2) return launch_split_cfg<1, 2, 1, 4, 1, 3>(p, span, s);
+    }
+    set_error("launch_split: bf16-resident tensors: this tile shape has no instance (fp32 <-> bf16 conversions on the 128-row tile only)");
+    return VS_EUNSUPPORTED;
 }
 
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s) {

@@ -305,7 +305,9 @@ int vs_respair_supported(const vs_conv_t *c1, const vs_conv_t *c2) {
 }
 
 int vs_respair_forward(vs_conv_t *c1, vs_conv_t *c2, const vs_conv_io_t *io, void *stream) {
-    VS_REQUIRE(!io || (io->x_dtype == VS_DTYPE_F32 && io->y_dtype == VS_DTYPE_F32), "vs_respair_forward: fp32 tensors only");
+    VS_REQUIRE(!io || (io->x_dtype == io->y_dtype && (io->x_dtype == VS_DTYPE_F32 || (io->x_dtype == VS_DTYPE_BF16 && c1 && c2 &&
+               c1->math == VS_MATH_BF16 && c2->math == VS_MATH_BF16))),
+               "vs_respair_forward: x and y share one element type; bf16-resident tensors need the plain-bf16 arithmetic on both convs");
     VS_REQUIRE(c1 && c2 && io, "vs_respair_forward: NULL argument");
     VS_REQUIRE(vs_respair_supported(c1, c2), "vs_respair_forward: unsupported pair of convs");
     VS_REQUIRE(c1->weights_set && c2->weights_set, "vs_respair_forward: weights not set");

@@ -58,10 +58,14 @@ __device__ __forceinline__ void pstamp(const PairSplitParams &p, int slot) {
 
 // TERMS = 6: split-bf16 x6 (three planes, fp32 class); TERMS = 1: operands rounded to bf16 (one plane) -- VS_MATH_BF16, where a
 // narrow conv is even further below the HBM ridge as its own launch.
-template <int NT_W, int WAVES_M, int WAVES_N, int TERMS>
+// PB: x, res, acc and y are bf16-RESIDENT tensors (plain-bf16 arithmetic only, vs_dtype): half the bytes of a kernel that is HBM-bound in
+// that arithmetic (3.3-4.7 TB/s algorithmic with fp32 tensors).  Every difference is one `if constexpr (PB)` around a load or a store, so
+// that the fp32-tensor instances compile to what they were.
+template <int NT_W, int WAVES_M, int WAVES_N, int TERMS, bool PB = false>
 __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitParams p) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     static_assert(TERMS == 6 || TERMS == 1, "split-bf16 x6 or plain bf16");
+    static_assert(!PB || TERMS == 1, "bf16-resident tensors go with the plain-bf16 arithmetic");
     constexpr int NPL = (TERMS == 6) ? 3 : 1;
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int WT = BN + QHALO;                 // column pitch of the intermediate tile
@@ -82,7 +86,8 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     const int PLSZ = 2 * W * 4;                    // dwords per staged plane: [k-group(2)][column][4 dwords]
     unsigned *const lbuf0 = reinterpret_cast<unsigned *>(smem);
     unsigned *const lbuf1 = lbuf0 + NPL * PLSZ;
-    const float *const xb = p.x + (long long)b * p.x_bs;
+    const float *xb = p.x + (long long)b * p.x_bs;
+    if constexpr (PB) xb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(p.x) + (long long)b * p.x_bs * 2);
     const int KT = p.K;
     const int nsteps = p.nchunks * KT;
 
@@ -102,7 +107,12 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-            for (int it = 0; it < E_NIT; ++it) r4[ps][it] = *reinterpret_cast<const float4 *>(resp0 + goff0 + (long long)(8 * ps + it * E_RPI) * p.T);
+            for (int it = 0; it < E_NIT; ++it) {
+                if constexpr (PB)
+                    r4[ps][it] = bf4_to_f4(*reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p.res) + (long long)b * p.res_bs +
+                                                                            goff0 + (long long)(8 * ps + it * E_RPI) * p.T));
+                else r4[ps][it] = *reinterpret_cast<const float4 *>(resp0 + goff0 + (long long)(8 * ps + it * E_RPI) * p.T);
+            }
     }
 
     // ------------------------------------------------------------------------------------------- phase 1: conv1(lrelu(x))
@@ -115,15 +125,22 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     }
     float st[4][CIT];
     const __amdgpu_buffer_rsrc_t xsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.C * p.T * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)xb, 0, (int)((long long)p.C * p.T * (PB ? 2 : 4)), 0x00020000);
     auto stage_load = [&](int chunk) __attribute__((always_inline)) {
         const int nbase = xg0 + lane;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int voff = ((chunk * CK + 4 * wave + j) * p.T + nbase) * 4;
+            if constexpr (PB) {
+                const int voff = ((chunk * CK + 4 * wave + j) * p.T + nbase) * 2;
 #pragma unroll
-            for (int i = 0; i < CIT; ++i)
-                st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
+                for (int i = 0; i < CIT; ++i)
+                    st[j][i] = u2f((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xsrc, voff + i * 128, 0, 0) << 16);
+            } else {
+                const int voff = ((chunk * CK + 4 * wave + j) * p.T + nbase) * 4;
+#pragma unroll
+                for (int i = 0; i < CIT; ++i)
+                    st[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, voff + i * 256, 0, 0));
+            }
         }
     };
     const bool time_edge = (xg0 < 0) || (xg0 + W > p.T);
@@ -298,7 +315,12 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) a4[ps][it] = *reinterpret_cast<const float4 *>(accp + goff0 + (long long)(8 * ps + it * RPI) * p.T);
+                for (int it = 0; it < NIT; ++it) {
+                    if constexpr (PB)
+                        a4[ps][it] = bf4_to_f4(*reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p.acc) + (long long)b * p.acc_bs +
+                                                                                goff0 + (long long)(8 * ps + it * RPI) * p.T));
+                    else a4[ps][it] = *reinterpret_cast<const float4 *>(accp + goff0 + (long long)(8 * ps + it * RPI) * p.T);
+                }
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -313,7 +335,10 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
                     if (has_res) { v.x += r4[ps][it].x; v.y += r4[ps][it].y; v.z += r4[ps][it].z; v.w += r4[ps][it].w; }
                     if (has_acc) { v.x += a4[ps][it].x; v.y += a4[ps][it].y; v.z += a4[ps][it].z; v.w += a4[ps][it].w; }
                     if (p.scale != 1.f) { v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale; }
-                    *reinterpret_cast<float4 *>(yb + goff0 + (long long)(8 * ps + it * RPI) * p.T) = v;
+                    if constexpr (PB)
+                        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(p.y) + (long long)b * p.y_bs + goff0 +
+                                                   (long long)(8 * ps + it * RPI) * p.T) = f4_to_bf4(v);
+                    else *reinterpret_cast<float4 *>(yb + goff0 + (long long)(8 * ps + it * RPI) * p.T) = v;
                 }
             }
         }
@@ -328,10 +353,17 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
             for (int r = 0; r < 16; ++r) {
                 const long long off = (long long)(tile_row0 + acc_row(r)) * p.T + nc;
                 float v = acc[j][r];
-                if (has_res) v += resp[off];
-                if (has_acc) v += accp[off];
-                v *= p.scale;
-                if (okc) yb[off] = v;
+                if constexpr (PB) {
+                    if (has_res) v += u2f((unsigned)(reinterpret_cast<const unsigned short *>(p.res) + (long long)b * p.res_bs)[off] << 16);
+                    if (has_acc) v += u2f((unsigned)(reinterpret_cast<const unsigned short *>(p.acc) + (long long)b * p.acc_bs)[off] << 16);
+                    v *= p.scale;
+                    if (okc) (reinterpret_cast<unsigned short *>(p.y) + (long long)b * p.y_bs)[off] = (unsigned short)(rne_bf16(v) >> 16);
+                } else {
+                    if (has_res) v += resp[off];
+                    if (has_acc) v += accp[off];
+                    v *= p.scale;
+                    if (okc) yb[off] = v;
+                }
             }
         }
     }
@@ -341,10 +373,10 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     }
 }
 
-template <int NT_W, int WAVES_M, int WAVES_N, int TERMS>
+template <int NT_W, int WAVES_M, int WAVES_N, int TERMS, bool PB = false>
 static int launch_pair_split_cfg(PairSplitParams p, hipStream_t s) {
     constexpr int BN = 32 * NT_W * WAVES_N, WT = BN + QHALO, NPL = (TERMS == 6) ? 3 : 1;
-    auto kern = respair_split_kernel<NT_W, WAVES_M, WAVES_N, TERMS>;
+    auto kern = respair_split_kernel<NT_W, WAVES_M, WAVES_N, TERMS, PB>;
     p.W1 = BN + (p.K - 1) * p.d1;
     const size_t lds = std::max<size_t>({(size_t)2 * NPL * 2 * p.W1 * 16, (size_t)NPL * (p.C / 8) * WT * 16,
                                          (size_t)4 * 8 * (32 * NT_W) * sizeof(float)});
@@ -356,7 +388,8 @@ static int launch_pair_split_cfg(PairSplitParams p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, BN - p.PH), 1, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("respair_split_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, TERMS);
+    if (PB) set_last_kernel("respair_split_kernel<%d, %d, %d, %d, true>", NT_W, WAVES_M, WAVES_N, TERMS);
+    else set_last_kernel("respair_split_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, TERMS);
     return VS_OK;
 }
 
@@ -383,6 +416,10 @@ int vs_respair_split_launch(const vs_conv *c1, const vs_conv *c2, const vs_conv_
     p.PH = ((c1->k - 1) + 3) & ~3;
     p.fast_epi = fast_epi;
     p.stamps = g_stamp_buf;
+    if (io->x_dtype == VS_DTYPE_BF16) {        // (vs_respair_forward: x and y types agree, plain-bf16 arithmetic)
+        if (C == 32) return launch_pair_split_cfg<2, 1, 4, 1, true>(p, s);
+        return launch_pair_split_cfg<2, 2, 2, 1, true>(p, s);
+    }
     if (c1->math == VS_MATH_BF16) {
         if (C == 32) return launch_pair_split_cfg<2, 1, 4, 1>(p, s);
         return launch_pair_split_cfg<2, 2, 2, 1>(p, s);

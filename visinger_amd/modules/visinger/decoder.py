@@ -79,15 +79,17 @@ class Generator(nn.Module):
         cb = None
         if g is not None:
             cb = self.cond.run(g.contiguous().float())          # [B, C0, 1] -> per-item bias of conv_pre
-        # bf16-RESIDENT activations (hipconv.set_activation_storage, BASELINE config 5): the tensors between the convs of the stages with
-        # >= 128 channels are bf16 -- on the bf16 matrix pipe those convs are HBM-bound with fp32 tensors; the narrow stages (fused fp32
-        # pairs) and the waveform stay fp32.  Everything downstream allocates with empty_like(x), so the element type follows x.
+        # bf16-RESIDENT activations (hipconv.set_activation_storage, BASELINE config 5): every tensor between conv_pre and conv_post is
+        # bf16 -- in the plain-bf16 arithmetic the narrow stages' fused pairs are HBM-bound and the wide convs' epilogues stream residual
+        # and output; the waveform (conv_post's output) is fp32.  Everything downstream allocates with empty_like(x), so the element type
+        # follows x.  (Stages narrower than 32 channels -- the reference's hop-300 generator ends at 16 -- stay fp32: no bf16 instance of
+        # their tile shape with an fp32 input.)
         bf = self.__dict__.get("_hip_storage") == torch.bfloat16
         if bf and self.conv_pre._op(bind=False).math != L.MATH_BF16:
             raise L.VisingerHipError("bf16 activation storage needs the plain-bf16 arithmetic: set_conv_math(model, L.MATH_BF16) first")
 
         def store(ch):
-            return torch.bfloat16 if (bf and ch >= 128) else None
+            return torch.bfloat16 if (bf and ch >= 32) else None
 
         x = self.conv_pre.run(x, bias_b=cb, in_act=L.IN_NONE if mask is None else L.IN_MASK, mask=mask, y_dtype=store(self.ups[0].in_channels))
         nk = self.num_kernels

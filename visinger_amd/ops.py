@@ -404,18 +404,23 @@ def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
     """a11: y = conv2(lrelu(conv1(lrelu(x)))) + res [+ acc] [* scale] in one launch (csrc/resblock_pair.hip)."""
     B, C, T = x.shape
     io = L.ConvIO()
-    io.x = L.ptr(x)
+    io.x, io.x_dtype = L.act_ptr(x)
     io.x_bs, io.B, io.T = 0, B, T
     io.in_act = L.IN_LRELU
     o = io.out[0]
-    o.y, o.res, o.acc = L.ptr(y), L.ptr(res), L.ptr(acc)
+    o.y, io.y_dtype = L.act_ptr(y)
+    for name, t in (("res", res), ("acc", acc)):
+        q, dt = L.act_ptr(t)
+        if t is not None and dt != io.y_dtype:
+            raise L.VisingerHipError(f"respair_forward: {name} is {t.dtype}, y is {y.dtype}")
+        setattr(o, name, q)
     o.scale = scale
     if PROFILER.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
         e1.record()
-        nb = 4.0 * B * C * T * (2 + (res is not None) + (acc is not None))
+        nb = (2.0 if io.y_dtype else 4.0) * B * C * T * (2 + (res is not None) + (acc is not None))
         PROFILER.records.append((op1.last_kernel(), op1.algorithmic_flops(B, T) + op2.algorithmic_flops(B, T), nb, e0, e1))
     else:
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
