@@ -41,6 +41,34 @@ __global__ void __launch_bounds__(256) gconv_fwd_kernel(const GConvParams p) {
     p.y[e] = acc;
 }
 
+// COG outputs per thread: a thread owns output position n of one (batch item, group) and all COG output channels of the group, so every
+// x value it loads feeds COG FMAs (the one-output kernel above issues two loads per FMA: 3 TFLOP/s, 4.3 ms of the config-3 training
+// step); the weights of a group are wave-uniform (blockIdx.y = group) and come through the scalar cache.
+template <int COG>
+__global__ void __launch_bounds__(256) gconv_fwd_group_kernel(const GConvParams p) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, b = blockIdx.z;
+    if (n >= p.Tout) return;
+    const float *__restrict__ wg = p.w + (long long)g * COG * p.cig * p.K;
+    const float *xb = p.x + ((long long)b * p.Cin + (long long)g * p.cig) * p.T;
+    float acc[COG];
+#pragma unroll
+    for (int c = 0; c < COG; ++c) acc[c] = p.bias ? p.bias[g * COG + c] : 0.f;
+    const int t0 = n * p.stride - p.pad;
+    for (int ci = 0; ci < p.cig; ++ci) {
+        const float *xr = xb + (long long)ci * p.T;
+        for (int k = 0; k < p.K; ++k) {
+            const int t = t0 + k;
+            const float xv = (t >= 0 && t < p.T) ? xr[t] : 0.f;
+#pragma unroll
+            for (int c = 0; c < COG; ++c) acc[c] = fmaf(wg[((long long)c * p.cig + ci) * p.K + k], xv, acc[c]);
+        }
+    }
+    float *yb = p.y + ((long long)b * p.Cout + (long long)g * COG) * p.Tout + n;
+#pragma unroll
+    for (int c = 0; c < COG; ++c) yb[(long long)c * p.Tout] = acc[c];
+}
+
 // one thread per input element, t fastest
 __global__ void __launch_bounds__(256) gconv_bwd_data_kernel(const GConvParams p) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -114,7 +142,10 @@ int vs_gconv1d_fwd(const float *x, const float *w, const float *bias, float *y, 
     VS_TRY(check(p));
     p.x = x; p.w = w; p.bias = bias; p.y = y;
     const long long total = (long long)p.B * p.Cout * p.Tout;
-    hipLaunchKernelGGL(gconv_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), p);
+    const dim3 ggrid((unsigned)ceil_div(p.Tout, 256), (unsigned)p.groups, (unsigned)p.B);
+    if (p.cog == 16 && p.groups <= 65535 && p.B <= 65535) hipLaunchKernelGGL(gconv_fwd_group_kernel<16>, ggrid, dim3(256), 0, as_stream(stream), p);
+    else if (p.cog == 4 && p.groups <= 65535 && p.B <= 65535) hipLaunchKernelGGL(gconv_fwd_group_kernel<4>, ggrid, dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(gconv_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, as_stream(stream), p);
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
 }
