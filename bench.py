@@ -169,7 +169,7 @@ def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
     return res
 
 
-PROFILE_TAGS = ("r02_c", "r02_b", "r02_a", "r01_f", "r01_e", "r01_c")      # newest first: profiles/<tag>_pmc_*.json
+PROFILE_TAGS = ("r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e", "r01_c")      # newest first: profiles/<tag>_pmc_*.json
 
 
 def _norm(kernel):
@@ -466,7 +466,7 @@ def main():
             "vs_baseline": None,
             "dtype": DTYPE[args.math] if args.storage == "f32" else "bf16 operands, f32 accumulate (bf16-resident activations between the generator's convs, f32 tensors elsewhere)",
             "data": "synthetic",
-            "config": {"workload": workload + f"B={B}/GPU T_mel={T} hop={HOP} hidden={args.hidden} fp32 tensors, random-init weights",
+            "config": {"workload": workload + f"B={B}/GPU T_mel={T} hop={HOP} hidden={args.hidden} " + ("fp32 tensors" if args.storage == "f32" else "bf16-resident generator activations") + ", random-init weights",
                        "baseline_config": args.config or "headline (north_star: B=32, T_mel=1024, hop 256)",
                        "per_gpu_batch": B, "global_batch": B * world, "t_mel": T, "hop": HOP, "hidden": args.hidden,
                        "parallelism": f"dp{world} (utterance shard, no collective)",

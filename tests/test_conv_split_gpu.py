@@ -340,7 +340,7 @@ def test_fused_pair_and_conv_post_on_bf16_resident_tensors(C, k, d, T, B):
     for use_acc, scale in ((False, 1.0), (True, 1.0 / 3)):
         ref = respair_forward(ops_[0], ops_[1], xb.float(), torch.empty(B, C, T, device="cuda"), res=xb.float(),
                               acc=accb.float() if use_acc else None, scale=scale)
-        assert ops_[0].kernel_instance() in ("respair_split_kernel<2, 1, 4, 1>", "respair_split_kernel<2, 2, 2, 1>")
+        assert ops_[0].kernel_instance() in ("respair_split_kernel<2, 1, 4, 1, false>", "respair_split_kernel<2, 2, 2, 1, false>")
         y = respair_forward(ops_[0], ops_[1], xb, torch.empty_like(xb), res=xb, acc=accb if use_acc else None, scale=scale)
         assert ops_[0].kernel_instance().endswith(", 1, true>"), ops_[0].kernel_instance()
         assert y.dtype == torch.bfloat16 and torch.equal(y, ref.bfloat16()), float((y.float() - ref).abs().max())

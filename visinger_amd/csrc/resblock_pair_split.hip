@@ -388,8 +388,7 @@ static int launch_pair_split_cfg(PairSplitParams p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, BN - p.PH), 1, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    if (PB) set_last_kernel("respair_split_kernel<%d, %d, %d, %d, true>", NT_W, WAVES_M, WAVES_N, TERMS);
-    else set_last_kernel("respair_split_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, TERMS);
+    set_last_kernel("respair_split_kernel<%d, %d, %d, %d, %s>", NT_W, WAVES_M, WAVES_N, TERMS, PB ? "true" : "false");     // (as rocprofv3 prints it)
     return VS_OK;
 }
 
