@@ -351,7 +351,7 @@ def test_resblock_pair_fused_launch(oracle, C, k, d, T, B, math):
     y = respair_forward(op1, op2, xd, torch.empty_like(xd), res=xd)
     close(y, ref, tol)
     assert op1.kernel_instance().startswith("respair_kernel<" if math == L.MATH_F32 else "respair_split_kernel<")
-    assert op1.kernel_instance().endswith({L.MATH_F32: ">", L.MATH_SPLIT6: ", 6>", L.MATH_BF16: ", 1>"}[math])
+    assert op1.kernel_instance().endswith({L.MATH_F32: ">", L.MATH_SPLIT6: ", 6, false>", L.MATH_BF16: ", 1, false>"}[math])
     acc_t = dev(accb)
     respair_forward(op1, op2, xd, acc_t, res=xd, acc=acc_t, scale=1.0 / 3.0)       # in-place accumulate, MRF average
     close(acc_t, (ref + accb) / 3.0, tol)
