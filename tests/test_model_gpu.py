@@ -319,7 +319,8 @@ def test_full_size_model_end_to_end_vs_oracle(oracle, hop):
     assert maxerr(wav, ref["wav_out"]) <= 1e-4
 
 
-def test_generator_with_bf16_resident_activations(oracle, capsys):
+@pytest.mark.parametrize("rates,kernels", [([8, 8, 2, 2], [16, 16, 4, 4]), ([5, 5, 3, 2, 2], [11, 11, 7, 4, 4])])
+def test_generator_with_bf16_resident_activations(oracle, capsys, rates, kernels):
     """BASELINE config 5 ("bf16 activations"): the generator with every tensor between conv_pre and conv_post held as bf16
     (hipconv.set_activation_storage + L.MATH_BF16) against the fp64 oracle and against the same arithmetic on fp32 tensors: the extra
     error of the bf16 residual stream stays within a small multiple of the arithmetic's own, and the waveform stays within the stated
@@ -327,14 +328,16 @@ def test_generator_with_bf16_resident_activations(oracle, capsys):
     from visinger_amd.modules.hipconv import set_activation_storage, set_conv_math
     from visinger_amd.modules.visinger.decoder import Generator
     B, T = 2, 24
-    gen = Generator(192, "1", [3, 7, 11], [[1, 3, 5]] * 3, [8, 8, 2, 2], 512, [16, 16, 4, 4], gin_channels=256)
+    # (hop 300, the reference's own generator: it ends in a 16-channel stage, which has no bf16 instance -- the tensors go back to fp32 at
+    #  the 128 -> 64 transposed conv)
+    gen = Generator(192, "1", [3, 7, 11], [[1, 3, 5]] * 3, rates, 512, kernels, gin_channels=256)
     sdg = _rand_sd(gen, 21)
     gen = gen.cuda().eval()
     r = np.random.default_rng(257)
     z = r.standard_normal((B, 192, T)).astype(np.float32)
     g = r.standard_normal((B, 256, 1)).astype(np.float32)
     wav_ref = oracle.generator(sdg, z, g, resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5]] * 3,
-                               upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4])
+                               upsample_rates=rates, upsample_kernel_sizes=kernels)
     set_activation_storage(gen, torch.bfloat16)
     with pytest.raises(L.VisingerHipError):            # not with the fp32-class arithmetic
         with torch.no_grad():

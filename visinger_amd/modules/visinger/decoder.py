@@ -82,20 +82,27 @@ class Generator(nn.Module):
         # bf16-RESIDENT activations (hipconv.set_activation_storage, BASELINE config 5): every tensor between conv_pre and conv_post is
         # bf16 -- in the plain-bf16 arithmetic the narrow stages' fused pairs are HBM-bound and the wide convs' epilogues stream residual
         # and output; the waveform (conv_post's output) is fp32.  Everything downstream allocates with empty_like(x), so the element type
-        # follows x.  (Stages narrower than 32 channels -- the reference's hop-300 generator ends at 16 -- stay fp32: no bf16 instance of
-        # their tile shape with an fp32 input.)
+        # follows x.  Stages narrower than 32 channels (the reference's hop-300 generator ends at 16) have no bf16 instance: the tensors
+        # go back to fp32 at the last transposed conv before them that runs on 128-row tiles (the only shape with a bf16 -> fp32 instance).
         bf = self.__dict__.get("_hip_storage") == torch.bfloat16
         if bf and self.conv_pre._op(bind=False).math != L.MATH_BF16:
             raise L.VisingerHipError("bf16 activation storage needs the plain-bf16 arithmetic: set_conv_math(model, L.MATH_BF16) first")
+        n_bf = self.num_upsamples if bf else 0          # stages [0, n_bf) hold bf16 tensors
+        if bf:
+            chans = [u.out_channels for u in self.ups]
+            narrow = next((i for i, c in enumerate(chans) if c < 32), None)
+            if narrow is not None:
+                # (whole 128-row blocks: with 192 virtual rows -- 128 -> 64 at stride 3 -- the engine takes 64-row tiles)
+                n_bf = max((i for i in range(narrow) if (self.ups[i].stride[0] * chans[i]) % 128 == 0), default=0)
 
-        def store(ch):
-            return torch.bfloat16 if (bf and ch >= 32) else None
+        def store(stage):                               # element type of the tensors of `stage` (-1: conv_pre's output)
+            return torch.bfloat16 if (bf and stage < n_bf) else None
 
-        x = self.conv_pre.run(x, bias_b=cb, in_act=L.IN_NONE if mask is None else L.IN_MASK, mask=mask, y_dtype=store(self.ups[0].in_channels))
+        x = self.conv_pre.run(x, bias_b=cb, in_act=L.IN_NONE if mask is None else L.IN_MASK, mask=mask, y_dtype=store(-1))
         nk = self.num_kernels
         act = L.IN_LRELU if mask is None else L.IN_LRELU_MASK
         for i in range(self.num_upsamples):
-            x = self.ups[i].run(x, in_act=act, mask=mask, y_dtype=store(self.ups[i].out_channels))
+            x = self.ups[i].run(x, in_act=act, mask=mask, y_dtype=store(i))
             if mask is not None:                                # the frame mask at this stage's resolution
                 mask = mask.repeat_interleave(x.shape[2] // mask.shape[1], dim=1).contiguous()
             xs = torch.empty_like(x)
