@@ -9,12 +9,14 @@ NEXT layer's `(x + g) * mask` fused.
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
 from .. import _lib as L
 from .. import autograd
-from ..ops import layernorm_c, rel_attention, _off
+from ..ops import ConvOp, layernorm_c, rel_attention, _off
 from .hipconv import HipConv1d, mask2d, _forward_only_guard
 
 
@@ -110,6 +112,26 @@ class MultiHeadAttention(nn.Module):
             self.conv_k.bias.data.copy_(self.conv_q.bias.data)
         nn.init.xavier_uniform_(self.conv_v.weight)
 
+    def _fused_qkv_op(self):
+        """One conv handle for conv_q | conv_k | conv_v (three nn.Conv1d(channels, channels, 1) of the same input in self-attention,
+        rel_transformer.py:120-122, 141-143): the weights are concatenated and packed once per version of the six parameters."""
+        convs = (self.conv_q, self.conv_k, self.conv_v)
+        if any(hasattr(cv, "weight_g") or cv.bias is None for cv in convs):
+            return None
+        params = [t for cv in convs for t in (cv.weight, cv.bias)]
+        math = self.conv_q._op(bind=False).math
+        key = tuple((t.data_ptr(), t._version) for t in params) + (math,)
+        st = self.__dict__.get("_hip_qkv_inf")
+        if st is None or st[0] != key:
+            op = st[1] if st is not None else ConvOp(L.CONV1D, self.channels, 3 * self.channels, 1, 1, 0)
+            if op.math != math:
+                op.set_math(math)
+            w = torch.cat([cv.weight.detach() for cv in convs], 0).contiguous()
+            b = torch.cat([cv.bias.detach() for cv in convs], 0).contiguous()
+            op.set_weights(w, None, b, force=True)
+            st = self.__dict__["_hip_qkv_inf"] = (key, op, w, b)
+        return st[1]
+
     def forward(self, x, c, attn_mask=None, frame_mask=None, in_mask=False):
         """x, c: [B, C, T].  attn_mask: the reference's [B, 1, T, T] mask, which RelativeEncoder always builds as
         m[:, :, :, None] * m[:, :, None, :] from the frame mask m; the streaming kernel takes m itself (`frame_mask`
@@ -139,8 +161,12 @@ class MultiHeadAttention(nn.Module):
         c = x if c is x else c.contiguous().float()
         qkv = torch.empty((B, 3 * C, T), device=x.device, dtype=torch.float32)
         ia = L.IN_MASK if in_mask else L.IN_NONE
-        for j, (conv, src) in enumerate(((self.conv_q, x), (self.conv_k, c), (self.conv_v, c))):
-            conv.run(src, in_act=ia, mask=m2, y_ptr=_off(qkv, j * C * T), y_bs=3 * C * T)
+        fused = self._fused_qkv_op() if (c is x and not os.environ.get("VS_NO_FUSED_QKV")) else None
+        if fused is not None:
+            fused.forward(x, in_act=ia, mask=m2, y=qkv)       # q | k | v: ONE [3C, C] projection of the same x (rows are independent: same sums)
+        else:
+            for j, (conv, src) in enumerate(((self.conv_q, x), (self.conv_k, c), (self.conv_v, c))):
+                conv.run(src, in_act=ia, mask=m2, y_ptr=_off(qkv, j * C * T), y_bs=3 * C * T)
         rel_k = self.emb_rel_k if self.window_size is not None else None
         rel_v = self.emb_rel_v if self.window_size is not None else None
         # the attention core follows the arithmetic of the projections around it (bf16 GEMMs only under VS_MATH_BF16)
