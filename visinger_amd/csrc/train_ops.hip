@@ -210,9 +210,11 @@ int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const
     hipStream_t s = as_stream(stream);
     dim3 grid((unsigned)ceil_div(T, 64), (unsigned)B);
     const int Ci = (int)C, Ti = (int)T;
+    // (16 channel groups of <= 16 channels for the usual widths: 1 024 threads per 64-frame block -- with 4 groups of 48 channels a
+    //  B = 16, T = 512 launch was 128 blocks of 256 threads walking 48 rows each: 67 us for 19 MB)
     if (C <= 4 * 16) hipLaunchKernelGGL((layernorm_c_bwd_kernel<4, 16>), grid, dim3(256), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
-    else if (C <= 4 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<4, 64>), grid, dim3(256), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
-    else if (C <= 8 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<8, 64>), grid, dim3(512), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
+    else if (C <= 16 * 16) hipLaunchKernelGGL((layernorm_c_bwd_kernel<16, 16>), grid, dim3(1024), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
+    else if (C <= 16 * 32) hipLaunchKernelGGL((layernorm_c_bwd_kernel<16, 32>), grid, dim3(1024), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
     else if (C <= 16 * 64) hipLaunchKernelGGL((layernorm_c_bwd_kernel<16, 64>), grid, dim3(1024), 0, s, a, r, gamma, dy, dx, dgamma, dbeta, Ci, Ti, eps);
     else { set_error("vs_layernorm_c_bwd: C=%lld > 1024 unsupported", (long long)C); return VS_EUNSUPPORTED; }
     VS_CHECK_HIP(hipGetLastError());

@@ -375,8 +375,8 @@ int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma, const
     hipStream_t s = as_stream(stream);
     dim3 grid((unsigned)ceil_div(T, 64), (unsigned)B);
     if (C <= 4 * 16) hipLaunchKernelGGL((layernorm_c_kernel<4, 16>), grid, dim3(256), 0, s, p);
-    else if (C <= 4 * 64) hipLaunchKernelGGL((layernorm_c_kernel<4, 64>), grid, dim3(256), 0, s, p);
-    else if (C <= 8 * 64) hipLaunchKernelGGL((layernorm_c_kernel<8, 64>), grid, dim3(512), 0, s, p);
+    else if (C <= 16 * 16) hipLaunchKernelGGL((layernorm_c_kernel<16, 16>), grid, dim3(1024), 0, s, p);     // (16 groups of <= 16 channels: 4x the threads of <4, 64> per 64-frame block)
+    else if (C <= 16 * 32) hipLaunchKernelGGL((layernorm_c_kernel<16, 32>), grid, dim3(1024), 0, s, p);
     else if (C <= 16 * 64) hipLaunchKernelGGL((layernorm_c_kernel<16, 64>), grid, dim3(1024), 0, s, p);
     else { set_error("vs_layernorm_c_fwd: C=%lld > 1024 unsupported", (long long)C); return VS_EUNSUPPORTED; }
     VS_CHECK_HIP(hipGetLastError());
