@@ -61,21 +61,21 @@ def test_committed_bench_line_and_kernel_stats_agree():
 
 
 def test_latest_round2_profile_agrees_and_pair_kernel_traffic_is_compulsory():
-    """profiles/r02_d_* (end of round 2; r02_c_*: the same two hours earlier): rocprofv3's average launch of the dominant instance equals the HIP-event average of the same run,
+    """profiles/r02_e_* (end of round 2; r02_c_*: the same two hours earlier): rocprofv3's average launch of the dominant instance equals the HIP-event average of the same run,
     and the fused residual pair no longer re-reads x from memory as the residual: 2 x FETCH_SIZE + WRITE_SIZE per launch
     against the algorithmic bytes fell from 1.61x / 1.74x (r02_b: residual requested at the end of the kernel) to 1.15x / 1.23x; what is
     left is the halo a fused pair stages on both sides of its tile (13 % of a 244-output tile at 32 channels, 27 % of a 116-output tile at
     64) under the guide's doubled FETCH_SIZE, an upper bound."""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_d_bench_line_profiled.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_e_bench_line_profiled.json")))
     r = line["roofline"]
     assert r["kernel"] == "conv_split_kernel<1, 8, 4, 1, 6>" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    with open(os.path.join(ROOT, "profiles", "r02_d_bench_kernel_stats.csv"), newline="") as f:
+    with open(os.path.join(ROOT, "profiles", "r02_e_bench_kernel_stats.csv"), newline="") as f:
         rows = {row["Name"]: row for row in csv.DictReader(f)}
     avg_ms = float(rows["void vs::conv_split_kernel<1, 8, 4, 1, 6>(vs::ConvParams)"]["AverageNs"]) * 1e-6
     assert abs(avg_ms - r["avg_launch_ms"]) <= 0.02 * avg_ms
-    full = json.load(open(os.path.join(ROOT, "profiles", "r02_d_bench_line.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02_e_bench_line.json")))
     assert full["steps"] == 30 and full["warmup"] == 10 and full["value"] > 75e6 and full["flow_logdet_rel_err"] <= 1e-4
-    t = json.load(open(os.path.join(ROOT, "profiles", "r02_d_pmc_traffic.json")))["kernels"]
+    t = json.load(open(os.path.join(ROOT, "profiles", "r02_e_pmc_traffic.json")))["kernels"]
     # B = 32, T_mel = 1024: one tensor pass of the 32- / 64-channel stage = 32 * C * r * 1024 * 4 B = 1.074 GB; a pair reads x and writes y
     # (two passes), the last pair of a resblock also reads the MRF accumulator (three): 2.15 / 3.22 GB, on average over the 9 / 3 pairs
     # of a step (6 + 3 / 2 + 1 with and without the accumulator) 2.51 GB
@@ -87,8 +87,8 @@ def test_latest_round2_profile_agrees_and_pair_kernel_traffic_is_compulsory():
         assert new["hbm_bytes_per_launch_corrected"] <= bound * alg, (name, new["hbm_bytes_per_launch_corrected"] / alg)
         assert old[name]["hbm_bytes_per_launch_corrected"] >= 1.6 * alg
         assert abs(new["write_size_bytes_per_launch"] - one) <= 0.04 * one            # y written exactly once
-    c3 = json.load(open(os.path.join(ROOT, "profiles", "r02_d_config3_bench_line.json")))
+    c3 = json.load(open(os.path.join(ROOT, "profiles", "r02_e_config3_bench_line.json")))
     assert c3["config"]["baseline_config"] == 3 and c3["config"]["p_dropout"] == 0.1 and c3["ms_per_step"] < 185.0
-    c5 = json.load(open(os.path.join(ROOT, "profiles", "r02_d_config5_bench_line.json")))
+    c5 = json.load(open(os.path.join(ROOT, "profiles", "r02_e_config5_bench_line.json")))
     assert c5["config"]["baseline_config"] == 5 and "bf16-resident" in c5["dtype"] and c5["ms_per_step"] < 75.0
     assert "hbm_frac_of_8tbps" in c5["roofline"]
