@@ -172,6 +172,15 @@ VS_API int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_
                           const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B,
                           int n_heads, int k_channels, int64_t T, int window_size, int n_heads_rel, int math, void *stream);
 
+/* The same with the KEYS of every (batch, head) cut into `ksplit` ranges (1..16) that run as separate workgroups and are merged by a
+ * second kernel: for launches too small to fill the chip (a single utterance is 16 workgroups of 32 serial key tiles).  `work`:
+ * B * n_heads * ksplit * (k_channels + 2 + 2 * window + 1) * T floats of scratch.  Only the bf16-pipe kernels (VS_MATH_SPLIT6 /
+ * VS_MATH_BF16 on shapes they take) split; any other case runs exactly as vs_relattn_fwd.                                          */
+VS_API int vs_relattn_fwd_ksplit(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                                 const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                                 int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,
+                                 void *stream);
+
 /* a7  channel LayerNorm with its neighbours fused (rel_transformer.py:24-42; call sites 297-299, 305-307, 314-316):
  *     y = ((LayerNorm_C(a + r) * gamma + beta) + g) * mask      r, g, mask optional.
  *     g is the conditioning added at the top of the NEXT encoder layer: [B, C, T] (g_time_stride = 1,

@@ -352,3 +352,29 @@ def test_fused_pair_and_conv_post_on_bf16_resident_tensors(C, k, d, T, B):
         w32 = post.forward(xb.float(), in_act=L.IN_LRELU, out_act=L.OUT_TANH)
         wb = post.forward(xb, in_act=L.IN_LRELU, out_act=L.OUT_TANH)
         assert wb.dtype == torch.float32 and post.kernel_instance().startswith("conv_small_kernel") and torch.equal(wb, w32)
+
+
+@pytest.mark.parametrize("dk,nh,T,ws,share,B,math", [(96, 2, 1024, 4, True, 1, L.MATH_SPLIT6), (96, 2, 516, 4, True, 2, L.MATH_SPLIT6), (64, 2, 260, 4, False, 1, L.MATH_SPLIT6),
+                                                     (128, 1, 2048, None, True, 1, L.MATH_SPLIT6), (96, 2, 1024, 4, True, 1, L.MATH_BF16),
+                                                     (256, 2, 1024, 4, True, 1, L.MATH_BF16)])
+def test_key_split_attention_equals_one_pass(dk, nh, T, ws, share, B, math):
+    """vs_relattn_fwd_ksplit: the keys of a (batch, head) cut into ranges that run as separate workgroups and are merged by a second kernel
+    (single utterances: B * heads * T / 128 workgroups do not fill the chip) -- same scores, same relative terms, same -1e4 fill; the
+    merged rows equal the one-pass rows up to the reassociation of the row sums (ragged mask with the whole tail of the keys padded,
+    key-tile counts that do not divide by the number of ranges, shared and per-head tables, no window)."""
+    from visinger_amd.ops import rel_attention
+    g = torch.Generator().manual_seed(dk + T + nh)
+    C = nh * dk
+    qkv = torch.randn(B, 3 * C, T, generator=g).cuda()
+    R = 2 * ws + 1 if ws is not None else 0
+    rel_k = (torch.randn(1 if share else nh, R, dk, generator=g) * dk ** -0.5).cuda() if ws is not None else None
+    rel_v = (torch.randn(1 if share else nh, R, dk, generator=g) * dk ** -0.5).cuda() if ws is not None else None
+    mask = torch.ones(B, T)
+    mask[-1, (3 * T) // 5:] = 0
+    mask = mask.cuda()
+    one = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=math, ksplit_auto=False)
+    inst = L.lib().vs_last_kernel_name().decode()
+    split = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=math, ksplit_auto=True)
+    assert inst.startswith("relattn_bf16_kernel<") and bool(torch.isfinite(split).all())
+    tol = 2e-6 if math == L.MATH_SPLIT6 else 2e-3
+    assert float((split - one).abs().max()) <= tol * max(1.0, float(one.abs().max())), float((split - one).abs().max())

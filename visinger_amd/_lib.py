@@ -77,6 +77,7 @@ def lib():
     L.vs_conv_out_len.restype = ctypes.c_int64
     i64, ci, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
     L.vs_relattn_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, i64, ci, ci, i64, ci, ci, ci, vp]
+    L.vs_relattn_fwd_ksplit.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, i64, ci, ci, i64, ci, ci, ci, _f32p, ci, vp]
     L.vs_layernorm_c_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, i64, ci, _f32p, _f32p, i64, i64, i64,
                                      ctypes.c_float, vp]
     L.vs_gate_fwd.argtypes = [_f32p, _f32p, i64, _f32p, i64, i64, i64, vp]

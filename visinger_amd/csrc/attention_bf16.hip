@@ -51,7 +51,9 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int i0 = (blockIdx.x * 4 + wave) * 32;
+    const int KSPL = (p.part && p.ksplit > 1) ? p.ksplit : 1;          // key split: blockIdx.x = query block * KSPL + key range
+    const int ksi = blockIdx.x % KSPL;
+    const int i0 = ((blockIdx.x / KSPL) * 4 + wave) * 32;
     const int dk = p.dk, T = p.T;
     const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
 
@@ -220,15 +222,17 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     float m_run = -INFINITY, l_half = 0.f;
     const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
 
-    const int ntiles = (T + AKT - 1) / AKT;
-    load_k(0);
-    load_v(0);
-    store_k(0, 0);
-    store_v(0, 0);
+    const int ntiles_all = (T + AKT - 1) / AKT;
+    const int jt_lo = (int)((long long)ksi * ntiles_all / KSPL);
+    const int ntiles = (int)((long long)(ksi + 1) * ntiles_all / KSPL);        // (end of this workgroup's key tiles)
+    load_k(jt_lo);
+    load_v(jt_lo);
+    store_k(jt_lo, 0);
+    store_v(jt_lo, 0);
     __syncthreads();
-    for (int jt = 0; jt < ntiles; ++jt) {
+    for (int jt = jt_lo; jt < ntiles; ++jt) {
         const int j0 = jt * AKT;
-        const int buf = (NBUF == 2) ? (jt & 1) : 0;
+        const int buf = (NBUF == 2) ? ((jt - jt_lo) & 1) : 0;
         const unsigned *Kb = Ks + buf * KBUF, *Vb = Vs + buf * VBUF;
         const float *Mb = Ms + buf * AKT;
         // two buffers: the next tile's K is in flight under the S^T MFMAs and written once they have issued, its V is in flight under
@@ -346,6 +350,29 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         }
     }
 
+    if (KSPL > 1) {
+        // key split: un-normalised rows (relative to this range's maximum), the maximum, the sum and the in-window raw scores of this key
+        // range; launch_attn_combine() merges the ranges, adds the relative-value term and normalises
+        const float l_tot = l_half + __shfl_xor(l_half, 32);
+        const int rows = dk + 2 + nrel;
+        float *pb = p.part + ((long long)(b * p.nh + h) * KSPL + ksi) * rows * T;
+        if (qi < T) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (d < dk) pb[(long long)d * T + qi] = o[t][r];
+                }
+            if (half == 0) {
+                pb[(long long)dk * T + qi] = m_run;
+                pb[(long long)(dk + 1) * T + qi] = l_tot;
+            }
+            for (int rr = half; rr < nrel; rr += 2) pb[(long long)(dk + 2 + rr) * T + qi] = Sww[l31 * ATT_QRS + rr];
+        }
+        return;
+    }
+
     // ---- finish: normalise, add the relative-value term (fp32), store ----
     // (the loop's last barrier has retired every read of the K / V buffers: 2 * KBUF dwords >= 16 rows x 256 channels)
     for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
@@ -378,6 +405,67 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     }
 }
 
+// merge of the key ranges: out[d] = (sum_k O_k[d] e^{m_k - m}) / L + sum_r e^{s_r - m} / L * rel_v[r][d],
+// m = max_k m_k, L = sum_k l_k e^{m_k - m}, s_r = the in-window score (owned by exactly one range; -inf elsewhere).
+// Block = 64 queries x 4 channel groups, blockIdx.x = query block * CG + channel-group block: each thread re-derives the weights of its
+// query (a few dozen loads) and merges dk / (4 CG) channels -- one thread per query walked all channels serially: 180 us at B = 1.
+constexpr int CMB_CG = 4;       // channel-group blocks per query block (x 4 groups per block = 16 groups)
+__global__ void __launch_bounds__(256) relattn_combine_kernel(const AttnParams p) {
+    const int qi = (blockIdx.x / CMB_CG) * 64 + (threadIdx.x & 63);
+    const int grp = (blockIdx.x % CMB_CG) * 4 + (threadIdx.x >> 6);          // 0 .. 4 CMB_CG - 1
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (qi >= p.T) return;
+    const int dk = p.dk, T = p.T, KS = p.ksplit;
+    const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
+    const int rows = dk + 2 + nrel;
+    const float *pb = p.part + (long long)(b * p.nh + h) * KS * rows * T + qi;
+    float mk[16], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mk[k] = (k < KS) ? pb[((long long)k * rows + dk) * T] : -INFINITY;
+        m = fmaxf(m, mk[k]);
+    }
+    float wk[16], L = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        wk[k] = (k < KS && mk[k] != -INFINITY) ? expf(mk[k] - m) : 0.f;
+        if (k < KS) L += pb[((long long)k * rows + dk + 1) * T] * wk[k];
+    }
+    const float inv = 1.0f / L;
+    float wr[ATT_MAXREL];
+#pragma unroll
+    for (int rr = 0; rr < ATT_MAXREL; ++rr) {
+        float sb = -INFINITY;
+        if (rr < nrel) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < KS) sb = fmaxf(sb, pb[((long long)k * rows + dk + 2 + rr) * T]);
+        }
+        wr[rr] = (rr < nrel) ? expf(sb - m) * inv : 0.f;
+    }
+    const float *relv = nrel ? p.rel_v + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+    float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T + qi;
+    const int per = (dk + 4 * CMB_CG - 1) / (4 * CMB_CG);
+    for (int d = grp * per; d < min(dk, (grp + 1) * per); ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < KS) acc += pb[((long long)k * rows + d) * T] * wk[k];
+        acc *= inv;
+#pragma unroll
+        for (int rr = 0; rr < ATT_MAXREL; ++rr)
+            if (rr < nrel) acc += wr[rr] * relv[rr * dk + d];
+        ob[(long long)d * T] = acc;
+    }
+}
+
+int launch_attn_combine(const AttnParams &p, hipStream_t s) {
+    dim3 grid((unsigned)(ceil_div(p.T, 64) * CMB_CG), (unsigned)p.nh, (unsigned)p.B);
+    hipLaunchKernelGGL(relattn_combine_kernel, grid, dim3(256), 0, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 bool attn_bf16_supported(const AttnParams &p, int terms) {
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     return p.dk <= (terms == 6 ? 128 : 256) && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
@@ -394,10 +482,12 @@ static int launch_bf16(const AttnParams &p, hipStream_t s) {
         attr_set = true;
     }
     if (lds > 160 * 1024) { set_error("vs_relattn_fwd (bf16): head dim %d needs %zu B of LDS", p.dk, lds); return VS_EUNSUPPORTED; }
-    dim3 grid((unsigned)ceil_div(p.T, 128), (unsigned)p.nh, (unsigned)p.B);
+    const int ks = (p.part && p.ksplit > 1) ? p.ksplit : 1;
+    dim3 grid((unsigned)(ceil_div(p.T, 128) * ks), (unsigned)p.nh, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
     set_last_kernel("relattn_bf16_kernel<%d, %d, %d>", DT, AKT, TERMS);
+    if (ks > 1) return launch_attn_combine(p, s);
     return VS_OK;
 }
 

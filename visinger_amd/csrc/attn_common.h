@@ -17,6 +17,10 @@ struct AttnParams {
     long long out_bs;
     int B, nh, dk, T, ws, nh_rel;
     float scale;
+    // key split (attention_bf16.hip, single utterances): the keys of a (batch, head) are cut into `ksplit` ranges, each workgroup writes
+    // its un-normalised output rows, row maximum, row sum and in-window scores to `part`, a second kernel combines them
+    float *part;                  // [B * nh * ksplit][dk + 2 + nrel][T], or null
+    int ksplit;                   // >= 2 with part, else 0 / 1
 };
 
 // attention_bf16.hip: both GEMMs on the bf16 matrix instruction, fp32 softmax / accumulation; terms = 1: bf16 operands (dk <= 256),
@@ -24,5 +28,6 @@ struct AttnParams {
 // q / k / v rows: when attn_bf16_supported() says no, the caller runs the exact-fp32 MFMA kernel.
 bool attn_bf16_supported(const AttnParams &p, int terms);
 int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s);
+int launch_attn_combine(const AttnParams &p, hipStream_t s);
 
 }  // namespace vs

@@ -326,9 +326,28 @@ static int launch_attn(const AttnParams &p, hipStream_t s) {
 
 extern "C" {
 
+static int relattn_fwd_impl(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                            const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                            int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit, void *stream);
+
 int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                    const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
                    int k_channels, int64_t T, int window_size, int n_heads_rel, int math, void *stream) {
+    return relattn_fwd_impl(q, k, v, qkv_batch_stride, rel_k, rel_v, mask, out, out_batch_stride, B, n_heads, k_channels, T, window_size,
+                            n_heads_rel, math, nullptr, 0, stream);
+}
+
+int vs_relattn_fwd_ksplit(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                          const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                          int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit, void *stream) {
+    VS_REQUIRE(ksplit >= 1 && ksplit <= 16 && (ksplit == 1 || work), "vs_relattn_fwd_ksplit: ksplit in 1..16, work buffer for ksplit > 1");
+    return relattn_fwd_impl(q, k, v, qkv_batch_stride, rel_k, rel_v, mask, out, out_batch_stride, B, n_heads, k_channels, T, window_size,
+                            n_heads_rel, math, work, ksplit, stream);
+}
+
+static int relattn_fwd_impl(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                            const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                            int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit, void *stream) {
     VS_REQUIRE(q && k && v && out, "vs_relattn_fwd: NULL tensor");
     VS_REQUIRE(B > 0 && B <= 65535 && n_heads > 0 && k_channels > 0 && T > 0, "vs_relattn_fwd: bad dims");
     VS_REQUIRE(window_size < 0 || (rel_k && rel_v), "vs_relattn_fwd: window given but relative embeddings are NULL");
@@ -343,14 +362,18 @@ int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_b
     p.out_bs = out_batch_stride ? out_batch_stride : (long long)n_heads * k_channels * T;
     p.B = (int)B; p.nh = n_heads; p.dk = k_channels; p.T = (int)T; p.ws = window_size; p.nh_rel = n_heads_rel;
     p.scale = 1.0f / sqrtf((float)k_channels);
+    p.part = nullptr; p.ksplit = 0;
     hipStream_t s = as_stream(stream);
     VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6, "vs_relattn_fwd: unknown arithmetic %d", math);
     // VS_MATH_BF16: both GEMMs on the bf16 matrix instruction (attention_bf16.hip); any other arithmetic, and shapes that kernel does
     // not take (T % 4 != 0, unaligned rows), run the exact-fp32 MFMA kernel below
     // VS_MATH_SPLIT6 (the default arithmetic of the path): the same kernel with every operand split exactly into three bf16 planes and
     // six cross products per product -- fp32-class scores and outputs at 16/6 of the fp32 matrix rate; VS_MATH_F32: the kernel below
+    // (key split: only the bf16-pipe kernels take it; the number of ranges is capped by the key tiles of the kernel, 32 keys each at least)
+    if (work && ksplit > 1 && T / 64 >= ksplit) { p.part = work; p.ksplit = ksplit; }
     if (math == VS_MATH_BF16 && attn_bf16_supported(p, 1) && !getenv("VS_NO_BF16_ATTN")) return launch_attn_bf16(p, 1, s);
     if (math == VS_MATH_SPLIT6 && attn_bf16_supported(p, 6) && !getenv("VS_NO_SPLIT_ATTN")) return launch_attn_bf16(p, 6, s);
+    p.part = nullptr; p.ksplit = 0;
     const int DT = (int)ceil_div(k_channels, 32);
     switch (DT) {
         case 1: return launch_attn<1, 4, false>(p, s);

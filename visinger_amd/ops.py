@@ -233,7 +233,7 @@ def weightnorm_fold(v, g):
     return w
 
 
-def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=None, out=None, math=L.MATH_F32):
+def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=None, out=None, math=L.MATH_F32, ksplit_auto=True):
     """a6: attention core on a fused [B, 3C, T] q|k|v buffer -> [B, C, T].  math = L.MATH_BF16: both GEMMs on the bf16 matrix
     instruction (the arithmetic of the q / k / v convs around it, BASELINE config 5); otherwise exact fp32."""
     lib = L.require_gpu()
@@ -242,14 +242,26 @@ def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=N
     if out is None:
         out = torch.empty((B, C, T), device=qkv.device, dtype=torch.float32)
     ws = -1 if window_size is None else int(window_size)
+    # launches that do not fill the chip (single utterances: B * heads * ceil(T / 128) workgroups, each walking every key tile) split the
+    # keys over several workgroups and merge the partial rows in a second kernel (vs_relattn_fwd_ksplit)
+    nwg = B * n_heads * -(-T // 128)
+    ksplit = 1
+    if ksplit_auto and nwg < 128 and T >= 256 and not os.environ.get("VS_NO_ATTN_KSPLIT"):
+        ksplit = max(1, min(8, 256 // nwg, T // 128))
+        if os.environ.get("VS_ATTN_KSPLIT"):
+            ksplit = max(1, min(16, int(os.environ["VS_ATTN_KSPLIT"]), T // 64))
+    work = None
+    if ksplit > 1:
+        R = 0 if rel_k is None else rel_k.shape[1]
+        work = torch.empty((B * n_heads * ksplit * (C // n_heads + 2 + R) * T,), device=qkv.device, dtype=torch.float32)
     if PROFILER.enabled:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(lib.vs_relattn_fwd(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
-                               L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
-                               L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
-                               C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
-                               int(math), L.stream_ptr()))
+    L.check(lib.vs_relattn_fwd_ksplit(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
+                                      L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
+                                      L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
+                                      C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
+                                      int(math), L.ptr(work), ksplit, L.stream_ptr()))
     if PROFILER.enabled:
         e1.record()      # algorithmic work: Q K^T and P V over the full [T, T] score matrix = 4 * T * T * k_channels per head
         PROFILER.records.append((lib.vs_last_kernel_name().decode(), 4.0 * B * C * T * T, 4.0 * B * 4 * C * T, e0, e1))
