@@ -378,3 +378,69 @@ def test_key_split_attention_equals_one_pass(dk, nh, T, ws, share, B, math):
     assert inst.startswith("relattn_bf16_kernel<") and bool(torch.isfinite(split).all())
     tol = 2e-6 if math == L.MATH_SPLIT6 else 2e-3
     assert float((split - one).abs().max()) <= tol * max(1.0, float(one.abs().max())), float((split - one).abs().max())
+
+
+def test_bf16_resident_tensors_random_sweep():
+    """Randomised version of the two tests above: 160 random (shape, dilation / stride, fused option) cases of the plain-bf16 conv on
+    bf16-RESIDENT tensors, each bit for bit against the same launch on the same values held in fp32 (output rounded once)."""
+    from visinger_amd.ops import ConvOp
+    r = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(2024)
+    done = 0
+    for case in range(160):
+        tr = r.random() < 0.25
+        B = int(r.integers(1, 4))
+        if tr:
+            u = int(r.choice([2, 3, 5, 8]))
+            k = int(u * r.integers(1, 3) + r.integers(0, 2))
+            if (k - u) % 2:
+                k += 1
+            Cin = int(r.integers(8, 300))
+            Cout = int(r.choice([32, 64, 128, 256])) if r.random() < 0.7 else int(r.integers(20, 200))
+            T = int(r.integers(1, 400))
+            op = ConvOp(L.CONV_TRANSPOSE1D, Cin, Cout, k, u, (k - u) // 2).set_math(L.MATH_BF16)
+            w = torch.randn(Cin, Cout, k, generator=g) / np.sqrt(Cin * k / u)
+            rows = u * Cout
+        else:
+            k = int(r.choice([1, 3, 5, 7, 9, 11]))
+            d = int(r.choice([1, 2, 3, 5]))
+            Cin, Cout = int(r.integers(4, 300)), int(r.choice([32, 64, 128, 192, 256, 384])) if r.random() < 0.7 else int(r.integers(5, 300))
+            T = int(r.integers(1, 3000))
+            op = ConvOp(L.CONV1D, Cin, Cout, k, d, d * (k - 1) // 2).set_math(L.MATH_BF16)
+            w = torch.randn(Cout, Cin, k, generator=g) / np.sqrt(Cin * k)
+            rows = Cout
+        op.set_weights(w.cuda(), None, torch.randn(Cout, generator=g).cuda() if r.random() < 0.8 else None)
+        xb = torch.randn(B, Cin, T, generator=g).cuda().bfloat16()
+        Tout = op.out_len(T)
+        kw = dict(in_act=int(r.choice([L.IN_NONE, L.IN_LRELU])))
+        mask = None
+        if r.random() < 0.4:
+            mask = (torch.rand(B, T, generator=g) < 0.8).float().cuda()
+            kw.update(in_act=L.IN_LRELU_MASK if kw["in_act"] == L.IN_LRELU else L.IN_MASK, mask=mask)
+        res = acc = None
+        if not tr:
+            if r.random() < 0.6:
+                res = torch.randn(B, Cout, Tout, generator=g).cuda().bfloat16()
+            if r.random() < 0.3:
+                acc = torch.randn(B, Cout, Tout, generator=g).cuda().bfloat16()
+                kw.update(scale=float(r.choice([1.0, 1.0 / 3])))
+            if r.random() < 0.3:
+                kw.update(out_act=L.OUT_RELU)
+            if mask is not None and r.random() < 0.5:
+                kw.update(out_mask=True)
+        ref = op.forward(xb.float(), res=None if res is None else res.float(), acc=None if acc is None else acc.float(), **kw)
+        wide = rows >= 96                                            # 128-row tiles: every combination of element types
+        try:
+            y = op.forward(xb, res=res, acc=acc, y_dtype=torch.bfloat16, **kw)
+        except L.VisingerHipError:
+            assert rows < 32 or (rows % 128 == 64 and rows > 128) or rows <= 4, (case, rows)      # tile shapes without a bf16 instance: loud
+            continue
+        assert torch.equal(y, ref.bfloat16()), (case, tr, Cin, Cout, k, T, kw.keys(), float((y.float() - ref).abs().max()))
+        done += 1
+        if wide and res is None and acc is None:
+            try:
+                y1 = op.forward(xb, **kw)
+            except L.VisingerHipError:
+                continue
+            assert torch.equal(y1, ref), (case, "bf16 in / fp32 out")
+    assert done >= 100, done
