@@ -236,9 +236,29 @@ def spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, VS_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    # Poll ALL children: a rank that dies leaves its siblings in dist.barrier() forever.  On the first non-zero exit the others are
+    # terminated (then killed) and the launcher exits non-zero; only these fresh children are ever signalled, by their exact PIDs.
+    rc, live = 0, list(procs)
+    while live and rc == 0:
+        for pr in list(live):
+            r = pr.poll()
+            if r is not None:
+                live.remove(pr)
+                if r != 0:
+                    rc = abs(r) or 1
+                    print(f"[bench] rank process {pr.pid} exited with {r}: stopping the other {len(live)} rank(s)", file=sys.stderr, flush=True)
+                    break
+        if live and rc == 0:
+            time.sleep(0.2)
+    for pr in live:
+        pr.terminate()
+    deadline = time.time() + 10.0
+    for pr in live:
+        try:
+            pr.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.wait()
     return rc
 
 
@@ -303,6 +323,8 @@ def dry_run(args):
     """The N-rank launch path without GPU work: rendezvous, barrier, max-over-ranks of a per-rank value, census of the ranks."""
     rank, local_rank, world, dist, backend = init_ranks(args)
     from visinger_amd.dp import max_over_ranks
+    if os.environ.get("VS_BENCH_DIE_RANK") == str(rank):      # test hook: this rank dies before the first barrier
+        os._exit(7)
     seen, pids = [rank], [os.getpid()]
     dev = torch.device("cuda", local_rank) if (backend == "nccl" and world > 1) else None
     if dist is not None:
@@ -329,7 +351,6 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))        # this process never touches the GPU
-    os.environ["VS_CONV_MATH"] = str(MATH[args.math])      # read by vs_conv_create: before any conv handle exists
     if args.dry_run:
         return dry_run(args)
     if not torch.cuda.is_available():
@@ -339,7 +360,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
+    from visinger_amd import _lib as L
     from visinger_amd.ops import PROFILER
+    L.set_option("VS_CONV_MATH", MATH[args.math])      # arithmetic of every conv handle created from here on (vs_conv_create)
     from visinger_amd.dp import shard_batch, max_over_ranks
     global HOP, SR
     HOP, SR = args.hop, (22050 if args.hop == 256 else 24000)

@@ -38,7 +38,14 @@ VS_API const char *vs_last_error(void);
  * this library, so a caller that attributes per-launch timings to kernel instances (bench.py's roofline line) reads it back
  * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
 VS_API const char *vs_last_kernel_name(void);
-VS_API int vs_abi_version(void);
+VS_API int vs_abi_version(void);          /* 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
+/* Dispatch switches (A/B comparisons and debugging; never needed for correct results).  The library reads the environment
+ * variables of the same names ONCE, when it is loaded; afterwards only these calls change a switch, and no launch path touches
+ * the environment.  Names and meanings: INTEGRATION.md "Switches".  Unknown name -> VS_EINVAL.  (No reference counterpart: the
+ * reference steers nothing on this path but `hparams`.)                                                                       */
+VS_API int vs_set_option(const char *name, long long value);
+VS_API int vs_get_option(const char *name, long long *value);
+VS_API int vs_reset_option(const char *name);
 /* number of HIP devices visible / name of device 0 written into buf (diagnostics for the loader) */
 VS_API int vs_device_info(char *buf, size_t buf_bytes);
 

@@ -28,3 +28,19 @@ def oracle():
     from oracle import visinger_oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture
+def vs_option():
+    """vs_option(name, value): set a dispatch switch (library: vs_set_option; Python layer: _lib.PY_SWITCHES) for this test only.
+    The switches are read from the environment once, at load: tests change them through the C ABI, not through os.environ."""
+    from visinger_amd import _lib as L
+    old = {}
+
+    def set_(name, value):
+        old.setdefault(name, L.get_option(name))
+        L.set_option(name, value)
+
+    yield set_
+    for name, v in old.items():
+        L.set_option(name, v)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 10
     missing = [s for s in sorted(syms) if not hasattr(lib, s)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
-    assert _lib.lib().vs_abi_version() >= 1
+    assert _lib.lib().vs_abi_version() == _lib.EXPECTED_ABI == 4
 
 
 def test_arguments_are_validated_without_a_gpu():
@@ -157,3 +157,49 @@ def test_conv_handles_survive_copy_and_pickle():
     op._wkey = ("stale",)
     repack_weights(m)
     assert op._wkey is None
+    # the fused q | k | v projection of an attention layer is keyed on (data_ptr, _version) of six parameters, which a
+    # `.data` edit does not change: repack_weights must drop it (and its training twin), and it must never be pickled
+    from visinger_amd.modules.rel_transformer import MultiHeadAttention, RelativeEncoder
+    enc = RelativeEncoder(16, 32, 2, 1, kernel_size=3)
+    att = enc.attn_layers[0]
+    att.__dict__["_hip_qkv_inf"] = (("key",), op, torch.zeros(1), torch.zeros(1))
+    att.__dict__["_hip_qkv"] = object()
+    att.conv_q.weight.data.mul_(2.0)                                 # the edit the cache key cannot see
+    a2 = pickle.loads(pickle.dumps(att))
+    assert isinstance(a2, MultiHeadAttention) and not any(k in a2.__dict__ for k in ("_hip_qkv_inf", "_hip_qkv"))
+    assert torch.equal(a2.conv_q.weight, att.conv_q.weight)
+    repack_weights(enc)
+    assert not any(k in att.__dict__ for k in ("_hip_qkv_inf", "_hip_qkv"))
+
+
+def test_dispatch_switches_are_read_once_and_set_through_the_abi():
+    """VERDICT r2 hygiene: no getenv / os.environ on a launch path -- the library reads its switches from the environment when it
+    is loaded (a child process shows it) and changes them only through vs_set_option; the Python layer likewise."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from visinger_amd import _lib as L\n"
+            "a = L.get_option('VS_NO_WSPLIT'), L.get_option('VS_SMALL_GRID_T6'), L.get_option('VS_CONV_MATH'), L.switch('VS_NO_RESPAIR')\n"
+            "os.environ['VS_NO_WSPLIT'] = '0'; os.environ['VS_NO_RESPAIR'] = ''\n"          # too late: read at load / import
+            "b = L.get_option('VS_NO_WSPLIT'), L.switch('VS_NO_RESPAIR')\n"
+            "L.set_option('VS_NO_WSPLIT', 0); L.set_option('VS_NO_RESPAIR', 0)\n"
+            "c = L.get_option('VS_NO_WSPLIT'), L.switch('VS_NO_RESPAIR')\n"
+            "with L.options(VS_CONV_MATH=0, VS_NO_TRAIN_ATTN=1):\n"
+            "    d = L.get_option('VS_CONV_MATH'), L.switch('VS_NO_TRAIN_ATTN')\n"
+            "e = L.get_option('VS_CONV_MATH'), L.switch('VS_NO_TRAIN_ATTN')\n"
+            "try:\n    L.set_option('VS_NO_SUCH_SWITCH', 1); f = 'accepted'\nexcept L.VisingerHipError: f = 'refused'\n"
+            "print(a, b, c, d, e, f)\n") % ROOT
+    env = dict(os.environ, VS_NO_WSPLIT="1", VS_NO_RESPAIR="1", PYTHONDONTWRITEBYTECODE="1")
+    env.pop("VS_CONV_MATH", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip() == "(1, 512, -1, 1) (1, 1) (0, 0) (0, 1) (-1, 0) refused", out.stdout
+    # and the sources: no getenv outside the one-time table initialisation, no os.environ switch outside _lib.py
+    import glob
+    import re
+    for path in glob.glob(os.path.join(ROOT, "visinger_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "visinger_amd", "csrc", "*.inc")):
+        text = open(path).read()
+        assert len(re.findall(r"\bgetenv\(", text)) == (1 if path.endswith("conv_engine.hip") else 0), path
+    for path in glob.glob(os.path.join(ROOT, "visinger_amd", "**", "*.py"), recursive=True):
+        if not path.endswith(("_lib.py", os.path.join("csrc", "build.py"))):
+            assert "os.environ" not in open(path).read(), path

@@ -263,9 +263,9 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("B,Cin,Cout,T,k,dil", WINO_CASES)
-def test_conv1d_winograd_path(oracle, monkeypatch, B, Cin, Cout, T, k, dil):
+def test_conv1d_winograd_path(oracle, vs_option, B, Cin, Cout, T, k, dil):
     from visinger_amd.ops import ConvOp
-    monkeypatch.setenv("VS_WINO_FORCE", "1")     # also the shapes the dispatch heuristic leaves on the direct engine
+    vs_option("VS_WINO_FORCE", 1)     # also the shapes the dispatch heuristic leaves on the direct engine
     r = rng(B * 977 + Cin + 3 * Cout + T + 11 * k + dil)
     x = r.standard_normal((B, Cin, T)).astype(np.float32)
     v = r.standard_normal((Cout, Cin, k)).astype(np.float32)
@@ -290,7 +290,7 @@ def test_conv1d_winograd_path(oracle, monkeypatch, B, Cin, Cout, T, k, dil):
     close(y, np.tanh(convm + res) * mask[:, None])
 
 
-def test_winograd_matches_direct_engine_at_size(monkeypatch):
+def test_winograd_matches_direct_engine_at_size(vs_option):
     """size-independent property at a resblock-sized launch: the F(2,3) path and the direct path agree to fp32 rounding"""
     from visinger_amd.ops import ConvOp
     torch.manual_seed(3)
@@ -300,28 +300,25 @@ def test_winograd_matches_direct_engine_at_size(monkeypatch):
     bias = torch.randn(C, device="cuda")
     op = ConvOp(L.CONV1D, C, C, k, dil, (k * dil - dil) // 2).set_math(L.MATH_F32)
     op.set_weights(w, None, bias)
-    monkeypatch.setenv("VS_WINO_FORCE", "1")
+    vs_option("VS_WINO_FORCE", 1)
     y_w = op.forward(x, in_act=L.IN_LRELU, res=x)
-    monkeypatch.delenv("VS_WINO_FORCE")
-    monkeypatch.setenv("VS_NO_WINO", "1")
+    vs_option("VS_WINO_FORCE", 0)
+    vs_option("VS_NO_WINO", 1)
     y_d = op.forward(x, in_act=L.IN_LRELU, res=x)
     torch.cuda.synchronize()
     assert float((y_w - y_d).abs().max()) <= 2e-5 * (1.0 + float(y_d.abs().max()))
 
 
 @pytest.mark.parametrize("seed", [11, 12])
-def test_conv_engine_random_sweep(seed, monkeypatch):
+def test_conv_engine_random_sweep(seed, monkeypatch, vs_option):
     """tools/conv_fuzz.py: 150 random (shape, dilation / stride, fused option) cases per seed across every kernel instance"""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import conv_fuzz
     monkeypatch.setattr(sys, "argv", ["conv_fuzz.py", "150", str(seed)])
-    monkeypatch.delenv("VS_WINO_FORCE", raising=False)
-    try:
-        conv_fuzz.main()
-    finally:
-        os.environ.pop("VS_WINO_FORCE", None)
+    vs_option("VS_WINO_FORCE", 0)
+    conv_fuzz.main()          # (sets VS_WINO_FORCE per case through L.set_option; the fixture restores it)
 
 
 @pytest.mark.parametrize("C,k,d,T,B", [(32, 3, 1, 2048, 2), (32, 7, 3, 1500, 1), (32, 11, 5, 1024, 2), (64, 3, 5, 1000, 1),

@@ -22,11 +22,11 @@ def rel_rms(y, ref):
 
 @pytest.mark.parametrize("C,k,d,T", [(128, 3, 1, 2048), (128, 7, 3, 1500), (256, 11, 1, 777), (64, 11, 5, 4096), (32, 7, 1, 3000),
                                       (192, 5, 1, 1000), (96, 1, 1, 513)])
-def test_split6_error_not_above_fp32_mfma(oracle, monkeypatch, C, k, d, T):
+def test_split6_error_not_above_fp32_mfma(oracle, vs_option, C, k, d, T):
     """the six-product split keeps the fp32 class: its RMS error against fp64 is not above the exact-fp32 MFMA engine's
     direct form (both are dominated by fp32 accumulation rounding; tools/conv_accuracy.py prints the table)"""
     from visinger_amd.ops import ConvOp
-    monkeypatch.setenv("VS_NO_WINO", "1")        # MATH_F32 = the direct fp32 MFMA kernel, not its F(2,3) variant
+    vs_option("VS_NO_WINO", 1)        # MATH_F32 = the direct fp32 MFMA kernel, not its F(2,3) variant
     r = np.random.default_rng(C * 31 + k * 7 + d + T)
     x = r.standard_normal((2, C, T)).astype(np.float32)
     w = (r.standard_normal((C, C, k)) / np.sqrt(C * k)).astype(np.float32)
@@ -158,7 +158,7 @@ def test_bf16_attention_matches_fp32_kernel(dk, nh, T, ws, share):
                                               (128, 128, 3, 1, 4, 2), (136, 384, 9, 1, 260, 1),
                                               (64, 64, 11, 1, 1024, 2), (64, 64, 11, 3, 700, 1), (64, 64, 11, 5, 516, 2), (64, 64, 7, 1, 300, 1),
                                               (64, 64, 7, 5, 1000, 1), (64, 64, 3, 3, 130, 2), (48, 192, 9, 1, 250, 1), (64, 64, 3, 1, 2, 1)])
-def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
+def test_wsplit_f23_on_split_engine(oracle, vs_option, Cin, Cout, k, d, T, B):
     """csrc/conv_wsplit.hip: minimal filtering F(2,3) on the split-bf16 x6 arithmetic (4 products of 6 cross terms per output pair
     and tap group instead of 6) against the fp64 oracle, with every fused option of the LINEAR epilogue it serves -- residual,
     accumulate + scale (the MRF average), leaky-relu / mask on the input, ReLU and mask on the output, per-item conditioning bias --
@@ -166,7 +166,7 @@ def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
     are not a multiple of the 16-channel chunk; and next to the direct split kernel on the same data (decoder.py:72-87 resblock
     convs, rel_transformer.py:332-333 FFN k = 9)."""
     from visinger_amd.ops import ConvOp
-    monkeypatch.setenv("VS_WSPLIT_FORCE", "1")            # k = 7 too (zero-padded last group)
+    vs_option("VS_WSPLIT_FORCE", 1)            # k = 7 too (zero-padded last group)
     r = np.random.default_rng(Cin * 13 + Cout + k * 7 + d + T)
     x = r.standard_normal((B, Cin, T)).astype(np.float32)
     v = r.standard_normal((Cout, Cin, k)).astype(np.float32)
@@ -205,7 +205,7 @@ def test_wsplit_f23_on_split_engine(oracle, monkeypatch, Cin, Cout, k, d, T, B):
     convlm = oracle.conv1d(xl * m3, w, bias, dilation=d, padding=pad)
     close(op.forward(dev(x), in_act=L.IN_LRELU_MASK, mask=dev(mask), out_mask=True, bias_b=dev(cond)), (convlm + cond[:, :, None]) * m3)
     # same arithmetic class as the direct split kernel on the same data (not bit-identical: different summation order)
-    monkeypatch.setenv("VS_NO_WSPLIT", "1")
+    vs_option("VS_NO_WSPLIT", 1)
     yd = op.forward(dev(x), in_act=L.IN_LRELU)
     assert op.kernel_instance().startswith("conv_split_kernel<")
     ref_rms = float(np.sqrt((conv ** 2).mean()))

@@ -144,3 +144,19 @@ def test_bench_gpus_n_spawns_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1"),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_stops_all_ranks_when_one_dies():
+    """spawn_ranks waited for its children one after the other -- a rank that died left its siblings in dist.barrier()
+    (and the launcher) hanging.  Now the launcher polls all of them, terminates the survivors and exits non-zero."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(VS_BENCH_BACKEND="gloo", VS_BENCH_DIE_RANK="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 7, (out.returncode, out.stderr[-2000:])
+    assert "stopping the other 1 rank(s)" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]          # no line for a broken run
+    assert time.time() - t0 < 240

@@ -287,11 +287,11 @@ def test_discriminators_gpu():
 
 
 @pytest.mark.parametrize("math", ["6", "0"])
-def test_modules_random_sweep(monkeypatch, math):
+def test_modules_random_sweep(monkeypatch, math, vs_option):
     """tools/module_fuzz.py: 60 random (hyper-parameters, batch, length, ragged mask) cases over WaveNet, coupling layer /
     block (both directions, log-det), generator (random upsampling stacks, ResBlock1/2), relative encoder and posterior
     encoder, against the fp64 oracle -- on the default split-bf16 engine and on the fp32 MFMA / F(2,3) engine."""
-    monkeypatch.setenv("VS_CONV_MATH", math)
+    vs_option("VS_CONV_MATH", int(math))
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

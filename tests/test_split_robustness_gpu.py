@@ -34,10 +34,10 @@ def run(oracle, x, w, bias, k, d, maths=(L.MATH_F32, L.MATH_SPLIT6)):
 
 
 @pytest.mark.parametrize("C,k,d,T,span", [(128, 7, 1, 1500, 20), (64, 11, 3, 2048, 20), (256, 3, 1, 700, 12), (32, 7, 5, 3000, 20)])
-def test_wide_dynamic_range(oracle, monkeypatch, C, k, d, T, span):
+def test_wide_dynamic_range(oracle, vs_option, C, k, d, T, span):
     """activations and weights with magnitudes log-uniform over 2^-span .. 2^span and random signs: every plane of the split sees
     every exponent; the lower planes (x - xh, x - xh - xm) of large and of tiny values are all exercised"""
-    monkeypatch.setenv("VS_NO_WINO", "1")
+    vs_option("VS_NO_WINO", 1)
     r = np.random.default_rng(C + 13 * k + d)
     x = (r.choice([-1.0, 1.0], (2, C, T)) * np.exp2(r.uniform(-span, span, (2, C, T))) * r.uniform(1, 2, (2, C, T))).astype(np.float32)
     w = (r.choice([-1.0, 1.0], (C, C, k)) * np.exp2(r.uniform(-span, span, (C, C, k))) * r.uniform(1, 2, (C, C, k))).astype(np.float32)
@@ -53,10 +53,10 @@ def test_wide_dynamic_range(oracle, monkeypatch, C, k, d, T, span):
 
 
 @pytest.mark.parametrize("C,k,T", [(128, 7, 1024), (64, 3, 4096)])
-def test_catastrophic_cancellation(oracle, monkeypatch, C, k, T):
+def test_catastrophic_cancellation(oracle, vs_option, C, k, T):
     """pairs of channels carry +a and -a(1 - 2^-12) under equal weights: each output is the small difference of products 2^12
     times larger, so any error of the operand split relative to the OPERANDS (not to the result) would surface 4096-fold"""
-    monkeypatch.setenv("VS_NO_WINO", "1")
+    vs_option("VS_NO_WINO", 1)
     r = np.random.default_rng(7 * C + k)
     a = (r.standard_normal((2, C // 2, T)) * 100.0).astype(np.float32)
     x = np.empty((2, C, T), np.float32)

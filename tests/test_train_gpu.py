@@ -342,7 +342,7 @@ def test_training_attention_kernels_match_torch_autograd(B, nh, dk, T, w, nh_rel
         assert e <= 3e-5 * max(1.0, float(b.abs().max())), (name, e, float(b.abs().max()))
 
 
-def test_training_transformer_layer_uses_the_streaming_attention(monkeypatch):
+def test_training_transformer_layer_uses_the_streaming_attention(vs_option):
     """autograd.attention routes the training-mode core through AttnCoreFn: a relative encoder's output and parameter gradients are those of
     the PyTorch [T, T] version of the same function (VS_NO_TRAIN_ATTN) with dropout off."""
     from visinger_amd import autograd as A
@@ -355,7 +355,7 @@ def test_training_transformer_layer_uses_the_streaming_attention(monkeypatch):
     res = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("VS_NO_TRAIN_ATTN", "1")
+            vs_option("VS_NO_TRAIN_ATTN", 1)
         xi = x.clone().requires_grad_(True)
         y = A.rel_encoder(enc, xi, mask)
         ps = [p for p in enc.parameters() if p.requires_grad]

@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visinger_amd import autograd as A  # noqa: E402
+from visinger_amd import _lib as L  # noqa: E402
 from visinger_amd.modules.rel_transformer import MultiHeadAttention  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -49,5 +50,5 @@ def layer_fb():
 print(f"B={B} T={T} p_drop={pd}")
 print(f"AttnCoreFn forward {timed(core_fwd):.3f} ms, forward + backward {timed(core_fb):.3f} ms")
 print(f"whole attention layer (q/k/v/o convs + core), forward + backward: HIP core {timed(layer_fb):.3f} ms", end="")
-os.environ["VS_NO_TRAIN_ATTN"] = "1"
+L.set_option("VS_NO_TRAIN_ATTN", 1)
 print(f", PyTorch [T,T] core {timed(layer_fb):.3f} ms")

@@ -25,15 +25,14 @@ def run(C, k, d, T, B=2, seed=0, scale_x=1.0):
     for name, env, math in (("fp32 mfma", {"VS_NO_WINO": "1"}, L.MATH_F32), ("fp32 F(2,3)", {"VS_WINO_FORCE": "1"}, L.MATH_F32),
                             ("split-bf16 x6", {}, L.MATH_SPLIT6), ("bf16", {}, L.MATH_BF16)):
         for kk in ("VS_NO_WINO", "VS_WINO_FORCE"):
-            os.environ.pop(kk, None)
-        os.environ.update(env)
+            L.set_option(kk, int(env.get(kk, 0)))
         op = ConvOp(L.CONV1D, C, C, k, d, pad).set_math(math)
         op.set_weights(w, None, bias)
         y = op.forward(x)
         e = (y.double() - ref)
         out[name] = (e.pow(2).mean().sqrt().item() / rms, e.abs().max().item() / rms, op.kernel_instance())
     for kk in ("VS_NO_WINO", "VS_WINO_FORCE"):
-        os.environ.pop(kk, None)
+        L.set_option(kk, 0)
     y = torch.nn.functional.conv1d(x, w, bias, padding=pad, dilation=d)
     e = y.double() - ref
     out["torch fp32 (MIOpen)"] = (e.pow(2).mean().sqrt().item() / rms, e.abs().max().item() / rms, "-")

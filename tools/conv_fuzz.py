@@ -26,7 +26,7 @@ def main():
     worst = {}
     for case in range(n):
         transposed = r.random() < 0.2
-        math = int(os.environ["VS_CONV_MATH"]) if os.environ.get("VS_CONV_MATH") else int(r.choice([L.MATH_F32, L.MATH_SPLIT6]))
+        math = int(L.get_option("VS_CONV_MATH")) if L.get_option("VS_CONV_MATH") >= 0 else int(r.choice([L.MATH_F32, L.MATH_SPLIT6]))
         B = int(r.integers(1, 4))
         if transposed:
             u = int(r.choice([2, 3, 4, 5, 8]))
@@ -53,12 +53,8 @@ def main():
             Cout = int(r.choice([1, 2, 16, 32, 64, 96, 128, 192, 256, 70]))
             T = int(r.choice([1, 2, 5, 31, 64, 100, 127, 128, 129, 255, 256, 257, 500, 512, 1000, 1024, 2047]))
             pad = d * (k - 1) // 2
-            if os.environ.get("VS_WINO_FORCE") is None and r.random() < 0.5:
-                os.environ["VS_WINO_FORCE"] = "1"
-                forced = True
-            else:
-                os.environ.pop("VS_WINO_FORCE", None)
-                forced = False
+            forced = r.random() < 0.5
+            L.set_option("VS_WINO_FORCE", int(forced))
             x = r.standard_normal((B, Cin, T)).astype(np.float32)
             w = (r.standard_normal((Cout, Cin, k)) / np.sqrt(Cin * k)).astype(np.float32)
             bias = r.standard_normal(Cout).astype(np.float32) if r.random() < 0.8 else None

@@ -14,5 +14,5 @@ def bench(C,k,d,T,B=32):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/5*1e3
 for dbg in sys.argv[1:]:
-    os.environ["VS_WINO_DBG"]=dbg
+    L.set_option("VS_WINO_DBG", int(dbg))
     print("dbg",dbg, "C128 k11: %.0f us  k3: %.0f us  k7: %.0f   C64 k11: %.0f  k3: %.0f" % (bench(128,11,1,65536), bench(128,3,1,65536), bench(128,7,1,65536), bench(64,11,1,131072), bench(64,3,1,131072)), flush=True)

@@ -7,7 +7,7 @@ from visinger_amd import _lib as L
 from visinger_amd.ops import ConvOp
 
 B = int(os.environ.get("CB_B", 32))
-os.environ["VS_WSPLIT_FORCE"] = "1"
+L.set_option("VS_WSPLIT_FORCE", 1)
 
 
 def run(op, x, y, res, n):
@@ -31,15 +31,15 @@ for cin, cout, T in ((256, 256, 8192), (128, 128, 65536), (64, 64, 131072), (192
             res = torch.randn_like(y)
             tw, td = [], []
             for rnd in range(3):
-                os.environ.pop("VS_NO_WSPLIT", None)
+                L.set_option("VS_NO_WSPLIT", 0)
                 run(op, x, y, res, 1)
                 tw.append(run(op, x, y, res, 4))
                 kw = op.kernel_instance()
-                os.environ["VS_NO_WSPLIT"] = "1"
+                L.set_option("VS_NO_WSPLIT", 1)
                 run(op, x, y, res, 1)
                 td.append(run(op, x, y, res, 4))
                 kd = op.kernel_instance()
-            os.environ.pop("VS_NO_WSPLIT", None)
+            L.set_option("VS_NO_WSPLIT", 0)
             fl = op.algorithmic_flops(B, T)
             w, dd = min(tw), min(td)
             mult = (4 if d == 1 else 1) if cin == cout else 1

@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visinger_amd import _lib as L
 from visinger_amd.ops import ConvOp
-os.environ["VS_WSPLIT_FORCE"] = "1"
+L.set_option("VS_WSPLIT_FORCE", 1)
 B = 32
 for C, T in ((128, 65536), (256, 8192)):
     for k, d in ((3, 1), (7, 1), (11, 1), (11, 5)):
@@ -14,7 +14,7 @@ for C, T in ((128, 65536), (256, 8192)):
         x = torch.randn(B, C, T, device="cuda"); y = torch.empty_like(x); res = torch.randn_like(x)
         line = f"C={C} k={k} d={d}:"
         for stg in (0, 32, 64, 128, 0):
-            os.environ["VS_WSPLIT_STAGGER"] = str(stg)
+            L.set_option("VS_WSPLIT_STAGGER", int(stg))
             best = 1e9
             for rnd in range(3):
                 op.forward(x, y=y, res=res, in_act=L.IN_LRELU)

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visinger_amd import _lib as L
 from visinger_amd.ops import ConvOp
 
-os.environ["VS_WSPLIT_FORCE"] = "1"
+L.set_option("VS_WSPLIT_FORCE", 1)
 C, k, d, T, B = int(os.environ.get("C", 128)), int(os.environ.get("K", 3)), int(os.environ.get("D", 1)), int(os.environ.get("T", 65536)), int(os.environ.get("B", 32))
 op = ConvOp(L.CONV1D, C, C, k, d, (k * d - d) // 2)
 op.set_weights(torch.randn(C, C, k, device="cuda") * 0.05, None, torch.randn(C, device="cuda"))

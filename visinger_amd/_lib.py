@@ -22,6 +22,8 @@ FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 MATH_F32, MATH_BF16, MATH_SPLIT6 = 0, 1, 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
+EXPECTED_ABI = 4          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
+
 _f32p = ctypes.c_void_p
 
 
@@ -63,7 +65,14 @@ def lib():
     L.vs_last_error.restype = ctypes.c_char_p
     L.vs_last_kernel_name.restype = ctypes.c_char_p
     L.vs_abi_version.restype = ctypes.c_int
+    got = L.vs_abi_version()
+    if got != EXPECTED_ABI:       # a stale or partially rebuilt .so would be called with the wrong argument layout (ConvIO, vs_relattn_fwd)
+        raise VisingerHipError(f"{LIB_PATH} exports ABI version {got}, this package binds version {EXPECTED_ABI}: rebuild it "
+                               f"(python -m visinger_amd.csrc.build --force)")
     L.vs_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    L.vs_set_option.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    L.vs_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]
+    L.vs_reset_option.argtypes = [ctypes.c_char_p]
     L.vs_weightnorm_fold.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
     L.vs_conv_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint]
@@ -105,6 +114,51 @@ def lib():
     L.vs_gconv1d_bwd_weight.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
     _lib = L
     return L
+
+
+# Switches of the Python layer (A/B and debugging), read from the environment ONCE at import like the library's own
+# (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
+PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
+               for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
+                            "VS_NO_WGRAD_GEMM", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED")}
+
+
+def switch(name):
+    return PY_SWITCHES[name]
+
+
+def set_option(name, value):
+    """Set a dispatch switch by its (environment-variable) name: a Python-layer switch or one of the library's (vs_set_option)."""
+    if name in PY_SWITCHES:
+        PY_SWITCHES[name] = int(value)
+    else:
+        check(lib().vs_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    if name in PY_SWITCHES:
+        return PY_SWITCHES[name]
+    v = ctypes.c_longlong(0)
+    check(lib().vs_get_option(name.encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
+class options:
+    """with options(VS_NO_WINO=1, VS_WSPLIT_FORCE=1): ...  -- switches set for the block, previous values restored after it"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def check(rc):

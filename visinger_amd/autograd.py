@@ -302,7 +302,10 @@ def wavenet(m, x, x_mask, g=None):
     output = torch.zeros_like(x)
     if g is not None:
         g = conv(m.cond_layer, g)
-    fused = x.is_cuda and not os.environ.get("VS_NO_TRAIN_FUSED") and (m.p_dropout == 0 or not m.training)
+    # (the gate kernel reads the conditioning as ONE column per item, g[b, c, 0]: a time-varying [B, gin, T] condition -- which the
+    # reference's WN broadcasts as well -- or a non-fp32 one takes the PyTorch formulation)
+    fused = (x.is_cuda and not L.switch("VS_NO_TRAIN_FUSED") and (m.p_dropout == 0 or not m.training) and
+             (g is None or (g.shape[2] == 1 and g.dtype == torch.float32)))
     for i in range(m.n_layers):
         x_in = conv(m.in_layers[i], x)
         if fused:
@@ -397,7 +400,7 @@ def generator(m, x, g=None):
 
 def layer_norm(m, x, r=None):
     """rel_transformer.py:33-42 on x (+ r: the residual add of the encoder layers folded in)"""
-    if x.is_cuda and x.dim() == 3 and x.shape[1] <= 1024 and not os.environ.get("VS_NO_TRAIN_FUSED"):
+    if x.is_cuda and x.dim() == 3 and x.shape[1] <= 1024 and not L.switch("VS_NO_TRAIN_FUSED"):
         return LayerNormFn.apply(x, r, m.gamma, m.beta, m.eps)
     if r is not None:
         x = x + r
@@ -506,11 +509,11 @@ def attention(m, x, frame_mask):
     relative terms laid onto the band through strided views (what the reference's pad / reshape skew implements)."""
     B, C, T = x.shape
     nh, dk, w = m.n_heads, m.k_channels, m.window_size
-    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not os.environ.get("VS_NO_TRAIN_ATTN"):
+    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not L.switch("VS_NO_TRAIN_ATTN"):
         rel_k, rel_v = (m.emb_rel_k, m.emb_rel_v) if w is not None else (None, None)
         pd = m.drop.p if m.training else 0.0
         plain = all(not hasattr(c, "weight_g") and c.bias is not None and c.kernel_size[0] == 1 for c in (m.conv_q, m.conv_k, m.conv_v))
-        if plain and not os.environ.get("VS_NO_FUSED_QKV"):
+        if plain and not L.switch("VS_NO_FUSED_QKV"):
             # q | k | v as one [3C, C_in] projection (rel_transformer.py:120-122 are three nn.Conv1d(channels, channels, 1) of the same x)
             holder = m.__dict__.get("_hip_qkv")
             if holder is None:

@@ -45,6 +45,29 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def includes(path, seen=None):
+    """the local files `path` includes, transitively (quoted includes and the VS_EPILOGUE_INC-style macro definitions)"""
+    import re
+    seen = set() if seen is None else seen
+    try:
+        text = open(path).read()
+    except OSError:
+        return seen
+    for name in re.findall(r'#\s*(?:include|define\s+\w+_INC)\s+"([^"]+)"', text):
+        dep = os.path.normpath(os.path.join(os.path.dirname(path), name))
+        if dep not in seen and os.path.exists(dep):
+            seen.add(dep)
+            includes(dep, seen)
+    return seen
+
+
+def stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__)] + sorted(includes(src)))
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -53,6 +76,8 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = src[:-4] + ".o"
         objs.append(obj)
+        if not force and not stale(src, obj):      # (objects are per translation unit: only the units whose sources changed)
+            continue
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
         guarded = os.path.basename(src) in NO_SCRATCH
         if guarded:

@@ -272,7 +272,7 @@ static int wgrad_slices(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out) {
 
 // the split-bf16 kernel: 2..12 taps, >= 64 output channels, float4-loadable gy rows, enough positions to fill its 64-position units
 static bool wgrad_split_ok(int64_t B, int64_t c_out, int64_t T_out, int k) {
-    return k >= 2 && k <= WS_MAXK && c_out >= 64 && (T_out % 4) == 0 && B * T_out >= 512 && !getenv("VS_NO_WGRAD_SPLIT");
+    return k >= 2 && k <= WS_MAXK && c_out >= 64 && (T_out % 4) == 0 && B * T_out >= 512 && !opt(OPT_NO_WGRAD_SPLIT);
 }
 static int wgrad_split_slices(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out) {
     const int64_t units = B * ceil_div(T_out, WS_TU);
@@ -295,7 +295,12 @@ int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, 
     p.gy = gy; p.x = x; p.gw = gw_planes;
     p.B = (int)B; p.Cout = (int)c_out; p.Cin = (int)c_in; p.Tout = (int)T_out; p.Tin = (int)T_in;
     p.K = k; p.dil = dil; p.pad = pad;
-    if (wgrad_split_ok(B, c_out, T_out, k) && (reinterpret_cast<uintptr_t>(gy) & 15u) == 0) {
+    if (wgrad_split_ok(B, c_out, T_out, k)) {
+        // vs_conv_wgrad_planes sized `gw_planes` for THIS kernel's reduction slices from the shape alone: an unaligned gy cannot fall back
+        // to conv_wgrad_kernel (a different plane count: it would write past the buffer or leave planes unwritten)
+        VS_REQUIRE((reinterpret_cast<uintptr_t>(gy) & 15u) == 0,
+                   "vs_conv_wgrad: gy must be 16-byte aligned for this shape (k = %d, c_out = %lld: float4 row loads); copy it to an aligned buffer",
+                   k, (long long)c_out);
         p.units_per_item = (int)ceil_div(T_out, WS_TU);
         p.units = p.B * p.units_per_item;
         dim3 grid((unsigned)ceil_div(c_in, 32), (unsigned)ceil_div(c_out, k < 8 ? 128 : 64), (unsigned)wgrad_split_slices(B, c_out, c_in, T_out));

@@ -39,6 +39,27 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- dispatch switches: see vs_internal.h (enum Opt).  Read from the environment ONCE, when the library is loaded.
+struct OptEntry { const char *name; long long dflt; long long value; };
+static OptEntry g_opts[OPT_COUNT] = {
+    {"VS_CONV_MATH", -1, -1}, {"VS_NO_SMALL_CONV", 0, 0}, {"VS_NO_FAST_EPI", 0, 0}, {"VS_WINO_FORCE", 0, 0}, {"VS_NO_WINO", 0, 0},
+    {"VS_NO_WINO_K7", 0, 0}, {"VS_WINO_DBG", 0, 0}, {"VS_NO_WSPLIT", 0, 0}, {"VS_WSPLIT_FORCE", 0, 0}, {"VS_WSPLIT_STAGGER", 0, 0},
+    {"VS_NO_SMALL_GRID", 0, 0}, {"VS_SMALL_GRID_T6", 512, 512}, {"VS_CONV_CFG", -1, -1}, {"VS_SPLIT_DBG", 0, 0}, {"VS_TRACE", 0, 0},
+    {"VS_NO_BF16_ATTN", 0, 0}, {"VS_NO_SPLIT_ATTN", 0, 0}, {"VS_NO_WGRAD_SPLIT", 0, 0}, {"VS_NO_PERSIST", 0, 0},
+};
+static const bool g_opts_loaded = [] {
+    for (OptEntry &e : g_opts) {
+        const char *v = getenv(e.name);
+        if (v && *v) {
+            char *end = nullptr;
+            const long long n = strtoll(v, &end, 10);
+            e.value = (end != v) ? n : 1;          // (a non-numeric value counts as "set")
+        }
+    }
+    return true;
+}();
+long long opt(Opt o) { return g_opts[o].value; }
+
 thread_local char g_last_kernel[160] = "";
 void set_last_kernel(const char *fmt, ...) {
     va_list ap;
@@ -1159,7 +1180,29 @@ extern "C" {
 
 const char *vs_last_error(void) { return g_err; }
 const char *vs_last_kernel_name(void) { return g_last_kernel; }
-int vs_abi_version(void) { return 3; }
+int vs_abi_version(void) { return 4; }
+
+int vs_set_option(const char *name, long long value) {
+    VS_REQUIRE(name, "vs_set_option: NULL name");
+    for (OptEntry &e : g_opts)
+        if (strcmp(e.name, name) == 0) { e.value = value; return VS_OK; }
+    set_error("vs_set_option: unknown option %s", name);
+    return VS_EINVAL;
+}
+int vs_get_option(const char *name, long long *value) {
+    VS_REQUIRE(name && value, "vs_get_option: NULL argument");
+    for (const OptEntry &e : g_opts)
+        if (strcmp(e.name, name) == 0) { *value = e.value; return VS_OK; }
+    set_error("vs_get_option: unknown option %s", name);
+    return VS_EINVAL;
+}
+int vs_reset_option(const char *name) {          /* back to the built-in default (not to the environment's value) */
+    VS_REQUIRE(name, "vs_reset_option: NULL name");
+    for (OptEntry &e : g_opts)
+        if (strcmp(e.name, name) == 0) { e.value = e.dflt; return VS_OK; }
+    set_error("vs_reset_option: unknown option %s", name);
+    return VS_EINVAL;
+}
 
 int vs_device_info(char *buf, size_t n) {
     int cnt = 0;
@@ -1237,17 +1280,17 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     if (kind == VS_CONV1D && k >= 3 && (k & 1) && (dil == 1 || dil == 3 || dil == 5) && pad == dil * (k - 1) / 2 &&
         c_out % 32 == 0 && 3 * (int)ceil_div(k, 3) * dil <= MAX_SPAN)
         h->wino_groups = (int)ceil_div(k, 3);
-    h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !getenv("VS_NO_WINO_K7");
-    h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !getenv("VS_NO_WINO_K7");
+    h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !opt(OPT_NO_WINO_K7);
+    h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !opt(OPT_NO_WINO_K7);
     // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
     h->wsplit = h->wino_groups > 0 && (h->MT % 2) == 0 && (flags & ~VS_CONV_ADJOINT) == 0 && wsplit_instance(dil, h->wino_groups) &&
-                (k >= 9 || getenv("VS_WSPLIT_FORCE"));      // (where it pays: see vs_conv_forward)
+                (k >= 9 || opt(OPT_WSPLIT_FORCE));      // (where it pays: see vs_conv_forward)
     // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
     // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
     // VS_CONV_MATH=0 / 1 / 6: process-wide A/B switch for handles created from here on.
     h->math = VS_MATH_SPLIT6;
-    if (const char *e = getenv("VS_CONV_MATH")) {
-        const int m = atoi(e);
+    {
+        const int m = (int)opt(OPT_CONV_MATH);
         if (m == VS_MATH_F32 || m == VS_MATH_BF16 || m == VS_MATH_SPLIT6) h->math = m;
     }
     *out = h;
@@ -1406,7 +1449,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // (an INPUT mask -- VS_IN_MASK / VS_IN_LRELU_MASK, indexed by input frame while staging -- is fine with any kind)
     VS_REQUIRE(Tout == io->T || !need_out_mask, "vs_conv_forward: an output mask needs T_out == T (not with a transposed / unpadded conv)");
     hipStream_t s = as_stream(stream);
-    static const bool trace = getenv("VS_TRACE") != nullptr;   // debug: one line per launch on stderr
+    const bool trace = opt(OPT_TRACE) != 0;   // debug: one line per launch on stderr
     if (trace)
         fprintf(stderr, "[vs_conv_forward] kind %d %d->%d k%d d%d pad%d flags%u B%d T%d Tout%d in_act%d split%d mode%d,%d res%d acc%d "
                         "mask%d bias_b%d pair%d x%p y%p y1%p\n", h->kind, h->c_in, h->c_out, h->k, h->dil, h->pad, h->flags, p.B, p.Tin,
@@ -1418,7 +1461,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // the MFMA tiles even at 1 valid row in 32)
     if (h->kind == VS_CONV1D && h->c_out <= 4 && h->c_in * h->k <= 2048 && !(h->flags & (VS_CONV_FLIP_IN | VS_CONV_FLIP_OUT | VS_CONV_ADJOINT)) && !p.split_row &&
         !p.y_bf16 &&
-        !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_SMALL_CONV")) {
+        !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && !opt(OPT_NO_SMALL_CONV)) {
         SmallParams q;
         q.x = p.x; q.x_bs = p.x_bs; q.w = h->weff.as<float>(); q.bias = h->has_bias ? h->beff.as<float>() : nullptr;
         q.bias_b = p.bias_b; q.bias_b_bs = p.bias_b_bs; q.mask = p.mask; q.y = p.out[0].y; q.y_bs = p.out[0].y_bs;
@@ -1458,7 +1501,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     }
     {
         auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-        bool ok = (h->kind == VS_CONV1D) && (Tout % 4 == 0) && !getenv("VS_NO_FAST_EPI");
+        bool ok = (h->kind == VS_CONV1D) && (Tout % 4 == 0) && !opt(OPT_NO_FAST_EPI);
         for (int s2 = 0; s2 < (p.split_row ? 2 : 1) && ok; ++s2) {
             const OutSpec &d = p.out[s2];
             ok = ok && d.mode == VS_OUT_LINEAR && al16(d.y) && (d.y_bs % 4 == 0) && (!d.res || (al16(d.res) && d.res_bs % 4 == 0)) &&
@@ -1476,7 +1519,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // k = 7 through the straight-line instances (direct-form last tap, 10/14 of the direct MFMAs): +11..22 % at every dilation;
     // k = 11 likewise with an F(2,2) last group (15/22): another 6 %.
     const bool wino_pays = (h->MT & 1) ? (h->k >= 9 && h->dil == 1) : (h->dil == 1 || h->k >= 9 || h->wino_k7);
-    if (!h->math && h->wino_groups && (wino_pays || getenv("VS_WINO_FORCE")) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WINO")) {
+    if (!h->math && h->wino_groups && (wino_pays || opt(OPT_WINO_FORCE)) && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !opt(OPT_NO_WINO)) {
         ConvParams q = p;
         if (!h->wino_packed) {
             const size_t nw = (size_t)h->MT_alloc * h->nchunks * h->wino_groups * 2 * 16 * 64;
@@ -1492,7 +1535,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         q.wp = h->wpw.as<float>();
         q.KT = h->wino_groups;
         q.lo = -h->pad;
-        if (const char *e = getenv("VS_WINO_DBG")) q.dbg = atoi(e);
+        q.dbg = (int)opt(OPT_WINO_DBG);
         // the vector epilogue stores float4 (dilation 1) / float2 runs: same alignment preconditions as the direct engine's
         // (Tout % 4 == 0 checked above covers both)
         const int span_w = 3 * h->wino_groups * h->dil;
@@ -1506,10 +1549,10 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // Its three transformed arrays cost 4x the staging work of the direct kernel per 16-channel chunk (tools/wsplit_stamps.py:
     // 2.0 us of staging against 1.5 us of MFMAs at k = 3, 3.2 against 7.5 at k = 11), so k = 3 (4/6, x0.86 .. x0.98) and k = 7
     // (12/14 with the zero-padded last group, x0.90 .. x1.02) stay on the direct kernel.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B.
-    if (h->math == VS_MATH_SPLIT6 && h->wsplit && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !getenv("VS_NO_WSPLIT") &&
+    if (h->math == VS_MATH_SPLIT6 && h->wsplit && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !opt(OPT_NO_WSPLIT) &&
         ((ceil_div(p.N, 120) * p.B * (h->MT / 2) >= 512 &&              // (short launches: the small direct tiles)
           ((h->MT % 4) == 0 || h->dil == 1)) ||                         // (64-row workgroups: x1.12 at dilation 1, a tie at 3 / 5)
-         getenv("VS_WSPLIT_FORCE"))) {
+         opt(OPT_WSPLIT_FORCE))) {
         if (!h->wsplit_packed) {
             VS_TRY(h->wsw.reserve(wsplit_bytes(h->MT_alloc, h->nchunks, h->wino_groups)));
             VS_TRY(pack_wsplit(h->wp.as<float>(), h->wsw.p, h->KT, h->MT_alloc, h->nchunks, h->wino_groups, s));
@@ -1519,7 +1562,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         q.wp = h->wsw.as<float>();
         q.KT = h->wino_groups;
         q.lo = -h->pad;
-        if (const char *e = getenv("VS_WSPLIT_STAGGER")) q.dbg = atoi(e);
+        q.dbg = (int)opt(OPT_WSPLIT_STAGGER);
         return launch_wsplit(q, h->dil, h->wino_groups, s);
     }
     // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,
@@ -1533,16 +1576,16 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // the chip idle while each workgroup runs its full K loop -- the launch lasts as long as ONE workgroup.  On the bf16-pipe
     // engine take 64-row (then 32-row) tiles until the grid covers the CUs: the same kernel family, 2x / 4x the workgroups, each
     // with half / a quarter of the MFMAs per wave (B=1, T_mel=1024 synthesis latency: DESIGN.md 4.2).
-    if (h->math && !getenv("VS_NO_SMALL_GRID") && !p.x_bf16 && !p.y_bf16) {      // (bf16-resident tensors: the 128-row instance only)
+    if (h->math && !opt(OPT_NO_SMALL_GRID) && !p.x_bf16 && !p.y_bf16) {      // (bf16-resident tensors: the 128-row instance only)
         const long long ncol = ceil_div(p.N, 256) * p.B;
         if (cfg == 0 && ncol * ceil_div(h->MT, 4) < 256) cfg = 3;
         if (cfg == 3 && ncol * ceil_div(h->MT, 2) < 256 && (long long)p.N * p.B <= 65536) cfg = 2;
-        static const long long t6 = getenv("VS_SMALL_GRID_T6") ? atoll(getenv("VS_SMALL_GRID_T6")) : 512;
+        const long long t6 = opt(OPT_SMALL_GRID_T6);
         if (cfg == 2 && ncol * h->MT < t6 && h->kind != VS_CONV_TRANSPOSE1D) cfg = 6;     // 128-column tiles: twice the workgroups again
     }
-    if (const char *e = getenv("VS_CONV_CFG")) cfg = (h->MT >= 3) ? (atoi(e) == 3 ? 3 : (atoi(e) == 1 ? 1 : 0)) : cfg;   // A/B switch
+    if (opt(OPT_CONV_CFG) >= 0 && h->MT >= 3) cfg = (opt(OPT_CONV_CFG) == 3) ? 3 : (opt(OPT_CONV_CFG) == 1 ? 1 : 0);   // A/B switch
     if (h->math) p.wp = h->ws.as<float>();
-    if (h->math) { if (const char *e = getenv("VS_SPLIT_DBG")) p.dbg = atoi(e); }
+    if (h->math) p.dbg = (int)opt(OPT_SPLIT_DBG);
     auto launch = [&](const ConvParams &q) -> int {
         if (h->math) return launch_split(q, cfg, h->math, h->span, s);
         switch (cfg) {

@@ -371,8 +371,8 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     // six cross products per product -- fp32-class scores and outputs at 16/6 of the fp32 matrix rate; VS_MATH_F32: the kernel below
     // (key split: only the bf16-pipe kernels take it; the number of ranges is capped by the key tiles of the kernel, 32 keys each at least)
     if (work && ksplit > 1 && T / 64 >= ksplit) { p.part = work; p.ksplit = ksplit; }
-    if (math == VS_MATH_BF16 && attn_bf16_supported(p, 1) && !getenv("VS_NO_BF16_ATTN")) return launch_attn_bf16(p, 1, s);
-    if (math == VS_MATH_SPLIT6 && attn_bf16_supported(p, 6) && !getenv("VS_NO_SPLIT_ATTN")) return launch_attn_bf16(p, 6, s);
+    if (math == VS_MATH_BF16 && attn_bf16_supported(p, 1) && !opt(OPT_NO_BF16_ATTN)) return launch_attn_bf16(p, 1, s);
+    if (math == VS_MATH_SPLIT6 && attn_bf16_supported(p, 6) && !opt(OPT_NO_SPLIT_ATTN)) return launch_attn_bf16(p, 6, s);
     p.part = nullptr; p.ksplit = 0;
     const int DT = (int)ceil_div(k_channels, 32);
     switch (DT) {

@@ -16,6 +16,32 @@ void set_error(const char *fmt, ...);
 // rocprofv3 prints them) -- read back through vs_last_kernel_name() by the bench's per-launch attribution
 void set_last_kernel(const char *fmt, ...);
 
+// Dispatch switches (A/B and debug): ONE table, initialised from the environment variables of the same names when the library is
+// loaded and changed afterwards only through vs_set_option() -- no getenv on any launch path.  (INTEGRATION.md lists them.)
+enum Opt {
+    OPT_CONV_MATH,        // VS_CONV_MATH: arithmetic of conv handles created from now on (0 / 1 / 6), -1 = library default
+    OPT_NO_SMALL_CONV,    // VS_NO_SMALL_CONV: convs with <= 4 output channels on the MFMA tiles instead of the VALU kernel
+    OPT_NO_FAST_EPI,      // VS_NO_FAST_EPI: element-wise epilogue everywhere
+    OPT_WINO_FORCE,       // VS_WINO_FORCE: fp32 engine: F(2,3) on every eligible conv
+    OPT_NO_WINO,          // VS_NO_WINO: fp32 engine: never F(2,3)
+    OPT_NO_WINO_K7,       // VS_NO_WINO_K7: fp32 engine: no k-specialised F(2,3) instances (read at vs_conv_create)
+    OPT_WINO_DBG,         // VS_WINO_DBG: timing-only perturbations of conv_wino_kernel
+    OPT_NO_WSPLIT,        // VS_NO_WSPLIT: split engine: never F(2,3)
+    OPT_WSPLIT_FORCE,     // VS_WSPLIT_FORCE: split engine: F(2,3) on every eligible conv (eligibility is read at vs_conv_create)
+    OPT_WSPLIT_STAGGER,   // VS_WSPLIT_STAGGER: debug: late start of every other dispatch round
+    OPT_NO_SMALL_GRID,    // VS_NO_SMALL_GRID: keep the 128-row tile on launches that do not cover the chip
+    OPT_SMALL_GRID_T6,    // VS_SMALL_GRID_T6: workgroup count below which 32 x 128 tiles are taken (default 512)
+    OPT_CONV_CFG,         // VS_CONV_CFG: force a tile shape of the direct engine (-1 = automatic)
+    OPT_SPLIT_DBG,        // VS_SPLIT_DBG: timing-only perturbations of conv_split_kernel (-DVS_SPLIT_PERTURB builds)
+    OPT_TRACE,            // VS_TRACE: one line per conv launch on stderr
+    OPT_NO_BF16_ATTN,     // VS_NO_BF16_ATTN: VS_MATH_BF16 attention on the exact-fp32 kernel
+    OPT_NO_SPLIT_ATTN,    // VS_NO_SPLIT_ATTN: VS_MATH_SPLIT6 attention on the exact-fp32 kernel
+    OPT_NO_WGRAD_SPLIT,   // VS_NO_WGRAD_SPLIT: weight gradients on the exact-fp32 kernel only
+    OPT_NO_PERSIST,       // VS_NO_PERSIST: one column tile per workgroup in the split engine (no persistent tile loop)
+    OPT_COUNT
+};
+long long opt(Opt o);
+
 #define VS_CHECK_HIP(expr)                                                                             \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \

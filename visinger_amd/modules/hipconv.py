@@ -67,10 +67,7 @@ class _HipConvMixin:
         return self.run(x.contiguous().float())
 
     def __getstate__(self):                      # handles are process-local (forward, backward-data and discriminator caches)
-        st = self.__dict__.copy()
-        for key in ("_hip_ops", "_hip_bwd_ops", "_hip_disc_ops"):
-            st.pop(key, None)
-        return st
+        return drop_process_local_state(self.__dict__.copy())
 
 
 class HipConv1d(_HipConvMixin, nn.Conv1d):
@@ -117,7 +114,21 @@ def repack_weights(module):
         for key in ("_hip_ops", "_hip_bwd_ops", "_hip_disc_ops"):
             for op in m.__dict__.get(key, {}).values():
                 op.invalidate()
+        for key in DERIVED_CACHES:      # caches keyed on (data_ptr, _version) of SEVERAL parameters: rebuilt from the live ones
+            m.__dict__.pop(key, None)
     return module
+
+
+# per-module caches derived from more than one parameter (MultiHeadAttention: the fused q | k | v projection of the inference path,
+# its training twin): dropped by repack_weights and never pickled
+DERIVED_CACHES = ("_hip_qkv_inf", "_hip_qkv")
+
+
+def drop_process_local_state(state):
+    """__getstate__ helper: remove conv handles and derived caches (device copies, ctypes handles) from a module's __dict__ copy"""
+    for key in ("_hip_ops", "_hip_bwd_ops", "_hip_disc_ops") + DERIVED_CACHES:
+        state.pop(key, None)
+    return state
 
 
 def mask2d(x_mask, B, T):

@@ -17,7 +17,7 @@ from torch import nn
 from .. import _lib as L
 from .. import autograd
 from ..ops import ConvOp, layernorm_c, rel_attention, _off
-from .hipconv import HipConv1d, mask2d, _forward_only_guard
+from .hipconv import HipConv1d, mask2d, _forward_only_guard, drop_process_local_state
 
 
 class LayerNorm(nn.Module):
@@ -112,6 +112,9 @@ class MultiHeadAttention(nn.Module):
             self.conv_k.bias.data.copy_(self.conv_q.bias.data)
         nn.init.xavier_uniform_(self.conv_v.weight)
 
+    def __getstate__(self):      # the fused q | k | v handle and its concatenated device copies are process-local caches
+        return drop_process_local_state(self.__dict__.copy())
+
     def _fused_qkv_op(self):
         """One conv handle for conv_q | conv_k | conv_v (three nn.Conv1d(channels, channels, 1) of the same input in self-attention,
         rel_transformer.py:120-122, 141-143): the weights are concatenated and packed once per version of the six parameters."""
@@ -161,7 +164,7 @@ class MultiHeadAttention(nn.Module):
         c = x if c is x else c.contiguous().float()
         qkv = torch.empty((B, 3 * C, T), device=x.device, dtype=torch.float32)
         ia = L.IN_MASK if in_mask else L.IN_NONE
-        fused = self._fused_qkv_op() if (c is x and not os.environ.get("VS_NO_FUSED_QKV")) else None
+        fused = self._fused_qkv_op() if (c is x and not L.switch("VS_NO_FUSED_QKV")) else None
         if fused is not None:
             fused.forward(x, in_act=ia, mask=m2, y=qkv)       # q | k | v: ONE [3C, C] projection of the same x (rows are independent: same sums)
         else:

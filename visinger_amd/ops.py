@@ -246,10 +246,10 @@ def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=N
     # keys over several workgroups and merge the partial rows in a second kernel (vs_relattn_fwd_ksplit)
     nwg = B * n_heads * -(-T // 128)
     ksplit = 1
-    if ksplit_auto and nwg < 128 and T >= 256 and not os.environ.get("VS_NO_ATTN_KSPLIT"):
+    if ksplit_auto and nwg < 128 and T >= 256 and not L.switch("VS_NO_ATTN_KSPLIT"):
         ksplit = max(1, min(8, 256 // nwg, T // 128))
-        if os.environ.get("VS_ATTN_KSPLIT"):
-            ksplit = max(1, min(16, int(os.environ["VS_ATTN_KSPLIT"]), T // 64))
+        if L.switch("VS_ATTN_KSPLIT"):
+            ksplit = max(1, min(16, L.switch("VS_ATTN_KSPLIT"), T // 64))
     work = None
     if ksplit > 1:
         R = 0 if rel_k is None else rel_k.shape[1]
@@ -341,11 +341,13 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
     gy, x = gy.contiguous().float(), x.contiguous().float()
     B, Cout, Tout = gy.shape
     Cin, Tin = x.shape[1], x.shape[2]
-    if k == 1 and pad == 0 and Tin == Tout and Cout * Cin >= 64 * 64 and not os.environ.get("VS_NO_WGRAD_GEMM"):
+    if k == 1 and pad == 0 and Tin == Tout and Cout * Cin >= 64 * 64 and not L.switch("VS_NO_WGRAD_GEMM"):
         # a 1x1 conv's weight gradient is a plain GEMM [Cout x B*T] . [B*T x Cin]: library territory (hipBLASLt through torch, as the
         # wide discriminator layers already do); vs_conv_wgrad's 32 x 32 tiles with the positions split over the waves ran it at
         # 7-9 TFLOP/s (tools/wgrad_breakdown.py: 94 calls, 11.8 ms of the config-3 step)
         return torch.einsum("bot,bit->oi", gy, x).unsqueeze(2)
+    if gy.data_ptr() % 16:       # (an offset view that is contiguous: the split kernel loads float4 rows of gy)
+        gy = gy.clone()
     planes = lib.vs_conv_wgrad_planes(B, Cout, Cin, Tout, int(k))
     part = torch.empty((planes, Cout, Cin, k), device=x.device, dtype=torch.float32)
     L.check(lib.vs_conv_wgrad(L.ptr(gy), L.ptr(x), L.ptr(part), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad), L.stream_ptr()))
@@ -393,11 +395,11 @@ def respair_supported(op1, op2, profitable_only=False):
     faster than the two launches.  fp32 MFMA arithmetic (tools/pair_bench.py with VS_CONV_MATH=0): at 32 channels x1.32-1.47 for k=3, x1.14 for
     k=7, a tie for k=11 (the F(2,3) kernel wins at dilation 1); at 64 channels only the dilated k=3 pairs (x1.06): from k=7 on
     the separate F(2,3) launches do 30 % less matrix work than the fused direct form."""
-    if os.environ.get("VS_NO_RESPAIR") or not op1.lib.vs_respair_supported(op1.h, op2.h):
+    if L.switch("VS_NO_RESPAIR") or not op1.lib.vs_respair_supported(op1.h, op2.h):
         return False
     if op1.math != op2.math:
         return False
-    if not profitable_only or os.environ.get("VS_RESPAIR_FORCE"):
+    if not profitable_only or L.switch("VS_RESPAIR_FORCE"):
         return True
     C, k, d = op1.c_in, op1.k, op1.dil
     if op1.math == L.MATH_BF16:

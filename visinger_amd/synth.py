@@ -60,7 +60,14 @@ class GraphedStep:
     allocates with hipMalloc or synchronises with the host after the warm-up, so the ~700 launches of a step replay as one graph
     (tests/test_model_gpu.py::test_synthesis_step_is_graph_capturable).  Inputs are copied into the graph's static buffers."""
 
+    @staticmethod
+    def fingerprint(model):
+        """(data_ptr, in-place version) of every parameter: changes with optimizer steps, load_state_dict and copy_ (not with edits
+        through `.data`, like the packed-weight caches: call hipconv.repack_weights AND drop the graphs after such an edit)"""
+        return tuple((p.data_ptr(), p._version) for p in model.parameters())
+
     def __init__(self, model, batch, noise, mask_decoder):
+        self.weights = self.fingerprint(model)       # a replay never re-folds / re-packs weights: the graph is only valid for these
         self.static = {k: v.clone() for k, v in batch.items()}
         self.noise = noise.clone()
 
@@ -83,7 +90,7 @@ class GraphedStep:
             self.static[k].copy_(v)
         self.noise.copy_(noise)
         self.graph.replay()
-        return self.out
+        return self.out          # the graph's STATIC output buffer: the next replay overwrites it (clone to keep it)
 
 
 @torch.no_grad()
@@ -116,7 +123,7 @@ def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1
         ragged = len({lengths[i] for i in idx}) > 1
         if graphs is not None:
             key = (B, batch["text_tokens"].shape[1], T, ragged)
-            if key not in graphs:
+            if key not in graphs or graphs[key].weights != GraphedStep.fingerprint(model):      # (re-captured after a weight update)
                 graphs[key] = GraphedStep(model, batch, noise, ragged)
             wav = graphs[key](batch, noise).float().cpu().numpy()
         else:
