@@ -101,11 +101,14 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(model, hp, budget_s=12.0, backend="c"):
-    """The CPU oracle (fp32 'port' of the reference arithmetic, oracle/) timed on a bounded sample of the SAME
-    workload (same weights, same synthetic input recipe): B=1, T_mel sized from a T_mel=32 probe to ~budget_s.
-    backend "c": the C/OpenMP restatement; "torch": the same composition with the convolutions (98 % of the CPU time) on
-    stock PyTorch CPU kernels with torch.set_num_threads(all cores) -- the reference's own CPU execution engine."""
+def cpu_baseline(model, hp, batch, backend="c", wav_dev=None, f0_dev=None, T_cap=1024):
+    """The CPU oracle (fp32 'port' of the reference arithmetic, oracle/) timed on a bounded sample of the SAME workload and the
+    SAME graph as `value` (same weights, pitch predictor on): ITEM 0 of the timed batch (B=1 of the 32, T_mel as timed, capped at
+    T_cap).  backend "c": the C/OpenMP restatement; "torch": the same composition with the convolutions (98 % of the CPU time) on stock
+    PyTorch CPU kernels with torch.set_num_threads(all cores) -- the reference's own CPU execution engine.
+    With wav_dev (the device's waveforms of the timed batch) the oracle's item is also the checker of the timed run:
+    `waveform_max_abs_err` = max |device - fp32 oracle| over item 0 (frames whose voicing logit the oracle puts within 1e-3 of the
+    threshold take the device's decision: `voicing_hinted_frames`)."""
     from oracle import visinger_oracle as orc
     orc.build()
     orc.CONV_BACKEND = backend
@@ -115,25 +118,49 @@ def cpu_baseline(model, hp, budget_s=12.0, backend="c"):
         cores = min(cores, 32)      # oneDNN on a B=1 conv does not scale past a few dozen threads (and thrashes at 256)
         torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    hpo = dict(hp, use_pitch_embed=False)   # the runnable reference configuration
-
-    def run(T):
-        text, pitch, dur, mel2ph, spk, noise = [t.numpy() for t in synthetic_batch(1, T, max(1, T // 8), 64, 1234, "cpu")]
-        t0 = time.perf_counter()
-        wav = orc.visinger_infer(sd, hpo, text, pitch, dur, mel2ph, spk, noise, dtype=np.float32)
-        return wav.size, time.perf_counter() - t0
-
-    T = 32
-    n, dt = run(T)
-    T2 = int(min(1024, 32 * max(1, 2 ** int(np.log2(max(1.0, budget_s / max(dt, 1e-3)))))))   # <= the workload's T_mel (attention is O(T^2))
-    if T2 > T:
-        T = T2
-        n, dt = run(T)
+    text, pitch, dur, mel2ph, spk, noise = [t[:1].cpu().numpy() for t in batch]
+    T = min(int(mel2ph.shape[1]), T_cap)
+    assert T == mel2ph.shape[1], "the baseline runs whole items of the timed batch"
+    hint = None if f0_dev is None else (f0_dev[:1, :, 1] <= 0).cpu().numpy()
+    t0 = time.perf_counter()
+    out = orc.visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk, noise, dtype=np.float32, return_all=True, voiced_hint=hint,
+                             hint_tol=1e-3 if hint is not None else 0.0)
+    dt = time.perf_counter() - t0
     orc.CONV_BACKEND = "c"
+    n = out["wav_out"].size
     what = "C+numpy port (OpenMP" if backend == "c" else "numpy composition with torch-CPU oneDNN convolutions (torch threads"
-    return {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ fp32 {what}, {cores} threads), B=1 T_mel={T} hop={HOP}: {n} samples in "
-                      f"{dt:.2f}s; text-encoder + frame-prior + flow-inverse + generator"}
+    res = {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/ fp32 {what}, {cores} threads), item 0 of the timed batch: B=1 T_mel={T} hop={HOP}: {n} samples in {dt:.2f}s; the "
+                     f"graph `value` times (text-encoder + pitch-predictor + frame-prior + flow-inverse + generator, use_pitch_embed="
+                     f"{bool(hp.get('use_pitch_embed'))})"}
+    if wav_dev is not None:
+        res["waveform_max_abs_err"] = float(np.abs(wav_dev[0].double().cpu().numpy() - out["wav_out"][0]).max())
+        res["waveform_tolerance"] = 1e-4
+        if out["f0_pred"] is not None:
+            res["voicing_hinted_frames"] = int((np.abs(out["f0_pred"][:, :, 1]) <= 1e-3).sum())
+    return res
+
+
+def cpu_baseline_config2(model, hp, batch, items=2):
+    """BASELINE.md 4 asks for the config-2 shape next to the GPU number: flow inverse + HiFi-GAN decode at T_mel=512, a bounded sample of
+    `items` of the 8 utterances, on the fp32 C/OpenMP port."""
+    from oracle import visinger_oracle as orc
+    orc.build()
+    cores = usable_cores()
+    orc.set_threads(cores)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    z_p, fmask, spk = [t[:items].cpu().numpy() for t in batch]
+    g = sd["spk_id_proj.weight"][spk][:, :, None]
+    t0 = time.perf_counter()
+    z_q = orc.flow_block(orc._sub(sd, "flow"), z_p, fmask, g, reverse=True, channels=z_p.shape[1], hidden_channels=z_p.shape[1], kernel_size=5,
+                         dilation_rate=1, n_layers=4, dtype=np.float32) * fmask
+    wav = orc.generator(orc._sub(sd, "decoder"), z_q, g, resblock=hp["dec_blocks"], resblock_kernel_sizes=hp["dec_kernel_size"],
+                        resblock_dilation_sizes=hp["dec_dilation_sizes"], upsample_rates=hp["upsample_rates"],
+                        upsample_kernel_sizes=hp["upsample_kernel_sizes"], dtype=np.float32)[:, 0]
+    dt = time.perf_counter() - t0
+    return {"value": wav.size / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ fp32 C+numpy port (OpenMP, {cores} threads), {items} of the 8 items of BASELINE config 2 (flow inverse + "
+                      f"HiFi-GAN decode, T_mel={z_p.shape[2]}): {wav.size} samples in {dt:.2f}s"}, wav
 
 
 def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
@@ -282,6 +309,7 @@ def parse_args():
     ap.add_argument("--dropout", type=float, default=0.1, help="config 3: p_dropout of the transformers (reference config: 0.1)")
     ap.add_argument("--storage", default=None, choices=("f32", "bf16"),
                     help="element type of the generator's activations in HBM (bf16 only with --math bf16; default: bf16 for --config 5)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the reduced lines of BASELINE configs 2 / 3 / 5")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (no GPU work): every rank joins the process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -347,6 +375,163 @@ def percentile_stats(ms):
     return {"median_ms": float(np.median(a)), "min_ms": float(a[0]), "max_ms": float(a[-1])}
 
 
+def roofline_from_profile(prof, dt, steps):
+    """`roofline` object of a bench line from the per-launch HIP-event records of the timed steps (ops.PROFILER.summary()): the dominant
+    kernel instance (largest share of the step), its algorithmic FLOP/s against the roof of its arithmetic, and the whole step."""
+    name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12            # ALGORITHMIC: the convs' own 2*MAC / measured kernel time
+    step_flops = sum(v["flops"] for v in prof.values()) / steps
+    step_bytes = sum(v["bytes"] for v in prof.values()) / steps
+    step_tflops = step_flops / (dt / steps) / 1e12
+    kern_ms = sum(v["ms"] for v in prof.values())
+    if name.startswith(("conv_split_kernel", "respair_split_kernel", "resblock_split_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
+        targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
+        ints = [int(a) for a in targs if a.isdigit()]
+        if name.startswith("conv_split_kernel"):
+            terms = ints[4]                                  # cross products per fp32 product (5th template argument)
+        elif name.startswith("conv_wsplit_kernel"):
+            terms = 6
+        else:
+            terms = ints[-1] if ints[-1] in (1, 3, 6) else ints[-2]
+        peak = BF16_MFMA_PEAK_TFLOPS / terms
+        peak_name = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
+                     f"this arithmetic for fp32-class results" if terms > 1 else "dense bf16 MFMA peak")
+        roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_name": peak_name, "frac_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "executed_tflops": achieved * terms, "frac_executed": achieved * terms / BF16_MFMA_PEAK_TFLOPS,
+                "frac_executed_of_measured_mfma_ceiling": achieved * terms / 1570.0,
+                "note": f"achieved = ALGORITHMIC FLOPs (the convs' own 2*MAC, SURVEY 8d) / HIP-event time of the kernel's launches; the "
+                        f"matrix pipe executes {terms} bf16 MFMA FLOPs per algorithmic FLOP (executed_tflops, frac_executed vs the 2500 "
+                        "dense peak; mfma_executed = the same from rocprofv3's MFMA counters).  Under this load the chip clocks at "
+                        "1.6-1.85 GHz: a bare loop of this MFMA sustains 1.57 PFLOP/s at 1.67 GHz on this box "
+                        "(tools/ubench/mfma_bf16_rate.hip) = the denominator of frac_executed_of_measured_mfma_ceiling"}
+    else:
+        roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "peak_name": "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+                "note": "achieved = ALGORITHMIC (direct-form) FLOPs / time; the F(2,3) minimal-filtering instances execute "
+                        "4/6 (k=3, 9), 10/14 (k=7), 15/22 (k=11) of them on the matrix pipe, so achieved can exceed the MFMA "
+                        "peak: mfma_executed is what the pipe really did"}
+    step_peak = roof["peak"]
+    roof.update({
+        "traffic": (pmc_traffic(name) or {}).get("bytes_per_launch"),
+        "traffic_source": (pmc_traffic(name) or {}).get("source"),
+        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+        "hbm_gbps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9, "hbm_frac_of_8tbps": d["bytes"] / (d["ms"] * 1e-3) / 8e12,
+        "mfma_executed": pmc_mfma_executed(name),
+        "launches_per_step": d["launches"] / steps,
+        "avg_launch_ms": d["ms"] / d["launches"],
+        "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+        "share_of_step": d["ms"] / (dt * 1e3),
+        "step": {"algorithmic_tflop_per_step": step_flops / 1e12, "achieved": step_tflops, "peak": step_peak, "unit": "TFLOP/s",
+                 "frac": step_tflops / step_peak, "frac_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+                 "frac_of_bf16_peak": step_tflops / BF16_MFMA_PEAK_TFLOPS,
+                 "algorithmic_gb_per_step": step_bytes / 1e9, "hbm_gbps_algorithmic": step_bytes / (dt / steps) / 1e9,
+                 "hbm_frac_of_8tbps": step_bytes / (dt / steps) / 8e12,
+                 "note": "whole step: the conv + attention launches' algorithmic FLOPs (2*MAC) and algorithmic HBM bytes (every launch's "
+                         "input once, residual / accumulate inputs once, output once) / wall time of the step"},
+        "all_instances": {k: {"ms_per_step": v["ms"] / steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                              "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
+                              "launches_per_step": v["launches"] / steps}
+                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+        "timed_kernels_share_of_step": kern_ms / (dt * 1e3)})
+    return roof
+
+
+class InferenceWorkload:
+    """One inference configuration of BASELINE.json (headline / 2 / 4 / 5): model, resident inputs, step()."""
+
+    def __init__(self, config, B, T, hidden, math, storage, hop, ragged, dev, rank=0, world=1):
+        from visinger_amd import _lib as L
+        from visinger_amd.dp import shard_batch
+        self.config, self.B, self.T, self.hidden, self.math, self.storage, self.hop = config, B, T, hidden, math, storage, hop
+        L.set_option("VS_CONV_MATH", MATH[math])      # arithmetic of every conv handle created from here on (vs_conv_create)
+        self.model, self.hp = build_model(hop=hop, hidden=hidden)
+        self.model = self.model.to(dev)
+        if storage == "bf16":
+            from visinger_amd.modules.hipconv import set_activation_storage
+            set_activation_storage(self.model, torch.bfloat16)
+        # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
+        gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", ragged=ragged, hidden=hidden)
+        self.batch = [t.to(dev) for t in shard_batch(gb, rank, world)]
+        text, pitch, dur, mel2ph, spk, noise = self.batch
+        model = self.model
+        if config == 2:      # flow inverse + generator only (BASELINE configs[1]); inputs: a prior sample z_p, the mask, the speaker
+            with torch.no_grad():
+                fmask = (mel2ph > 0).float().unsqueeze(1)
+                g = model.speaker_embedding(None, spk).transpose(1, 2).contiguous()
+                z_p = (noise * fmask).contiguous()
+            self.c2_inputs = (z_p, fmask, spk)
+
+            def step():
+                with torch.no_grad():
+                    z_q = model.flow(z_p, fmask, g=g, reverse=True) * fmask
+                    return {"wav_out": model.decoder(z_q, g=g).squeeze(1)}
+        else:
+            def step():
+                with torch.no_grad():
+                    return model(text, pitch, dur, mel2ph, spk_id=spk, infer=True, noise=noise)
+        self.step = step
+
+    def dtype_name(self):
+        if self.storage == "bf16":
+            return "bf16 operands, f32 accumulate (bf16-resident activations between the generator's convs, f32 tensors elsewhere)"
+        return DTYPE[self.math]
+
+    def describe(self, world=1):
+        what = ("VISinger synthesis (text-enc + pitch-pred + frame-prior + flow-inverse + HiFi-GAN), " if self.config != 2
+                else "VISinger flow inverse + HiFi-GAN decode (BASELINE config 2), ")
+        return {"workload": what + f"B={self.B}/GPU T_mel={self.T} hop={self.hop} hidden={self.hidden} " +
+                            ("fp32 tensors" if self.storage == "f32" else "bf16-resident generator activations") + ", random-init weights",
+                "baseline_config": self.config or "headline (north_star: B=32, T_mel=1024, hop 256)",
+                "per_gpu_batch": self.B, "global_batch": self.B * world, "t_mel": self.T, "hop": self.hop, "hidden": self.hidden,
+                "parallelism": f"dp{world} (utterance shard, no collective)"}
+
+
+def timed_run(step, steps, warmup, profile, barrier):
+    from visinger_amd.ops import PROFILER
+    for _ in range(warmup):
+        out = step()
+    barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if profile:
+        PROFILER.start()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        out = step()
+        marks[i + 1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if profile:
+        PROFILER.stop()
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    return out, dt, per_step
+
+
+def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
+    """A reduced bench line for BASELINE config 2 / 3 / 5 inside the default run: same timing discipline as the
+    headline (warm-up, barrier + synchronize on both sides, HIP events per launch for the roofline), fewer steps."""
+    from visinger_amd.ops import PROFILER
+    preset = CONFIGS[config]
+    if config == 3:
+        return train_line(preset["batch"], preset["frames"], 0.1, "split6", steps, warmup, 0, 1, None, dev, barrier)
+    math = "bf16" if preset.get("math") == "bf16" else "split6"
+    wl = InferenceWorkload(config, preset["batch"], preset["frames"], preset.get("hidden", 192), math, "bf16" if config == 5 else "f32", 256, False, dev)
+    out, dt, per_step = timed_run(wl.step, steps, warmup, True, barrier)
+    wav = out["wav_out"]
+    assert wav.shape == (wl.B, wl.T * 256) and bool(torch.isfinite(wav).all())
+    samples = wl.B * wl.T * 256 * steps
+    line = {"metric": "audio samples/sec (22.05 kHz)", "value": samples / dt, "unit": "audio samples/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "ms_per_step_stats": percentile_stats(per_step), "dtype": wl.dtype_name(), "data": "synthetic",
+            "config": dict(wl.describe(), realtime_factor=samples / dt / SR, what=preset["what"]),
+            "roofline": roofline_from_profile(PROFILER.summary(), dt, steps)}
+    if config == 2 and with_cpu:
+        line["cpu_baseline"], wav_cpu = cpu_baseline_config2(wl.model, wl.hp, wl.c2_inputs)
+        line["cpu_baseline"]["waveform_max_abs_err"] = float(np.abs(wav[:wav_cpu.shape[0]].double().cpu().numpy() - wav_cpu).max())
+        line["cpu_baseline"]["waveform_tolerance"] = 1e-4
+    return line
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,10 +545,8 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    from visinger_amd import _lib as L
     from visinger_amd.ops import PROFILER
-    L.set_option("VS_CONV_MATH", MATH[args.math])      # arithmetic of every conv handle created from here on (vs_conv_create)
-    from visinger_amd.dp import shard_batch, max_over_ranks
+    from visinger_amd.dp import max_over_ranks
     global HOP, SR
     HOP, SR = args.hop, (22050 if args.hop == 256 else 24000)
     B, T = args.batch, args.frames
@@ -375,106 +558,23 @@ def main():
         torch.cuda.synchronize()
 
     if args.config == 3:
-        return train_bench(args, rank, world, dist, dev, barrier)
+        line = train_line(B, T, args.dropout, args.math, args.steps, args.warmup, rank, world, dist, dev, barrier)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    model, hp = build_model(hop=args.hop, hidden=args.hidden)
-    model = model.to(dev)
-    if args.storage == "bf16":
-        from visinger_amd.modules.hipconv import set_activation_storage
-        set_activation_storage(model, torch.bfloat16)
-    # global batch of B*world utterances, strided shard per rank (tasks/base.py:130-133)
-    gb = synthetic_batch(B * world, T, T // 8, 64, 1234, "cpu", ragged=args.ragged, hidden=args.hidden)
-    text, pitch, dur, mel2ph, spk, noise = [t.to(dev) for t in shard_batch(gb, rank, world)]
-
-    if args.config == 2:      # flow inverse + generator only (BASELINE configs[1]); inputs: a prior sample z_p, the mask, the speaker
-        with torch.no_grad():
-            fmask = (mel2ph > 0).float().unsqueeze(1)
-            g = model.speaker_embedding(None, spk).transpose(1, 2).contiguous()
-            z_p = (noise * fmask).contiguous()
-
-        def step():
-            with torch.no_grad():
-                z_q = model.flow(z_p, fmask, g=g, reverse=True) * fmask
-                return model.decoder(z_q, g=g).squeeze(1)
-    else:
-        def step():
-            with torch.no_grad():
-                return model(text, pitch, dur, mel2ph, spk_id=spk, infer=True, noise=noise)["wav_out"]
-
-    def timed_run(steps, warmup, profile):
-        for _ in range(warmup):
-            wav = step()
-        barrier()
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        if profile:
-            PROFILER.start()
-        t0 = time.perf_counter()
-        marks[0].record()
-        for i in range(steps):
-            wav = step()
-            marks[i + 1].record()
-        barrier()
-        dt = time.perf_counter() - t0
-        if profile:
-            PROFILER.stop()
-        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-        return wav, dt, per_step
-
-    wav, dt, per_step = timed_run(args.steps, args.warmup, True)
+    wl = InferenceWorkload(args.config, B, T, args.hidden, args.math, args.storage, args.hop, args.ragged, dev, rank, world)
+    model, hp = wl.model, wl.hp
+    out_dev, dt, per_step = timed_run(wl.step, args.steps, args.warmup, True, barrier)
+    wav = out_dev["wav_out"]
     assert wav.shape == (B, T * HOP) and bool(torch.isfinite(wav).all())
     dt = max_over_ranks(dt, device=dev if backend == "nccl" else None)
     samples = B * world * T * HOP * args.steps
 
     if rank == 0:
-        prof = PROFILER.summary()
-        name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12            # ALGORITHMIC: the convs' own 2*MAC / measured kernel time
-        step_flops = sum(v["flops"] for v in prof.values()) / args.steps
-        step_tflops = step_flops / (dt / args.steps) / 1e12
-        kern_ms = sum(v["ms"] for v in prof.values())
-        if name.startswith(("conv_split_kernel", "respair_split_kernel")):
-            targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
-            ints = [int(a) for a in targs if a.isdigit()]
-            terms = ints[4] if name.startswith("conv_split_kernel") else ints[-1]     # cross products per fp32 product (5th / last template argument)
-            peak = BF16_MFMA_PEAK_TFLOPS / terms
-            peak_name = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
-                         f"this arithmetic for fp32-class results" if terms > 1 else "dense bf16 MFMA peak")
-            roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "peak_name": peak_name, "frac_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                    "executed_tflops": achieved * terms, "frac_executed": achieved * terms / BF16_MFMA_PEAK_TFLOPS,
-                    "frac_executed_of_measured_mfma_ceiling": achieved * terms / 1570.0,
-                    "note": f"achieved = ALGORITHMIC FLOPs (the convs' own 2*MAC, SURVEY 8d) / HIP-event time of the kernel's launches; the "
-                            f"matrix pipe executes {terms} bf16 MFMA FLOPs per algorithmic FLOP (executed_tflops, frac_executed vs the 2500 "
-                            "dense peak; mfma_executed = the same from rocprofv3's MFMA counters).  Under this load the chip clocks at "
-                            "1.6-1.85 GHz: a bare loop of this MFMA sustains 1.57 PFLOP/s at 1.67 GHz on this box "
-                            "(tools/ubench/mfma_bf16_rate.hip) = the denominator of frac_executed_of_measured_mfma_ceiling"}
-        else:
-            roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "peak_name": "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
-                    "note": "achieved = ALGORITHMIC (direct-form) FLOPs / time; the F(2,3) minimal-filtering instances execute "
-                            "4/6 (k=3, 9), 10/14 (k=7), 15/22 (k=11) of them on the matrix pipe, so achieved can exceed the MFMA "
-                            "peak: mfma_executed is what the pipe really did"}
-        step_peak = roof["peak"]
-        roof.update({
-            "traffic": (pmc_traffic(name) or {}).get("bytes_per_launch"),
-            "traffic_source": (pmc_traffic(name) or {}).get("source"),
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-            "hbm_gbps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9, "hbm_frac_of_8tbps": d["bytes"] / (d["ms"] * 1e-3) / 8e12,
-            "mfma_executed": pmc_mfma_executed(name),
-            "launches_per_step": d["launches"] / args.steps,
-            "avg_launch_ms": d["ms"] / d["launches"],
-            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-            "share_of_step": d["ms"] / (dt * 1e3),
-            "step": {"algorithmic_tflop_per_step": step_flops / 1e12, "achieved": step_tflops, "peak": step_peak, "unit": "TFLOP/s",
-                     "frac": step_tflops / step_peak, "frac_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
-                     "note": "whole step: the conv + attention launches' algorithmic FLOPs (2*MAC) / wall time of the step"},
-            "all_instances": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
-                                  "hbm_gbps_algorithmic": v["bytes"] / (v["ms"] * 1e-3) / 1e9,
-                                  "launches_per_step": v["launches"] / args.steps}
-                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
-            "timed_kernels_share_of_step": kern_ms / (dt * 1e3)})
-        workload = (f"VISinger synthesis (text-enc + pitch-pred + frame-prior + flow-inverse + HiFi-GAN), "
-                    if args.config != 2 else "VISinger flow inverse + HiFi-GAN decode (BASELINE config 2), ")
         out = {
             "metric": "audio samples/sec (22.05 kHz) + flow log-det rel-err, B=32 T_mel=1024",
             "value": samples / dt,
@@ -487,74 +587,99 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": DTYPE[args.math] if args.storage == "f32" else "bf16 operands, f32 accumulate (bf16-resident activations between the generator's convs, f32 tensors elsewhere)",
+            "dtype": wl.dtype_name(),
             "data": "synthetic",
-            "config": {"workload": workload + f"B={B}/GPU T_mel={T} hop={HOP} hidden={args.hidden} " + ("fp32 tensors" if args.storage == "f32" else "bf16-resident generator activations") + ", random-init weights",
-                       "baseline_config": args.config or "headline (north_star: B=32, T_mel=1024, hop 256)",
-                       "per_gpu_batch": B, "global_batch": B * world, "t_mel": T, "hop": HOP, "hidden": args.hidden,
-                       "parallelism": f"dp{world} (utterance shard, no collective)",
-                       "realtime_factor": samples / dt / SR},
-            "roofline": roof,
+            "config": dict(wl.describe(world), realtime_factor=samples / dt / SR),
+            "roofline": roofline_from_profile(PROFILER.summary(), dt, args.steps),
         }
+        headline = world == 1 and not args.no_cpu_baseline and args.config in (0, 4)
+        if headline:
+            # the CPU oracle on item 0 of the timed batch, the same graph: the reported baseline AND the checker of the timed run
+            out["cpu_baseline"] = cpu_baseline(model, hp, wl.batch, wav_dev=wav, f0_dev=out_dev.get("f0_pred"))
+            out["waveform_max_abs_err"] = out["cpu_baseline"]["waveform_max_abs_err"]
+            out["cpu_baseline_torch"] = cpu_baseline(model, hp, wl.batch, backend="torch")
+            out["flow_logdet"] = flow_logdet_check(model, dev)
+            out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
         if world == 1 and args.math == "split6" and not args.no_cpu_baseline:
             # the same workload on the exact-fp32 MFMA / F(2,3) kernels, same process, same weights, same --steps / --warmup: the
             # number to hold the split-bf16 arithmetic against (error against fp64: DESIGN.md 4, tests/test_conv_split_gpu.py)
             from visinger_amd.modules.hipconv import set_conv_math
             set_conv_math(model, MATH["f32"])
-            wav32, dt32, per32 = timed_run(args.steps, args.warmup, False)
+            o32, dt32, per32 = timed_run(wl.step, args.steps, args.warmup, False, barrier)
             set_conv_math(model, MATH["split6"])
             out["fp32_mfma_engine"] = {"value": B * T * HOP * args.steps / dt32, "unit": "audio samples/s", "ms_per_step": dt32 / args.steps * 1e3,
                                        "ms_per_step_stats": percentile_stats(per32), "steps": args.steps, "warmup": args.warmup,
-                                       "max_abs_waveform_diff_vs_value_run": float((wav32 - wav).abs().max()),
+                                       "max_abs_waveform_diff_vs_value_run": float((o32["wav_out"] - wav).abs().max()),
                                        "note": "bench.py --math f32: v_mfma_f32_32x32x2_f32 + Winograd F(2,3) kernels, no bf16 anywhere"}
-        if world == 1 and not args.no_cpu_baseline and args.config in (0, 4):
-            out["cpu_baseline"] = cpu_baseline(model, hp)
-            out["cpu_baseline_torch"] = cpu_baseline(model, hp, backend="torch")
-            out["flow_logdet"] = flow_logdet_check(model, dev)
-            out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
+        if headline and not args.no_other_configs:
+            # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each after 3 warm-up steps)
+            del wl, model, out_dev, wav
+            torch.cuda.empty_cache()
+            out["other_configs"] = {}
+            for c in (2, 3, 5):
+                out["other_configs"][str(c)] = other_config_line(c, dev, 10, 3, barrier)
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def train_bench(args, rank, world, dist, dev, barrier):
+def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barrier):
     """BASELINE config 3: one full GAN training step (generator pass + discriminator pass, both optimizers; under N > 1 ranks the
-    stock DistributedDataParallel gradient all-reduce over RCCL) on synthetic B=16, T_mel=512, segment 32 frames, hop 256."""
+    stock DistributedDataParallel gradient all-reduce over RCCL) on synthetic B=16, T_mel=512, segment 32 frames, hop 256.
+    -> the bench line (dict).  `roofline.step`: algorithmic FLOPs of one step -- every conv / attention launch of the forward, the
+    grad-input launches and the weight-gradient launches, counted by ops.PROFILER in counting mode on one extra un-timed step (no
+    events: 6 000 launches per step) -- over the measured step time."""
+    from visinger_amd import _lib as L
     from visinger_amd.dp import max_over_ranks
     from visinger_amd.models.visinger import hop256_hparams
+    from visinger_amd.ops import PROFILER
     from visinger_amd.train import VISingerTrainer, synthetic_train_batch
-    B, T = args.batch, args.frames
-    hp = hop256_hparams(p_dropout=args.dropout)        # the reference trains with p_dropout 0.1 (config/models/visinger.yaml:9)
+    L.set_option("VS_CONV_MATH", MATH[math])
+    hp = hop256_hparams(p_dropout=dropout)        # the reference trains with p_dropout 0.1 (config/models/visinger.yaml:9)
     torch.manual_seed(1234)
     tr = VISingerTrainer(64, 117, 131, hp).to(dev).configure().train()
     runner = tr
     if dist is not None:
         runner = torch.nn.parallel.DistributedDataParallel(tr, device_ids=[dev.index], find_unused_parameters=True)
     batch = synthetic_train_batch(B, T, T // 8, tr.hop, 64, hp["num_linear_bins"], 1234 + rank, dev)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         tr.training_step(batch, runner=runner)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         logs = tr.training_step(batch, runner=runner)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, device=dev if dist is not None else None)
-    if rank == 0:
-        assert all(np.isfinite(v) for v in logs.values()), logs
-        print(json.dumps({
-            "metric": "GAN training steps/sec (BASELINE config 3: posterior + flow fwd + MRF + MPD/MSD, both optimizer passes)",
-            "value": args.steps * world / dt, "unit": "global steps/s (x n_gpus batches of B)", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE[args.math], "data": "synthetic",
-            "config": {"workload": f"VISinger GAN training step, B={B}/GPU T_mel={T} segment={tr.segment_size} hop={tr.hop}, reference-size "
-                                   "generator + MPD/MSD, AdamW x2, random-init weights", "baseline_config": 3, "p_dropout": args.dropout, "per_gpu_batch": B,
-                       "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)"},
-            "generated_samples_per_s": B * world * tr.segment_size * tr.hop * args.steps / dt,
-            "losses_last_step": logs}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    PROFILER.start(count_only=True)
+    tr.training_step(batch, runner=runner)
+    torch.cuda.synchronize()
+    PROFILER.stop()
+    counts = PROFILER.counts()
+    step_flops = sum(v["flops"] for v in counts.values())
+    step_tflops = step_flops / (dt / steps) / 1e12
+    assert all(np.isfinite(v) for v in logs.values()), logs
+    peak = BF16_MFMA_PEAK_TFLOPS / 6 if math == "split6" else (FP32_MFMA_PEAK_TFLOPS if math == "f32" else BF16_MFMA_PEAK_TFLOPS)
+    return {
+        "metric": "GAN training steps/sec (BASELINE config 3: posterior + flow fwd + MRF + MPD/MSD, both optimizer passes)",
+        "value": steps * world / dt, "unit": "global steps/s (x n_gpus batches of B)", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE[math], "data": "synthetic",
+        "config": {"workload": f"VISinger GAN training step, B={B}/GPU T_mel={T} segment={tr.segment_size} hop={tr.hop}, reference-size "
+                               "generator + MPD/MSD, AdamW x2, random-init weights", "baseline_config": 3, "p_dropout": dropout, "per_gpu_batch": B,
+                   "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)"},
+        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": step_tflops, "peak": peak, "frac": step_tflops / peak,
+                     "frac_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+                     "step": {"algorithmic_tflop_per_step": step_flops / 1e12,
+                              "by_kind_tflop": {k: v["flops"] / 1e12 for k, v in sorted(counts.items(), key=lambda kv: -kv[1]["flops"])[:12]},
+                              "launches_counted": sum(v["launches"] for v in counts.values())},
+                     "note": "whole step (no single dominant kernel: 6 000 launches): algorithmic FLOPs (2*MAC) of every conv / attention "
+                             "launch of the forward, the grad-input launches and the weight-gradient launches (library GEMMs of the 1x1 / "
+                             "wide discriminator weight gradients included at their 2*MAC), counted on one extra step, / measured step time; "
+                             "peak = the roof of the arithmetic (dense bf16 MFMA / 6 cross products)"},
+        "generated_samples_per_s": B * world * tr.segment_size * tr.hop * steps / dt,
+        "losses_last_step": logs}
 
 
 if __name__ == "__main__":

@@ -481,8 +481,28 @@ def text_encoder(sd, text, pitch, dur, mel2ph, *, hidden_channels, n_heads, n_la
     return out.transpose(0, 2, 1)
 
 
-def visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk_id, noise, dtype=np.float64, return_all=False):
-    """VISinger.forward(infer=True) with use_pitch_embed=False, models/visinger.py:71-112."""
+def forward_pitch(sd, hp, prior, nonpad, spk, voiced_hint=None, hint_tol=0.0, dtype=np.float64):
+    """VISinger.forward_pitch with f0=None (synthesis), models/visinger.py:122-135: f0 = pred[..., 0], voiced = pred[..., 1] <= 0,
+    condition (f0 * voiced)[:, None, :] * nonpadding -> ([B, 1, T], pred [B, T, 2], voiced [B, T]).
+    The voicing decision is a threshold on a computed value: where the oracle's own |pred[..., 1]| <= hint_tol the caller's
+    `voiced_hint` decides (a parity test passes the device's decision for exactly those frames and asserts agreement elsewhere)."""
+    pred = pitch_predictor(_sub(sd, "pitch_predictor"), prior, nonpad, spk, n_heads=hp["num_heads"],
+                           n_layers=hp["pitch_predictor_layers"], kernel_size=hp["ffn_kernel_size"], dtype=dtype)
+    voiced = pred[:, :, 1] <= 0
+    if voiced_hint is not None:
+        near = np.abs(pred[:, :, 1]) <= hint_tol
+        voiced = np.where(near, np.asarray(voiced_hint, bool), voiced)
+    cond = (pred[:, :, 0] * voiced)[:, None, :] * nonpad
+    return cond, pred, voiced
+
+
+def visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk_id, noise, dtype=np.float64, return_all=False, voiced_hint=None,
+                   hint_tol=0.0):
+    """VISinger.forward(infer=True), models/visinger.py:71-112.  With hp["use_pitch_embed"] the pitch predictor conditions the frame
+    prior (visinger.py:86-90, 122-135).  The reference's own caller cannot run that branch: forward_pitch returns [B, 1, T] and
+    FramePriorNetwork.forward transposes it once more before a Conv1d(1, H, 1) (encoder.py:68-69; SURVEY.md 3.5-1: RuntimeError), so the
+    branch is restated as the modules define it -- pre_net sees the [B, 1, T] condition -- and is pinned at module level only
+    (tests/golden/pitch_predictor.npz, frame_prior.npz, rel_encoder_g.npz)."""
     H = hp["hidden_size"]
     kw = dict(n_heads=hp["num_heads"], kernel_size=hp["ffn_kernel_size"], dtype=dtype)
     nonpad = (np.asarray(mel2ph) > 0).astype(dtype)[:, None, :]
@@ -491,7 +511,11 @@ def visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk_id, noise, dtype=np.flo
     pos = sinusoidal_positional_embedding(prior.transpose(0, 2, 1)[..., 0], H, 0, init_size=2000).astype(dtype)
     prior = prior + pos.transpose(0, 2, 1)
     spk = _c(sd["spk_id_proj.weight"], dtype)[spk_id][:, :, None]                  # [B,gin,1]
-    mu_p, logs_p = frame_prior(_sub(sd, "frame_prior"), prior, nonpad, None, hidden_channels=H,
+    cond, f0_pred, voiced = None, None, None
+    if hp.get("use_pitch_embed"):
+        cond, f0_pred, voiced = forward_pitch(sd, hp, prior, nonpad, spk, voiced_hint, hint_tol, dtype)
+        cond = np.transpose(cond, (0, 2, 1))          # frame_prior() transposes it back, as FramePriorNetwork.forward does
+    mu_p, logs_p = frame_prior(_sub(sd, "frame_prior"), prior, nonpad, cond, hidden_channels=H,
                                n_layers=hp["frame_prior_layers"], **kw)
     z_p = (mu_p + _c(noise, dtype) * np.exp(logs_p)) * nonpad
     z_q = flow_block(_sub(sd, "flow"), z_p, nonpad, spk, reverse=True, channels=H, hidden_channels=H, kernel_size=5,
@@ -501,7 +525,7 @@ def visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk_id, noise, dtype=np.flo
                     upsample_rates=hp["upsample_rates"], upsample_kernel_sizes=hp["upsample_kernel_sizes"],
                     dtype=dtype)[:, 0]
     if return_all:
-        return dict(prior=prior, mu_p=mu_p, logs_p=logs_p, z_p=z_p, z_q=z_q, wav_out=wav)
+        return dict(prior=prior, mu_p=mu_p, logs_p=logs_p, z_p=z_p, z_q=z_q, wav_out=wav, f0_pred=f0_pred, voiced=voiced)
     return wav
 
 

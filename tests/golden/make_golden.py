@@ -406,6 +406,43 @@ def gen_model():
     torch.set_grad_enabled(False)
 
 
+def gen_model_pitch():
+    """The synthesis graph WITH the pitch predictor (use_pitch_embed=True, the shipped default: config/models/visinger.yaml:36) -- the
+    graph bench.py times.  The reference's own call chain raises there (forward_pitch returns [B, 1, T],
+    FramePriorNetwork.forward transposes it once more, encoder.py:68-69); the ONE change made here is at that call site, on the live
+    object: the condition is handed over as [B, T, 1], so the reference's own transpose restores what its Conv1d(1, H, 1) expects.
+    Every module forward and VISinger.forward / forward_pitch run unmodified."""
+    from models.visinger import VISinger
+    hp_t = dict(enc_layers=2, dec_blocks="1", hidden_size=16, use_pos_embed=True, segment_size=4, num_mel_bins=128,
+                use_spk_id=True, use_spk_embed=False, num_spk=1, gin_channels=8, ffn_filter_channels=24, num_heads=2,
+                ffn_kernel_size=3, p_dropout=0.0, use_pitch_embed=True, pitch_predictor_layers=2, use_phoneme_pred=True,
+                phoneme_predictor_layers=1, frame_prior_layers=2, num_linear_bins=21, dec_kernel_size=[3, 5],
+                dec_dilation_sizes=[[1, 3, 5]] * 2, upsample_rates=[4, 2], initial_upsample_channels=32,
+                upsample_kernel_sizes=[8, 4], predictor_grad=1.0)
+    m = VISinger(13, 9, 7, hp_t).eval()
+    randomize(m, 71, scale=0.7)
+    inner = m.frame_prior.forward
+    m.frame_prior.forward = lambda x, x_mask, g=None: inner(x, x_mask, None if g is None else g.transpose(1, 2))
+    B, T, Tph = 2, 23, 6
+    gi = torch.Generator().manual_seed(72)
+    text = torch.randint(1, 13, (B, Tph), generator=gi)
+    pitch = torch.randint(1, 9, (B, Tph), generator=gi)
+    dur = torch.randint(1, 7, (B, Tph), generator=gi)
+    mel2ph = torch.zeros(B, T, dtype=torch.long)
+    mel2ph[0] = torch.tensor([1] * 3 + [2] * 4 + [3] * 2 + [4] * 5 + [5] * 3 + [6] * 6)
+    mel2ph[1, :17] = torch.tensor([1] * 4 + [2] * 3 + [3] * 2 + [4] * 4 + [5] * 2 + [6] * 2)
+    spk_id = torch.zeros(B, dtype=torch.long)
+    torch.manual_seed(4322)
+    with CaptureRandn() as cap:
+        ret = m(text, pitch, dur, mel2ph, spk_id=spk_id, infer=True)
+    margin = float(ret["f0_pred"][:, :, 1].abs().min())
+    assert margin > 1e-3, margin          # no voicing decision of the fixture sits on the threshold
+    save("visinger_tiny_pitch", **sd_np(m), text=text, pitch=pitch, dur=dur, mel2ph=mel2ph, spk_id=spk_id, noise=cap.draws[0],
+         wav_out=ret["wav_out"], f0_pred=ret["f0_pred"])
+    with open(os.path.join(OUT, "visinger_tiny_pitch_hparams.json"), "w") as f:
+        json.dump(hp_t, f, sort_keys=True)
+
+
 if __name__ == "__main__":
     gen_wavenet()
     gen_posterior()
@@ -416,3 +453,4 @@ if __name__ == "__main__":
     gen_integer()
     gen_discriminators()
     gen_model()
+    gen_model_pitch()

@@ -195,6 +195,21 @@ def test_visinger_tiny_infer(oracle):
     close(wav, a["wav_out"], atol=5e-5, rtol=1e-4)
 
 
+def test_visinger_tiny_infer_with_pitch_predictor(oracle):
+    """the graph bench.py times (use_pitch_embed=True): the reference's own VISinger.forward / forward_pitch and module forwards, with the
+    condition handed to FramePriorNetwork as [B, T, 1] at the one call site that raises otherwise (make_golden.gen_model_pitch)"""
+    w, a = load_golden("visinger_tiny_pitch")
+    hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_pitch_hparams.json")))
+    assert hp["use_pitch_embed"] is True
+    out = oracle.visinger_infer(w, hp, a["text"], a["pitch"], a["dur"], a["mel2ph"], a["spk_id"], a["noise"], return_all=True)
+    close(out["f0_pred"], a["f0_pred"], atol=5e-5, rtol=1e-4)
+    assert np.array_equal(out["voiced"], a["f0_pred"][:, :, 1] <= 0)          # (the fixture keeps 1e-3 clear of the threshold)
+    close(out["wav_out"], a["wav_out"], atol=5e-5, rtol=1e-4)
+    # the condition matters: without it the waveform is a different one
+    off = oracle.visinger_infer(w, dict(hp, use_pitch_embed=False), a["text"], a["pitch"], a["dur"], a["mel2ph"], a["spk_id"], a["noise"])
+    assert float(np.abs(off - a["wav_out"]).max()) > 1e-3
+
+
 def _disc_weights(cls, seed, *args):
     """The discriminator fixtures store a seed, not 40 MB of weights: re-create them with the generator script's
     `randomize` recipe on our (state-dict identical) module."""

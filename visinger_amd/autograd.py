@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .ops import ConvOp, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_weight, gconv1d_fwd
+from .ops import PROFILER, ConvOp, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_weight, gconv1d_fwd
 
 LRELU_SLOPE = 0.1
 
@@ -179,6 +179,7 @@ class StridedConv1dFn(torch.autograd.Function):
                 # wide layers (512 / 1024 channels): per tap a plain [Cout x P] x [P x s*C] GEMM over the folded sequence --
                 # library GEMM territory (rocBLAS); vs_conv_wgrad's 32 x 32 tiles re-read both operands once per tile pair
                 g2 = torch.stack([gyF[0] @ XF[0][:, q:q + Lf].t() for q in range(Q)], dim=2)
+                PROFILER.note("strided-conv wgrad (library GEMM per tap)", 2.0 * Cout * stride * C * Q * Lf)
             else:
                 g2 = conv_wgrad(gyF, XF, Q, 1, 0)                                               # [Cout, s*C, Q]
             gw = g2.view(Cout, stride, C, Q).permute(0, 2, 3, 1).reshape(Cout, C, Q * stride)[:, :, :K].contiguous() if stride > 1 else g2
@@ -443,6 +444,7 @@ class AttnCoreFn(torch.autograd.Function):
         qp, kp, vp = (q, k, v) if packed else (L.ptr(q), L.ptr(k), L.ptr(v))
         L.check(lib.vs_relattn_train_fwd(qp, kp, vp, bs, L.ptr(rk), L.ptr(rv), L.ptr(mk), L.ptr(out), 0, L.ptr(lse), B, nh, dk, T,
                                          w if has_rel else -1, rk.shape[0] if has_rel else 1, float(p_drop), seed, L.stream_ptr()))
+        PROFILER.note("relattn_train_fwd", 4.0 * B * C * T * T)           # Q K^T and P V over the full [T, T] matrix
         none = out.new_empty(0)
         ctx.save_for_backward(*((qkv, none, none) if packed else (q, k, v)), rk if has_rel else none, rv if has_rel else none,
                               mk if mk is not None else none, out, lse)
@@ -474,6 +476,7 @@ class AttnCoreFn(torch.autograd.Function):
                                          L.ptr(mk) if has_mask else None, L.ptr(out), L.ptr(dout), 0, L.ptr(lse), dqp, dkp, dvp,
                                          bs, L.ptr(work), L.ptr(pk), L.ptr(pv), B, nh, dk, T, w if has_rel else -1, rk.shape[0] if has_rel else 1,
                                          p_drop, seed, L.stream_ptr()))
+        PROFILER.note("relattn_train_bwd", 8.0 * B * C * T * T)           # dV, dP, dQ, dK: four [T, T] x d GEMMs (the recomputed scores not counted)
         drk = drv = None
         if has_rel:
             dims = (0, 1, 2) if rk.shape[0] == 1 else (0, 2)

@@ -14,20 +14,44 @@ def _off(t, elems):
     return ctypes.c_void_p(t.data_ptr() + 4 * int(elems))
 
 
+class _NoEvent:
+    """stand-in for a HIP event in counting mode (no per-launch events: a training step has ~6 000 launches)"""
+
+    def record(self):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
 class LaunchProfiler:
     """Optional per-launch HIP-event timing of the conv engine (used by bench.py for the roofline line).
-    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    Events are recorded on the stream the kernels are launched on (torch's current stream).
+    start(count_only=True): count launches / algorithmic FLOPs / bytes per kernel instance without recording events."""
 
     def __init__(self):
         self.enabled = False
+        self.count_only = False
         self.records = []          # (kernel instance name, algorithmic flops, algorithmic HBM bytes, start event, end event)
 
-    def start(self):
+    def start(self, count_only=False):
         self.records = []
+        self.count_only = count_only
         self.enabled = True
 
     def stop(self):
         self.enabled = False
+
+    def events(self):
+        if self.count_only:
+            return _NoEvent(), _NoEvent()
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def note(self, name, flops, nbytes=0.0):
+        """count work done outside the event-timed launch sites (weight-gradient kernels, library GEMMs of the training path)"""
+        if self.enabled:
+            e = _NoEvent()
+            self.records.append((name, float(flops), float(nbytes), e, e))
 
     def summary(self):
         """-> {instance: dict(launches, flops, ms)} ; call after torch.cuda.synchronize()."""
@@ -39,6 +63,8 @@ class LaunchProfiler:
             d["bytes"] += by
             d["ms"] += e0.elapsed_time(e1)
         return out
+
+    counts = summary
 
 
 PROFILER = LaunchProfiler()
@@ -202,7 +228,7 @@ class ConvOp:
         io.pair_mode = pair_mode
         io.logdet = L.ptr(logdet)
         if PROFILER.enabled:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = PROFILER.events()
             e0.record()
             L.check(self.lib.vs_conv_forward(self.h, ctypes.byref(io), L.stream_ptr()))
             e1.record()
@@ -255,7 +281,7 @@ def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=N
         R = 0 if rel_k is None else rel_k.shape[1]
         work = torch.empty((B * n_heads * ksplit * (C // n_heads + 2 + R) * T,), device=qkv.device, dtype=torch.float32)
     if PROFILER.enabled:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = PROFILER.events()
         e0.record()
     L.check(lib.vs_relattn_fwd_ksplit(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
                                       L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
@@ -345,12 +371,14 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
         # a 1x1 conv's weight gradient is a plain GEMM [Cout x B*T] . [B*T x Cin]: library territory (hipBLASLt through torch, as the
         # wide discriminator layers already do); vs_conv_wgrad's 32 x 32 tiles with the positions split over the waves ran it at
         # 7-9 TFLOP/s (tools/wgrad_breakdown.py: 94 calls, 11.8 ms of the config-3 step)
+        PROFILER.note("wgrad 1x1 (library GEMM)", 2.0 * B * Cout * Cin * Tout)
         return torch.einsum("bot,bit->oi", gy, x).unsqueeze(2)
     if gy.data_ptr() % 16:       # (an offset view that is contiguous: the split kernel loads float4 rows of gy)
         gy = gy.clone()
     planes = lib.vs_conv_wgrad_planes(B, Cout, Cin, Tout, int(k))
     part = torch.empty((planes, Cout, Cin, k), device=x.device, dtype=torch.float32)
     L.check(lib.vs_conv_wgrad(L.ptr(gy), L.ptr(x), L.ptr(part), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad), L.stream_ptr()))
+    PROFILER.note("conv_wgrad (vs_conv_wgrad)", 2.0 * B * Cout * Cin * k * Tout)
     return part.sum(0) if planes > 1 else part[0]
 
 
@@ -367,6 +395,7 @@ def gconv1d_fwd(x, w, bias, stride, pad, groups):
     y = torch.empty((B, Cout, _gconv_out_len(T, k, stride, pad)), device=x.device, dtype=torch.float32)
     L.check(lib.vs_gconv1d_fwd(L.ptr(x), L.ptr(w), L.ptr(None if bias is None else bias.contiguous().float()), L.ptr(y), B, Cin, Cout, T,
                                k, stride, pad, groups, L.stream_ptr()))
+    PROFILER.note("gconv_fwd_kernel", 2.0 * B * Cout * (Cin // groups) * k * y.shape[2])
     return y
 
 
@@ -377,6 +406,7 @@ def gconv1d_bwd_data(gy, w, T, stride, pad, groups):
     cig, k = w.shape[1], w.shape[2]
     gx = torch.empty((B, cig * groups, T), device=gy.device, dtype=torch.float32)
     L.check(lib.vs_gconv1d_bwd_data(L.ptr(gy), L.ptr(w), L.ptr(gx), B, cig * groups, Cout, T, k, stride, pad, groups, L.stream_ptr()))
+    PROFILER.note("gconv_bwd_data_kernel", 2.0 * B * Cout * cig * k * gy.shape[2])
     return gx
 
 
@@ -387,6 +417,7 @@ def gconv1d_bwd_weight(gy, x, k, stride, pad, groups):
     Cin, T = x.shape[1], x.shape[2]
     planes = torch.empty((B, Cout, Cin // groups, k), device=x.device, dtype=torch.float32)
     L.check(lib.vs_gconv1d_bwd_weight(L.ptr(gy), L.ptr(x), L.ptr(planes), B, Cin, Cout, T, k, stride, pad, groups, L.stream_ptr()))
+    PROFILER.note("gconv_bwd_weight_kernel", 2.0 * B * Cout * (Cin // groups) * k * gy.shape[2])
     return planes.sum(0)
 
 
@@ -430,7 +461,7 @@ def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
         setattr(o, name, q)
     o.scale = scale
     if PROFILER.enabled:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = PROFILER.events()
         e0.record()
         L.check(op1.lib.vs_respair_forward(op1.h, op2.h, ctypes.byref(io), L.stream_ptr()))
         e1.record()
