@@ -98,10 +98,14 @@ VS_API int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, con
  *   VS_MATH_F32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), Winograd F(2,3) instances where they measured faster
  *   VS_MATH_SPLIT6 operands split exactly into three bf16 planes, the six leading cross products on v_mfma_f32_32x32x16_bf16:
  *                  fp32-class result (dropped terms <= 2^-23 relative per product) at 16/6 of the fp32 matrix rate (default)
+ *   VS_MATH_SPLIT3 operands split into two f16 planes, x * s = xh + xl (22 significant bits; s = a power of two per staged tile /
+ *                  per conv weight that puts the largest magnitude below 2^15, found on the device, taken out again in fp32), the
+ *                  three leading cross products on v_mfma_f32_32x32x16_f16: representation + dropped term <= 2^-22 relative per
+ *                  product, below the rounding of the fp32 accumulation itself; 16/3 of the fp32 matrix rate
  *   VS_MATH_BF16   operands rounded to bf16 (RNE), fp32 accumulate: BASELINE.json's long-form bf16 configuration
  * May be called before or after vs_conv_set_weights (the bf16 planes are re-packed from the fp32 fragments).
  * No reference counterpart: its arithmetic is whatever torch picks (config/models/base_config.yaml:5 `amp: false` = fp32).   */
-enum vs_conv_math { VS_MATH_F32 = 0, VS_MATH_BF16 = 1, VS_MATH_SPLIT6 = 6 };
+enum vs_conv_math { VS_MATH_F32 = 0, VS_MATH_BF16 = 1, VS_MATH_SPLIT3 = 3, VS_MATH_SPLIT6 = 6 };
 VS_API int vs_conv_set_math(vs_conv_t *h, int math, void *stream);
 VS_API int vs_conv_get_math(const vs_conv_t *h);
 

@@ -23,7 +23,7 @@ def run(C, k, d, T, B=2, seed=0, scale_x=1.0):
     rms = ref.pow(2).mean().sqrt().item()
     out = {}
     for name, env, math in (("fp32 mfma", {"VS_NO_WINO": "1"}, L.MATH_F32), ("fp32 F(2,3)", {"VS_WINO_FORCE": "1"}, L.MATH_F32),
-                            ("split-bf16 x6", {}, L.MATH_SPLIT6), ("bf16", {}, L.MATH_BF16)):
+                            ("split-bf16 x6", {}, L.MATH_SPLIT6), ("split-f16 x3", {}, L.MATH_SPLIT3), ("bf16", {}, L.MATH_BF16)):
         for kk in ("VS_NO_WINO", "VS_WINO_FORCE"):
             L.set_option(kk, int(env.get(kk, 0)))
         op = ConvOp(L.CONV1D, C, C, k, d, pad).set_math(math)

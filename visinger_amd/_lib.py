@@ -19,7 +19,7 @@ PAIR_GATE, PAIR_COUPLING_FWD, PAIR_COUPLING_INV = 0, 1, 2
 MODE_LINEAR, MODE_COUPLING_MEAN_FWD, MODE_COUPLING_MEAN_INV = 0, 1, 2
 FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 # enum vs_conv_math
-MATH_F32, MATH_BF16, MATH_SPLIT6 = 0, 1, 6
+MATH_F32, MATH_BF16, MATH_SPLIT3, MATH_SPLIT6 = 0, 1, 3, 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 EXPECTED_ABI = 4          # include/visinger_hip.h VS_ABI_VERSION this binding was written against

@@ -46,6 +46,7 @@ struct ConvParams {
     int row_lo, row_hi;         // only rows in [row_lo, row_hi) are stored
     int fast_epi;               // host-checked preconditions of the LDS-transposed float4 epilogue
     int x_bf16, y_bf16;         // bf16-RESIDENT tensors (plain-bf16 arithmetic only): x / (y, res, acc) hold bf16 elements; strides in elements
+    const float *wscale;        // split-f16 arithmetic: {s_w, 1 / s_w}, the power-of-two scale the packed weight planes carry (device memory)
     int dbg;                    // perturbation experiments (VS_WINO_DBG: 1 = no weight-fragment loads, 2 = no staging), 0 in production
     unsigned long long *stamps; // debug: per-workgroup phase time stamps (NULL in production)
 };
@@ -110,11 +111,41 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned (&out)[NPL
     }
 }
 
+// ---- split-f16 helpers (TERMS = 3, VS_MATH_SPLIT3): x * s = xh + xl with xh = RNE_f16(x * s), xl = RNE_f16(x * s - xh) -- 22 significant
+// bits under a power-of-two scale s that keeps the largest magnitude of the tile below 2^15; three cross products hh + hl + lh on
+// v_mfma_f32_32x32x16_f16, each exact in the fp32 accumulator; the dropped ll term and the 22-bit representation are <= 2^-22 of a product
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_h(float a, float b, unsigned (&out)[2]) {       // a, b already scaled
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);                       // v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);                   // exact
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    out[0] = __builtin_bit_cast(unsigned, h);
+    out[1] = __builtin_bit_cast(unsigned, l);
+}
+// biased exponent eb of the largest |value| of a tile -> the tile's scale 2^(141 - eb): every magnitude < 2^(eb - 126) lands below 2^15
+constexpr int F16_EB_MIN = 24;      // tiles whose largest magnitude is below 2^-102 share the scale of 2^-102 (their values flush towards 0)
+__device__ __forceinline__ float f16_scale(int eb) { return u2f((unsigned)(268 - eb) << 23); }
+__device__ __forceinline__ float f16_inv_scale(int eb) { return u2f((unsigned)(eb - 14) << 23); }
+// largest value of a wave-uniform-to-be 8-bit quantity over the 64 lanes, by bisection with ballots (no LDS, result in an SGPR)
+__device__ __forceinline__ int wave_max_u8(int v) {
+    int cur = 0;
+#pragma unroll
+    for (int bit = 7; bit >= 0; --bit) {
+        const int cand = cur | (1 << bit);
+        if (__builtin_amdgcn_ballot_w64(v >= cand) != 0ull) cur = cand;
+    }
+    return cur;
+}
+
 // conv_split.hip
 struct vs_split_pack {            // re-pack of the fp32 fragment-order weights into bf16 planes
     const float *wp;              // Wp[m_tile][tap][chunk][quad(2)][64][4] (pack_conv_kernel)
     void *ws;                     // Ws[m_tile][tap][chunk][plane][64 lanes][8 bf16]
     int MT_alloc, KT, nchunks, terms;
+    float *wscale;                // terms = 3 (two f16 planes): out, {s_w, 1 / s_w} with s_w = 2^(14 - floor(log2 max|w|))
 };
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);

@@ -1291,7 +1291,7 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     h->math = VS_MATH_SPLIT6;
     {
         const int m = (int)opt(OPT_CONV_MATH);
-        if (m == VS_MATH_F32 || m == VS_MATH_BF16 || m == VS_MATH_SPLIT6) h->math = m;
+        if (m == VS_MATH_F32 || m == VS_MATH_BF16 || m == VS_MATH_SPLIT6 || m == VS_MATH_SPLIT3) h->math = m;
     }
     *out = h;
     return VS_OK;
@@ -1302,12 +1302,17 @@ static int pack_split_planes(vs_conv *h, hipStream_t s) {
     VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * npl * 64 * 16));
     vs_split_pack q;
     q.wp = h->wp.as<float>(); q.ws = h->ws.p; q.MT_alloc = h->MT_alloc; q.KT = h->KT; q.nchunks = h->nchunks; q.terms = h->math;
+    q.wscale = nullptr;
+    if (h->math == VS_MATH_SPLIT3) {
+        VS_TRY(h->wsc.reserve(16));
+        q.wscale = h->wsc.as<float>();
+    }
     return pack_split(q, s);
 }
 
 int vs_conv_set_math(vs_conv_t *h, int math, void *stream) {
     VS_REQUIRE(h, "vs_conv_set_math: NULL handle");
-    VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6, "vs_conv_set_math: unknown arithmetic %d", math);
+    VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6 || math == VS_MATH_SPLIT3, "vs_conv_set_math: unknown arithmetic %d", math);
     if (h->math == math) return VS_OK;
     h->math = math;
     if (math && h->weights_set) VS_TRY(pack_split_planes(h, as_stream(stream)));
@@ -1345,7 +1350,12 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     q.w = w; q.scale = scale; q.bias = bias; q.wp = h->wp.as<float>(); q.biasp = h->biasp.as<float>();
     q.kind = h->kind; q.c_in = h->c_in; q.c_out = h->c_out; q.k = h->k; q.up = h->dil; q.pad = h->pad; q.dmin = h->dmin;
     q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags; q.wino_tail1 = 0;
-    if (h->math) {
+    if (h->math == VS_MATH_SPLIT3) {
+        // split-f16: the planes need the largest weight first (one scale per conv): fp32 fragments, then the scaled planes
+        const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
+        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
+        VS_TRY(pack_split_planes(h, s));
+    } else if (h->math) {
         // bf16-pipe arithmetic: fp32 fragments + bf16 planes in one launch
         const int npl = split_planes(h->math);
         VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * npl * 64 * 16));
@@ -1493,6 +1503,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         p.row_hi = h->c_out;
         if (h->math) {
             p.wp = h->ws.as<float>();
+            p.wscale = h->wsc.as<float>();
             return launch_split(p, (h->MT >= 4) ? 4 : 5, h->math, h->span, s);
         }
         if (h->MT >= 4) { p.W = 128 + h->span; return launch_cfg<2, 2, 2, 2>(p, s); }
@@ -1586,6 +1597,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     if (opt(OPT_CONV_CFG) >= 0 && h->MT >= 3) cfg = (opt(OPT_CONV_CFG) == 3) ? 3 : (opt(OPT_CONV_CFG) == 1 ? 1 : 0);   // A/B switch
     if (h->math) p.wp = h->ws.as<float>();
     if (h->math) p.dbg = (int)opt(OPT_SPLIT_DBG);
+    p.wscale = h->wsc.as<float>();
     auto launch = [&](const ConvParams &q) -> int {
         if (h->math) return launch_split(q, cfg, h->math, h->span, s);
         switch (cfg) {

@@ -94,8 +94,58 @@ __global__ void pack_split_kernel(const vs_split_pack q, int npl) {
     }
 }
 
+// ---- split-f16 (terms = 3): the weight planes carry ONE power-of-two scale per conv, s_w = 2^(14 - floor(log2 max|w|)) (largest weight below
+// 2^15), found on the device (the pack never synchronises with the host): |w| bits -> atomic max -> {s_w, 1 / s_w} -> two f16 planes
+__global__ void wabsmax_kernel(const float *wp, long long n, unsigned *maxbits) {
+    unsigned m = 0;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        m = max(m, f2u(wp[e]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
+}
+__global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *maxbits) {
+    const long long total = (long long)q.MT_alloc * q.KT * q.nchunks * 64;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int eb = max((int)(*maxbits >> 23), F16_EB_MIN);          // (all-zero weights: any scale does)
+    const float sw = f16_scale(eb);
+    if (e == 0) { q.wscale[0] = sw; q.wscale[1] = f16_inv_scale(eb); }
+    if (e >= total) return;
+    const int lane = (int)(e & 63);
+    const long long cell = e >> 6;                       // (m_tile, tap, chunk)
+    const int row = lane & 31, kg = lane >> 5;
+    const float *src = q.wp + cell * 512;
+    unsigned d[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cl = 8 * kg + 2 * t + u, cp = cl >> 1, par = cl & 1;
+            v[u] = src[(cp >> 2) * 256 + (row + 32 * par) * 4 + (cp & 3)] * sw;
+        }
+        split_pair_h(v[0], v[1], d[t]);
+    }
+    u32x4 *dst = reinterpret_cast<u32x4 *>(q.ws) + cell * 2 * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        u32x4 o; o.x = d[0][pl]; o.y = d[1][pl]; o.z = d[2][pl]; o.w = d[3][pl];
+        dst[pl * 64] = o;
+    }
+}
+
 int pack_split(const vs_split_pack &q, hipStream_t s) {
     const long long total = (long long)q.MT_alloc * q.KT * q.nchunks * 64;
+    if (q.terms == 3) {
+        if (!q.wscale) { set_error("pack_split: the split-f16 arithmetic needs a scale buffer"); return VS_EINVAL; }
+        unsigned *maxbits = reinterpret_cast<unsigned *>(q.wscale + 2);
+        VS_CHECK_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s));
+        const long long n = total * 8;                   // fp32 fragment elements (zero padding included)
+        hipLaunchKernelGGL(wabsmax_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256 * 8), 1024)), dim3(256), 0, s, q.wp, n, maxbits);
+        hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, (const unsigned *)maxbits);
+        VS_CHECK_HIP(hipGetLastError());
+        return VS_OK;
+    }
     hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, split_planes(q.terms));
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
@@ -111,7 +161,7 @@ static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
         else return conv_split_kernel_bf16io<MT_W, NT_W, WAVES_M, WAVES_N, TERMS, IO>;
     }();
     p.W = BN + span;
-    const size_t lds = std::max<size_t>((size_t)2 * NPL * 2 * p.W * 16, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
+    const size_t lds = std::max<size_t>((size_t)2 * NPL * 2 * p.W * 16 + (TERMS == 3 ? 32 : 0), (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -158,6 +208,7 @@ int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t 
         return io == 1 ? launch_split_io<1>(p, cfg, span, s) : io == 2 ? launch_split_io<2>(p, cfg, span, s) : launch_split_io<3>(p, cfg, span, s);
     }
     if (terms == 6) return launch_split_terms<6>(p, cfg, span, s);
+    if (terms == 3) return launch_split_terms<3>(p, cfg, span, s);
     if (terms == 1) return launch_split_terms<1>(p, cfg, span, s);
     set_error("launch_split: unsupported term count %d", terms);
     return VS_EUNSUPPORTED;

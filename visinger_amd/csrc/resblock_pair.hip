@@ -301,7 +301,8 @@ int vs_respair_supported(const vs_conv_t *c1, const vs_conv_t *c2) {
     const int C = c1->c_in;
     return c1->kind == VS_CONV1D && c2->kind == VS_CONV1D && (C == 32 || C == 64) && c1->c_out == C && c2->c_in == C && c2->c_out == C &&
            c1->k == c2->k && (c1->k & 1) && c1->k <= PHALO + 1 && c2->dil == 1 && c1->pad == c1->dil * (c1->k - 1) / 2 &&
-           c2->pad == (c2->k - 1) / 2 && (c1->k - 1) * c1->dil <= 64 && c1->flags == 0 && c2->flags == 0;
+           c2->pad == (c2->k - 1) / 2 && (c1->k - 1) * c1->dil <= 64 && c1->flags == 0 && c2->flags == 0 &&
+           c1->math != VS_MATH_SPLIT3 && c2->math != VS_MATH_SPLIT3;       // (the fused pair has no split-f16 instance yet)
 }
 
 int vs_respair_forward(vs_conv_t *c1, vs_conv_t *c2, const vs_conv_io_t *io, void *stream) {
