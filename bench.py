@@ -43,8 +43,10 @@ HOP = 256
 SR = 22050
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense bf16 (no sparsity)
-MATH = {"split6": 6, "f32": 0, "bf16": 1}
-DTYPE = {"split6": "f32 (operands split exactly into 3 bf16 planes, 6 cross products on the bf16 MFMA, fp32 accumulate)",
+MATH = {"split3": 3, "split6": 6, "f32": 0, "bf16": 1}
+DTYPE = {"split3": "f32 (operands as 2 f16 planes under a power-of-two scale per staged tile = 22 significant bits, 3 cross products on the "
+                   "f16 MFMA, fp32 accumulate; error vs fp64 below the fp32 MFMA's: tests/test_conv_split_gpu.py)",
+         "split6": "f32 (operands split exactly into 3 bf16 planes, 6 cross products on the bf16 MFMA, fp32 accumulate)",
          "f32": "f32", "bf16": "bf16 operands, f32 accumulate (f32 tensors in HBM)"}
 
 
@@ -304,8 +306,9 @@ def parse_args():
     ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
                     help="256: the BASELINE.json benchmark variant (default); 300: the reference's own generator configuration")
     ap.add_argument("--math", default=None, choices=tuple(MATH),
-                    help="arithmetic of the conv engine (include/visinger_hip.h vs_conv_math): split6 = fp32-class split-bf16 "
-                         "(default, the headline), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 operands (BASELINE config 5)")
+                    help="arithmetic of the conv engine (include/visinger_hip.h vs_conv_math): split3 = fp32-class split-f16 (default, the "
+                         "headline), split6 = fp32-class split-bf16 (the default of rounds 1-2), f32 = fp32 MFMA / Winograd F(2,3), bf16 = bf16 "
+                         "operands (BASELINE config 5)")
     ap.add_argument("--dropout", type=float, default=0.1, help="config 3: p_dropout of the transformers (reference config: 0.1)")
     ap.add_argument("--storage", default=None, choices=("f32", "bf16"),
                     help="element type of the generator's activations in HBM (bf16 only with --math bf16; default: bf16 for --config 5)")
@@ -318,7 +321,7 @@ def parse_args():
     args.frames = args.frames if args.frames is not None else preset.get("frames", 1024)
     args.hidden = args.hidden if args.hidden is not None else preset.get("hidden", 192)
     if args.math is None:
-        args.math = "bf16" if preset.get("math") == "bf16" else "split6"
+        args.math = "bf16" if preset.get("math") == "bf16" else "split3"
     if args.storage is None:
         args.storage = "bf16" if (args.config == 5 and args.math == "bf16") else "f32"
     if args.storage == "bf16" and args.math != "bf16":
@@ -384,17 +387,19 @@ def roofline_from_profile(prof, dt, steps):
     step_bytes = sum(v["bytes"] for v in prof.values()) / steps
     step_tflops = step_flops / (dt / steps) / 1e12
     kern_ms = sum(v["ms"] for v in prof.values())
-    if name.startswith(("conv_split_kernel", "respair_split_kernel", "resblock_split_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
+    if name.startswith(("conv_split_kernel", "respair_split_kernel", "resblock_f16_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
         targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
         ints = [int(a) for a in targs if a.isdigit()]
         if name.startswith("conv_split_kernel"):
             terms = ints[4]                                  # cross products per fp32 product (5th template argument)
         elif name.startswith("conv_wsplit_kernel"):
             terms = 6
+        elif name.startswith("resblock_f16_kernel"):
+            terms = 3
         else:
             terms = ints[-1] if ints[-1] in (1, 3, 6) else ints[-2]
         peak = BF16_MFMA_PEAK_TFLOPS / terms
-        peak_name = (f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
+        peak_name = (f"dense bf16 / f16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {terms} cross products per fp32 product = the roof of "
                      f"this arithmetic for fp32-class results" if terms > 1 else "dense bf16 MFMA peak")
         roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_name": peak_name, "frac_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -514,8 +519,8 @@ def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
     from visinger_amd.ops import PROFILER
     preset = CONFIGS[config]
     if config == 3:
-        return train_line(preset["batch"], preset["frames"], 0.1, "split6", steps, warmup, 0, 1, None, dev, barrier)
-    math = "bf16" if preset.get("math") == "bf16" else "split6"
+        return train_line(preset["batch"], preset["frames"], 0.1, "split3", steps, warmup, 0, 1, None, dev, barrier)
+    math = "bf16" if preset.get("math") == "bf16" else "split3"
     wl = InferenceWorkload(config, preset["batch"], preset["frames"], preset.get("hidden", 192), math, "bf16" if config == 5 else "f32", 256, False, dev)
     out, dt, per_step = timed_run(wl.step, steps, warmup, True, barrier)
     wav = out["wav_out"]
@@ -600,17 +605,21 @@ def main():
             out["cpu_baseline_torch"] = cpu_baseline(model, hp, wl.batch, backend="torch")
             out["flow_logdet"] = flow_logdet_check(model, dev)
             out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
-        if world == 1 and args.math == "split6" and not args.no_cpu_baseline:
-            # the same workload on the exact-fp32 MFMA / F(2,3) kernels, same process, same weights, same --steps / --warmup: the
-            # number to hold the split-bf16 arithmetic against (error against fp64: DESIGN.md 4, tests/test_conv_split_gpu.py)
+        if world == 1 and args.math in ("split3", "split6") and not args.no_cpu_baseline:
+            # the same workload on the other fp32-class engines, same process, same weights, same --steps / --warmup: the exact-fp32 MFMA /
+            # F(2,3) kernels and (for the split-f16 default) the split-bf16 x6 engine that was the default of rounds 1-2 -- the numbers to
+            # hold the headline arithmetic against (error against fp64: DESIGN.md 4, tests/test_conv_split_gpu.py)
             from visinger_amd.modules.hipconv import set_conv_math
-            set_conv_math(model, MATH["f32"])
-            o32, dt32, per32 = timed_run(wl.step, args.steps, args.warmup, False, barrier)
-            set_conv_math(model, MATH["split6"])
-            out["fp32_mfma_engine"] = {"value": B * T * HOP * args.steps / dt32, "unit": "audio samples/s", "ms_per_step": dt32 / args.steps * 1e3,
-                                       "ms_per_step_stats": percentile_stats(per32), "steps": args.steps, "warmup": args.warmup,
-                                       "max_abs_waveform_diff_vs_value_run": float((o32["wav_out"] - wav).abs().max()),
-                                       "note": "bench.py --math f32: v_mfma_f32_32x32x2_f32 + Winograd F(2,3) kernels, no bf16 anywhere"}
+            for other, key, note in (("f32", "fp32_mfma_engine", "bench.py --math f32: v_mfma_f32_32x32x2_f32 + Winograd F(2,3) kernels, no bf16 / f16 anywhere"),
+                                     ("split6", "split_bf16x6_engine", "bench.py --math split6: three exact bf16 planes, six cross products (the default of rounds 1-2)")):
+                if other == args.math:
+                    continue
+                set_conv_math(model, MATH[other])
+                o2, dt2, per2 = timed_run(wl.step, args.steps, args.warmup, False, barrier)
+                out[key] = {"value": B * T * HOP * args.steps / dt2, "unit": "audio samples/s", "ms_per_step": dt2 / args.steps * 1e3,
+                            "ms_per_step_stats": percentile_stats(per2), "steps": args.steps, "warmup": args.warmup,
+                            "max_abs_waveform_diff_vs_value_run": float((o2["wav_out"] - wav).abs().max()), "note": note}
+            set_conv_math(model, MATH[args.math])
         if headline and not args.no_other_configs:
             # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each after 3 warm-up steps)
             del wl, model, out_dev, wav
@@ -660,7 +669,7 @@ def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barri
     step_flops = sum(v["flops"] for v in counts.values())
     step_tflops = step_flops / (dt / steps) / 1e12
     assert all(np.isfinite(v) for v in logs.values()), logs
-    peak = BF16_MFMA_PEAK_TFLOPS / 6 if math == "split6" else (FP32_MFMA_PEAK_TFLOPS if math == "f32" else BF16_MFMA_PEAK_TFLOPS)
+    peak = BF16_MFMA_PEAK_TFLOPS / MATH[math] if math in ("split3", "split6") else (FP32_MFMA_PEAK_TFLOPS if math == "f32" else BF16_MFMA_PEAK_TFLOPS)
     return {
         "metric": "GAN training steps/sec (BASELINE config 3: posterior + flow fwd + MRF + MPD/MSD, both optimizer passes)",
         "value": steps * world / dt, "unit": "global steps/s (x n_gpus batches of B)", "n_gpus": world, "steps": steps,

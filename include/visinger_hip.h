@@ -148,6 +148,16 @@ typedef struct vs_conv_io {
 
 VS_API int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * a11  A whole MRF residual block (or any even-length prefix / suffix of its conv chain) in ONE launch on the split-f16 arithmetic:
+ *      for each pair (conv1, conv2):  x = conv2(lrelu(conv1(lrelu(x)))) + x;   y = (x [+ io->out[0].acc]) * io->out[0].scale
+ *      (modules/visinger/decoder.py:91-104; the accumulate input and the scale carry the MRF sum of decoder.py:52-56).
+ *      convs = {convs1[0], convs2[0], convs1[1], convs2[1], ...}: 2, 4 or 6 handles of 32 or 64 channels, one odd kernel size <= 11,
+ *      "same" padding, all in VS_MATH_SPLIT3.  The residual stream stays in registers (fp32) between the pairs; each tile recomputes
+ *      its receptive halo instead of exchanging it.  io: x, B, T, in_act = VS_IN_LRELU, out[0].y / acc / scale; nothing else.        */
+VS_API int vs_resblock_supported(vs_conv_t *const *convs, int nconv);
+VS_API int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *io, void *stream);
+
 /* One launch for a residual pair of the MRF blocks on the 32- / 64-channel stages (decoder.py:92-101):
  *     y = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + res [+ acc] [* scale]
  * conv1 / conv2 are existing handles (weights set): same channel count C in {32, 64}, same odd k <= 13, "same" padding, conv2

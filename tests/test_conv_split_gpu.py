@@ -34,13 +34,17 @@ def test_split6_error_not_above_fp32_mfma(oracle, vs_option, C, k, d, T):
     pad = d * (k - 1) // 2
     ref = oracle.conv1d(x.astype(np.float64), w, bias, dilation=d, padding=pad)
     errs = {}
-    for math in (L.MATH_F32, L.MATH_SPLIT6, L.MATH_BF16):
+    for math in (L.MATH_F32, L.MATH_SPLIT6, L.MATH_SPLIT3, L.MATH_BF16):
         op = ConvOp(L.CONV1D, C, C, k, d, pad).set_math(math)
         assert op.math == math
         op.set_weights(dev(w), None, dev(bias))
         errs[math] = rel_rms(op.forward(dev(x)), ref)
     assert errs[L.MATH_SPLIT6] <= 1.25 * errs[L.MATH_F32] + 1e-8, errs
     assert errs[L.MATH_SPLIT6] <= 3e-6, errs
+    # the split-f16 x3 engine (the default since round 3): 22-bit operands under a per-tile scale, half the products summed in fp32 --
+    # not above the fp32 MFMA's error either, and not above the six-product split's
+    assert errs[L.MATH_SPLIT3] <= 1.0 * errs[L.MATH_F32] + 1e-8, errs
+    assert errs[L.MATH_SPLIT3] <= 1.05 * errs[L.MATH_SPLIT6] + 1e-8, errs
     assert 1e-4 < errs[L.MATH_BF16] <= 6e-3, errs          # bf16 operands: ~2^-9 per product, fp32 accumulate
 
 
@@ -54,9 +58,9 @@ def test_split_kernel_instances_and_repack(oracle):
     w = (r.standard_normal((Cout, Cin, k)) / np.sqrt(Cin * k)).astype(np.float32)
     ref = oracle.conv1d(oracle.leaky_relu(x.astype(np.float64)), w, None, padding=2)
     op = ConvOp(L.CONV1D, Cin, Cout, k, 1, 2)
-    assert op.math == L.MATH_SPLIT6 and op.kernel_instance() == ""
+    assert op.math == L.MATH_SPLIT3 and op.kernel_instance() == ""          # the library default
     op.set_weights(dev(w), None, None)
-    for math, tol in ((L.MATH_SPLIT6, 2e-6), (L.MATH_F32, 2e-6), (L.MATH_BF16, 6e-3), (L.MATH_SPLIT6, 2e-6)):
+    for math, tol in ((L.MATH_SPLIT3, 2e-6), (L.MATH_SPLIT6, 2e-6), (L.MATH_F32, 2e-6), (L.MATH_BF16, 6e-3), (L.MATH_SPLIT3, 2e-6), (L.MATH_SPLIT6, 2e-6)):
         op.set_math(math)
         assert rel_rms(op.forward(dev(x), in_act=L.IN_LRELU), ref) <= tol, math
         # the instance name comes from the library's own dispatch (vs_last_kernel_name), template arguments as rocprofv3 prints them
@@ -67,10 +71,10 @@ def test_split_kernel_instances_and_repack(oracle):
         else:
             assert name.startswith("conv_split_kernel<1, ") and name.endswith(f", {math}>"), name
     with pytest.raises(L.VisingerHipError):
-        op.set_math(3)
+        op.set_math(4)
 
 
-@pytest.mark.parametrize("math,tol", [(L.MATH_SPLIT6, 3e-6), (L.MATH_BF16, 8e-3)])
+@pytest.mark.parametrize("math,tol", [(L.MATH_SPLIT6, 3e-6), (L.MATH_SPLIT3, 3e-6), (L.MATH_BF16, 8e-3)])
 def test_split_transposed_and_paired(oracle, math, tol):
     """polyphase transposed conv, WaveNet gate and affine-coupling epilogues on the split engine"""
     from visinger_amd.ops import ConvOp
@@ -180,7 +184,7 @@ def test_wsplit_f23_on_split_engine(oracle, vs_option, Cin, Cout, k, d, T, B):
     mask[-1, (2 * T) // 3:] = 0
     w = oracle.weight_norm(v, g)
     pad = d * (k - 1) // 2
-    op = ConvOp(L.CONV1D, Cin, Cout, k, d, pad)
+    op = ConvOp(L.CONV1D, Cin, Cout, k, d, pad).set_math(L.MATH_SPLIT6)          # (F(2,3) exists on the split-bf16 x6 arithmetic only)
     op.set_weights(dev(v), dev(g), dev(bias))
     xl = oracle.leaky_relu(x.astype(np.float64))
 

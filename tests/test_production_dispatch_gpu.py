@@ -100,8 +100,7 @@ def test_config2_flow_inverse_and_generator_at_full_size(oracle, capsys):
     assert ez[0] <= 5e-5
     assert ew[0] <= 1e-4                                         # waveform: 1e-4 abs (north_star)
     # at this size the launches fill the chip: the production instances, not the small-grid tiles of the T_mel <= 24 tests
-    for must in ("conv_split_kernel<1, 8, 4, 1, 6>", "conv_wsplit_kernel<1, 4, 1>", "respair_split_kernel<2, 1, 4, 6, false>",
-                 "respair_split_kernel<2, 2, 2, 6, false>"):
+    for must in ("conv_split_kernel<1, 8, 4, 1, 3>", "conv_split_kernel<1, 4, 2, 2, 3>", "resblock_f16_kernel<2, 1, 4>", "resblock_f16_kernel<4, 2, 2>"):
         assert must in names, (must, sorted(names))
 
 
@@ -122,9 +121,8 @@ def test_headline_batch_items_against_the_oracle(oracle, capsys):
     ret, names = dispatched(run)
     wav, f0_pred = ret["wav_out"], ret["f0_pred"]
     assert wav.shape == (B, T * 256) and bool(torch.isfinite(wav).all())
-    for must in ("conv_split_kernel<1, 8, 4, 1, 6>", "conv_split_kernel<1, 4, 2, 2, 6>", "conv_wsplit_kernel<1, 4, 1>",
-                 "conv_wsplit_kernel<3, 4, 1>", "conv_wsplit_kernel<5, 4, 1>", "conv_wsplit_kernel<1, 4, 2>",
-                 "respair_split_kernel<2, 1, 4, 6, false>", "respair_split_kernel<2, 2, 2, 6, false>", "relattn_bf16_kernel<3, 32, 6>"):
+    for must in ("conv_split_kernel<1, 8, 4, 1, 3>", "conv_split_kernel<1, 4, 2, 2, 3>", "conv_split_kernel<2, 2, 2, 2, 3>",
+                 "resblock_f16_kernel<2, 1, 4>", "resblock_f16_kernel<4, 2, 2>", "relattn_bf16_kernel<3, 32, 6>"):
         assert must in names, (must, sorted(names))
     oracle.set_threads(bench.usable_cores())
     tol_v = 1e-3          # voicing threshold (pred[..., 1] <= 0): frames the oracle itself puts within tol_v of 0 take the device's decision

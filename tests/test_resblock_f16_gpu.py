@@ -1,0 +1,83 @@
+"""csrc/resblock_f16.hip: a whole MRF residual block (reference modules/visinger/decoder.py:91-104) as ONE launch on the split-f16 x3
+arithmetic, against the fp64 oracle's ResBlock1: every kernel size of the generator and two more, both widths, the whole block and pair by
+pair, tiles in the interior / at both ends of the sequence / a sequence shorter than one tile / lengths that are no multiple of 4
+(element-wise epilogue), the MRF accumulate input and scale, non-finite inputs, and the dispatch of ResBlock1 itself."""
+import numpy as np
+import pytest
+import torch
+
+from visinger_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _block(C, k, seed):
+    from visinger_amd.modules.hipconv import set_conv_math
+    from visinger_amd.modules.visinger.decoder import ResBlock1
+    torch.manual_seed(seed)
+    m = ResBlock1(C, k, (1, 3, 5))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("weight_g"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[1] * p.shape[2]) ** 0.5)
+    sd = {k_: v.detach().numpy().copy() for k_, v in m.state_dict().items()}
+    return set_conv_math(m.cuda().eval(), L.MATH_SPLIT3), sd
+
+
+@pytest.mark.parametrize("C,k,B,T", [(32, 3, 2, 3000), (64, 3, 2, 1501), (32, 7, 1, 2048), (64, 7, 2, 777), (32, 11, 2, 1000), (64, 11, 1, 4096),
+                                     (64, 5, 1, 100), (32, 3, 3, 7), (64, 9, 1, 232), (32, 5, 1, 233)])
+@pytest.mark.parametrize("pairs", [3, 1])
+def test_whole_resblock_launch_vs_oracle(oracle, vs_option, C, k, B, T, pairs):
+    m, sd = _block(C, k, C + k)
+    vs_option("VS_RESBLOCK_PAIRS", pairs)
+    r = np.random.default_rng(C * 7 + k + T)
+    x = (2.0 * r.standard_normal((B, C, T))).astype(np.float32)
+    acc = r.standard_normal((B, C, T)).astype(np.float32)
+    ref = oracle.resblock1(sd, x.astype(np.float64), kernel_size=k, dilation=(1, 3, 5))
+    scale = float(np.sqrt((ref ** 2).mean()))
+    xd = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        y = m._run_fused(xd, torch.empty_like(xd), first=True, scale=1.0)
+        acc_t = torch.from_numpy(acc).cuda()
+        m._run_fused(xd, acc_t, first=False, scale=1.0 / 3.0)                  # in place on the MRF accumulator, averaged
+    assert m.convs1[0]._op().kernel_instance().startswith("resblock_f16_kernel<"), m.convs1[0]._op().kernel_instance()
+    assert np.abs(y.double().cpu().numpy() - ref).max() <= 1e-5 * scale
+    assert np.abs(acc_t.double().cpu().numpy() - (ref + acc) / 3.0).max() <= 1e-5 * scale
+    assert torch.equal(xd.cpu(), torch.from_numpy(x))                            # the input is left untouched
+
+
+def test_whole_resblock_equals_conv_by_conv_launches(vs_option):
+    """the fused launch against the SAME arithmetic launched conv by conv (csrc/conv_split.hip, TERMS = 3) at a production-sized tile count:
+    identical products and scales per tile differ (a staged chunk tile vs the whole-channel tile), so agreement is to fp32 rounding"""
+    m, _ = _block(64, 7, 5)
+    x = torch.randn(4, 64, 16384, device="cuda")
+    with torch.no_grad():
+        y_f = m._run_fused(x, torch.empty_like(x)).clone()
+        vs_option("VS_NO_RESBLOCK_FUSED", 1)
+        y_u = m._run_fused(x, torch.empty_like(x))
+    assert m.convs1[0]._op().kernel_instance().startswith("conv_split_kernel<")
+    assert float((y_f - y_u).abs().max()) <= 2e-6 * float(y_u.abs().max())
+
+
+def test_resblock_nonfinite_inputs_stay_local():
+    """an Inf / NaN activation poisons exactly the outputs whose receptive field (through all six convs) holds it: the tile's scale is taken
+    from its FINITE magnitudes (conv_common.h f16_maxkey), so every other output keeps its value"""
+    m, _ = _block(32, 3, 9)
+    x = torch.randn(1, 32, 4096, device="cuda")
+    with torch.no_grad():
+        clean = m._run_fused(x, torch.empty_like(x)).clone()
+        x[0, 5, 1000], x[0, 20, 3000] = float("inf"), float("nan")
+        y = m._run_fused(x, torch.empty_like(x))
+    bad = ~torch.isfinite(y[0]).all(0)
+    H = 12                                       # pads of the six convs: (1 + 1) + (3 + 1) + (5 + 1)
+    want = torch.zeros(4096, dtype=torch.bool, device="cuda")
+    for t in (1000, 3000):
+        want[t - H:t + H + 1] = True
+    assert bool((bad <= want).all()) and bool(bad[1000]) and bool(bad[3000])       # nothing outside the receptive cone
+    ok = ~want
+    assert float((y[0][:, ok] - clean[0][:, ok]).abs().max()) <= 1e-5 * float(clean.abs().max())

@@ -18,7 +18,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
-def run(oracle, x, w, bias, k, d, maths=(L.MATH_F32, L.MATH_SPLIT6)):
+def run(oracle, x, w, bias, k, d, maths=(L.MATH_F32, L.MATH_SPLIT6, L.MATH_SPLIT3)):
     from visinger_amd.ops import ConvOp
     C_out, C_in, _ = w.shape
     pad = d * (k - 1) // 2
@@ -50,6 +50,13 @@ def test_wide_dynamic_range(oracle, vs_option, C, k, d, T, span):
     # sums dominated by a handful of huge products: the split's dropped cross terms (<= 3 * 2^-24 of a product, one-sided because the
     # planes are truncations) weigh as much as the fp32 engine's own product rounding (<= 2^-24): same class, up to ~3x its rms
     assert rms6 <= 3.0 * rms32 + 2.0 ** -26, (rms6, rms32)
+    # split-f16 x3: one power-of-two scale per staged tile (16 channels x ~320 positions) and per conv weight -- operands more than 2^17
+    # below their tile's largest magnitude lose relative precision (absolute floor 2^-39 of that magnitude), which a sum normalised by
+    # S = sum |x||w| does not see: the same bounds hold
+    _, max3, rms3 = out[L.MATH_SPLIT3]
+    print(f"                              split3 max {max3:.3e} rms {rms3:.3e}")
+    assert max3 <= 4 * 2.0 ** -24 * np.sqrt(n) + 2.0 ** -22, (max3, max32)
+    assert rms3 <= 3.0 * rms32 + 2.0 ** -26, (rms3, rms32)
 
 
 @pytest.mark.parametrize("C,k,T", [(128, 7, 1024), (64, 3, 4096)])
@@ -69,6 +76,13 @@ def test_catastrophic_cancellation(oracle, vs_option, C, k, T):
     print(f"cancellation C={C} k={k}: max|err|/S split6 {max6:.3e} fp32-mfma {max32:.3e}; rms split6 {rms6:.3e} fp32-mfma {rms32:.3e}")
     assert max6 <= 4 * 2.0 ** -24 * np.sqrt(C * k) + 2.0 ** -22, (max6, max32)
     assert rms6 <= 1.5 * rms32 + 2.0 ** -26, (rms6, rms32)
+    # split-f16 x3 represents an operand with 22 significant bits (round to nearest on both planes: <= 2^-23 of the OPERAND, rms ~2^-24.3
+    # -- the size of one fp32 rounding of it); this test surfaces exactly that, 4096-fold relative to the result: stated bound 3x the
+    # fp32 engine's rms error relative to S, same max bound
+    _, max3, rms3 = out[L.MATH_SPLIT3]
+    print(f"                              split3 max {max3:.3e} rms {rms3:.3e}")
+    assert max3 <= 4 * 2.0 ** -24 * np.sqrt(C * k) + 2.0 ** -22, (max3, max32)
+    assert rms3 <= 3.0 * rms32 + 2.0 ** -26, (rms3, rms32)
     # alternating signs with exact cancellation: sum_k (+v, -v) * 1 == 0 exactly in every arithmetic (the six cross products of
     # +v and -v cancel pairwise inside the accumulator: no residue from the split)
     x2 = np.empty((1, C, T), np.float32)
@@ -98,7 +112,7 @@ def test_nonfinite_inputs_stay_local_and_nonfinite(oracle):
             tt = t + pad - j * d
             if 0 <= tt < T:
                 hit[b, tt] = True
-    for math in (L.MATH_SPLIT6, L.MATH_F32):
+    for math in (L.MATH_SPLIT6, L.MATH_SPLIT3, L.MATH_F32):
         op = ConvOp(L.CONV1D, C, C, k, d, pad).set_math(math)
         op.set_weights(dev(w), None, None)
         y = op.forward(dev(x)).cpu().double().numpy()

@@ -107,6 +107,8 @@ def lib():
     L.vs_mel2token_to_dur.argtypes = [vp, vp, i64, i64, i64, i64, vp]
     L.vs_respair_supported.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.vs_respair_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ConvIO), ctypes.c_void_p]
+    L.vs_resblock_supported.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+    L.vs_resblock_forward.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ConvIO), ctypes.c_void_p]
     L.vs_conv_wgrad.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, i64, ci, ci, ci, vp]
     L.vs_conv_wgrad_planes.argtypes = [i64, i64, i64, i64, ci]
     L.vs_gconv1d_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
@@ -120,7 +122,7 @@ def lib():
 # (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
 PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
                for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
-                            "VS_NO_WGRAD_GEMM", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED")}
+                            "VS_NO_WGRAD_GEMM", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS")}
 
 
 def switch(name):

@@ -129,6 +129,12 @@ __device__ __forceinline__ void split_pair_h(float a, float b, unsigned (&out)[2
 constexpr int F16_EB_MIN = 24;      // tiles whose largest magnitude is below 2^-102 share the scale of 2^-102 (their values flush towards 0)
 __device__ __forceinline__ float f16_scale(int eb) { return u2f((unsigned)(268 - eb) << 23); }
 __device__ __forceinline__ float f16_inv_scale(int eb) { return u2f((unsigned)(eb - 14) << 23); }
+// Running maximum of FINITE magnitudes in a form that costs two VALU per value: key(v) = (bits << 1) + 2^24 drops the sign, keeps the
+// order of finite magnitudes (keys 2^24 .. 2^32 - 1) and wraps +-Inf / NaN to keys below 2^24, i.e. below every finite value: a
+// non-finite activation must not set the tile's scale (it would flush every finite value of the tile to zero) -- it becomes Inf / NaN
+// planes under the scale of its finite neighbours and poisons exactly the outputs whose receptive field holds it, as in fp32.
+__device__ __forceinline__ unsigned f16_maxkey(unsigned key, float v) { return max(key, (f2u(v) << 1) + 0x01000000u); }
+__device__ __forceinline__ int f16_key_exponent(unsigned key) { return max((int)(key >> 24) - 1, 0); }      // biased exponent of the largest finite magnitude
 // largest value of a wave-uniform-to-be 8-bit quantity over the 64 lanes, by bisection with ballots (no LDS, result in an SGPR)
 __device__ __forceinline__ int wave_max_u8(int v) {
     int cur = 0;
@@ -146,6 +152,7 @@ struct vs_split_pack {            // re-pack of the fp32 fragment-order weights 
     void *ws;                     // Ws[m_tile][tap][chunk][plane][64 lanes][8 bf16]
     int MT_alloc, KT, nchunks, terms;
     float *wscale;                // terms = 3 (two f16 planes): out, {s_w, 1 / s_w} with s_w = 2^(14 - floor(log2 max|w|))
+    const unsigned *maxbits;      // terms = 3: the largest |w| (bits) when the caller already has it, else NULL (found here)
 };
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);

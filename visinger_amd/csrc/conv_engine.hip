@@ -815,6 +815,7 @@ struct PackParams {
     int kind, c_in, c_out, k, up, pad, dmin, KT, CP, MT_alloc, Hh;
     unsigned flags;
     int wino_tail1;      // pack_wino_kernel: the single tap of the last group in the direct form (k = 7 specialised instances)
+    unsigned *maxbits, *maxbits_clear;   // split-f16 arithmetic: largest |w| (bits) of this pack -> *maxbits; the other slot is zeroed for the next pack
 };
 
 // bias of virtual row m (rows past the real ones: 0)
@@ -874,17 +875,27 @@ __global__ void pack_conv_kernel(const PackParams q) {
     const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (long long)q.MT_alloc * 32) q.biasp[e] = packed_bias(q, (int)e);   // bias over virtual rows
-    if (e >= total) return;
-    const int sub = (int)(e & 3);
-    const int lane = (int)((e >> 2) & 63);
-    const int quad = (int)((e >> 8) & 1);
-    long long t = e >> 9;
-    const int nchunks = q.CP / (CK / 2);
-    const int chunk = (int)(t % nchunks);
-    t /= nchunks;
-    const int tap = (int)(t % q.KT);
-    const int mt = (int)(t / q.KT);
-    q.wp[e] = packed_weight(q, mt, tap, chunk, quad, lane, sub);
+    if (e == 0 && q.maxbits_clear) *q.maxbits_clear = 0u;
+    float v = 0.f;
+    if (e < total) {
+        const int sub = (int)(e & 3);
+        const int lane = (int)((e >> 2) & 63);
+        const int quad = (int)((e >> 8) & 1);
+        long long t = e >> 9;
+        const int nchunks = q.CP / (CK / 2);
+        const int chunk = (int)(t % nchunks);
+        t /= nchunks;
+        const int tap = (int)(t % q.KT);
+        const int mt = (int)(t / q.KT);
+        v = packed_weight(q, mt, tap, chunk, quad, lane, sub);
+        q.wp[e] = v;
+    }
+    if (q.maxbits) {       // (uniform over the launch) the conv's largest weight, for the scale of the f16 planes
+        unsigned m = f16_maxkey(0u, v);      // (finite magnitudes only: a NaN / Inf weight must not set the scale)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(q.maxbits, m);
+    }
 }
 
 // The same pack for the bf16-pipe engine in ONE launch: thread (cell = (m_tile, tap, chunk), lane) produces the eight values of its bf16
@@ -1285,10 +1296,11 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
     h->wsplit = h->wino_groups > 0 && (h->MT % 2) == 0 && (flags & ~VS_CONV_ADJOINT) == 0 && wsplit_instance(dil, h->wino_groups) &&
                 (k >= 9 || opt(OPT_WSPLIT_FORCE));      // (where it pays: see vs_conv_forward)
-    // Default arithmetic: the split-bf16 x6 engine -- measured faster than the fp32 MFMA / F(2,3) instances on every shape of the
-    // path (tools/conv_bench.py: x1.03 .. x1.5) and closer to the fp64 result than the fp32 MFMA (tools/conv_accuracy.py).
-    // VS_CONV_MATH=0 / 1 / 6: process-wide A/B switch for handles created from here on.
-    h->math = VS_MATH_SPLIT6;
+    // Default arithmetic: the split-f16 x3 engine (two f16 planes under a power-of-two scale per staged tile, three cross products) --
+    // measured x1.3 .. x1.45 the rate of the split-bf16 x6 engine on the 128- / 256-channel convs (tools/conv_bench.py) and CLOSER to the
+    // fp64 result than it and than the fp32 MFMA on every case of tools/split3_check.py / tools/conv_accuracy.py (half the products summed
+    // in fp32).  VS_CONV_MATH=0 / 1 / 3 / 6: process-wide A/B switch for handles created from here on.
+    h->math = VS_MATH_SPLIT3;
     {
         const int m = (int)opt(OPT_CONV_MATH);
         if (m == VS_MATH_F32 || m == VS_MATH_BF16 || m == VS_MATH_SPLIT6 || m == VS_MATH_SPLIT3) h->math = m;
@@ -1297,15 +1309,27 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
     return VS_OK;
 }
 
-static int pack_split_planes(vs_conv *h, hipStream_t s) {
+// {s_w, 1 / s_w, max |w| bits of the even packs, of the odd packs}
+static int reserve_wscale(vs_conv *h, hipStream_t s) {
+    if (h->wsc.p) return VS_OK;
+    VS_TRY(h->wsc.reserve(16));
+    VS_CHECK_HIP(hipMemsetAsync(h->wsc.p, 0, 16, s));
+    return VS_OK;
+}
+
+// maxbits_ready: the fp32 pack of THIS weight version has just left the conv's largest |w| in its slot (vs_conv_set_weights); otherwise
+// (vs_conv_set_math on a bound handle) pack_split finds it with a pass of its own over the fp32 fragments
+static int pack_split_planes(vs_conv *h, hipStream_t s, bool maxbits_ready = false) {
     const int npl = split_planes(h->math);
     VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * npl * 64 * 16));
     vs_split_pack q;
     q.wp = h->wp.as<float>(); q.ws = h->ws.p; q.MT_alloc = h->MT_alloc; q.KT = h->KT; q.nchunks = h->nchunks; q.terms = h->math;
     q.wscale = nullptr;
+    q.maxbits = nullptr;
     if (h->math == VS_MATH_SPLIT3) {
-        VS_TRY(h->wsc.reserve(16));
+        VS_TRY(reserve_wscale(h, s));
         q.wscale = h->wsc.as<float>();
+        q.maxbits = maxbits_ready ? reinterpret_cast<const unsigned *>(q.wscale + 2) + (h->pack_gen & 1) : nullptr;
     }
     return pack_split(q, s);
 }
@@ -1350,11 +1374,16 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     q.w = w; q.scale = scale; q.bias = bias; q.wp = h->wp.as<float>(); q.biasp = h->biasp.as<float>();
     q.kind = h->kind; q.c_in = h->c_in; q.c_out = h->c_out; q.k = h->k; q.up = h->dil; q.pad = h->pad; q.dmin = h->dmin;
     q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags; q.wino_tail1 = 0;
+    q.maxbits = q.maxbits_clear = nullptr;
     if (h->math == VS_MATH_SPLIT3) {
         // split-f16: the planes need the largest weight first (one scale per conv): fp32 fragments, then the scaled planes
         const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
+        VS_TRY(reserve_wscale(h, s));
+        ++h->pack_gen;
+        q.maxbits = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + (h->pack_gen & 1);
+        q.maxbits_clear = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + ((h->pack_gen + 1) & 1);
         hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
-        VS_TRY(pack_split_planes(h, s));
+        VS_TRY(pack_split_planes(h, s, true));
     } else if (h->math) {
         // bf16-pipe arithmetic: fp32 fragments + bf16 planes in one launch
         const int npl = split_planes(h->math);

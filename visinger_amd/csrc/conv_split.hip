@@ -99,7 +99,7 @@ __global__ void pack_split_kernel(const vs_split_pack q, int npl) {
 __global__ void wabsmax_kernel(const float *wp, long long n, unsigned *maxbits) {
     unsigned m = 0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
-        m = max(m, f2u(wp[e]) & 0x7fffffffu);
+        m = f16_maxkey(m, wp[e]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
@@ -107,7 +107,7 @@ __global__ void wabsmax_kernel(const float *wp, long long n, unsigned *maxbits) 
 __global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *maxbits) {
     const long long total = (long long)q.MT_alloc * q.KT * q.nchunks * 64;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int eb = max((int)(*maxbits >> 23), F16_EB_MIN);          // (all-zero weights: any scale does)
+    const int eb = max(f16_key_exponent(*maxbits), F16_EB_MIN);      // (*maxbits: the largest f16_maxkey; all-zero weights: any scale does)
     const float sw = f16_scale(eb);
     if (e == 0) { q.wscale[0] = sw; q.wscale[1] = f16_inv_scale(eb); }
     if (e >= total) return;
@@ -138,11 +138,19 @@ int pack_split(const vs_split_pack &q, hipStream_t s) {
     const long long total = (long long)q.MT_alloc * q.KT * q.nchunks * 64;
     if (q.terms == 3) {
         if (!q.wscale) { set_error("pack_split: the split-f16 arithmetic needs a scale buffer"); return VS_EINVAL; }
-        unsigned *maxbits = reinterpret_cast<unsigned *>(q.wscale + 2);
-        VS_CHECK_HIP(hipMemsetAsync(maxbits, 0, sizeof(unsigned), s));
-        const long long n = total * 8;                   // fp32 fragment elements (zero padding included)
-        hipLaunchKernelGGL(wabsmax_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256 * 8), 1024)), dim3(256), 0, s, q.wp, n, maxbits);
-        hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, (const unsigned *)maxbits);
+        const unsigned *maxbits = q.maxbits;
+        if (!maxbits) {       // (vs_conv_set_math on a bound handle: a pass over the fp32 fragments; the slots of the regular packs stay untouched)
+            unsigned *mb;
+            VS_CHECK_HIP(hipMallocAsync((void **)&mb, sizeof(unsigned), s));      // (rare, off the steady-state path; freed in stream order below)
+            VS_CHECK_HIP(hipMemsetAsync(mb, 0, sizeof(unsigned), s));
+            const long long n = total * 8;                   // fp32 fragment elements (zero padding included)
+            hipLaunchKernelGGL(wabsmax_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256 * 8), 1024)), dim3(256), 0, s, q.wp, n, mb);
+            hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, (const unsigned *)mb);
+            VS_CHECK_HIP(hipGetLastError());
+            VS_CHECK_HIP(hipFreeAsync(mb, s));
+            return VS_OK;
+        }
+        hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, maxbits);
         VS_CHECK_HIP(hipGetLastError());
         return VS_OK;
     }

@@ -1,0 +1,330 @@
+// resblock_f16.hip -- a whole MRF residual block of the HiFi-GAN generator in ONE launch, on the split-f16 x3 arithmetic (VS_MATH_SPLIT3):
+//
+//     for each pair m:   x = conv2_m(lrelu(conv1_m(lrelu(x)) + b1_m)) + b2_m + x          (reference modules/visinger/decoder.py:91-104)
+//     y = (x [+ acc]) * scale                                                               (the MRF sum and its 1 / num_kernels: decoder.py:52-56)
+//
+// With two f16 planes and three cross products a 32- / 64-channel conv is far below the HBM ridge as its own launch, and still below it
+// as a fused pair (x in, y out per pair).  Here the residual stream never leaves the CU between the pairs:
+//
+//   * a workgroup owns BN = 256 columns of the sequence and ALL channels.  The same BN columns go through every conv; each conv eats
+//     its receptive half-width off both ends of the range that is still exact, so after the block BN - 2 H columns are final outputs
+//     (H = the sum of the pads: 12 at k = 3, 36 at k = 7) and neighbouring tiles overlap by 2 H columns (recomputed, not exchanged);
+//   * the residual stream x lives in REGISTERS, fp32, in the accumulator layout of the 32x32 MFMA tile (row = (r&3) + 8(r>>2) + 4(lane>>5),
+//     column = lane&31): `x = xt + x` is an add on the accumulators of conv2, no LDS or HBM round trip, full fp32 precision;
+//   * the B operand of every conv is one LDS tile [plane(2)][channel group of 8][column + margin][8 f16], written straight from that
+//     layout (a lane holds 4 consecutive channels of a column = half a 16-byte cell: one ds_write_b64 per plane) after leaky-relu,
+//     zeroing outside the sequence (each conv's own zero padding) and the split x * s = xh + xl.  s is the power of two that puts
+//     the tile's largest magnitude below 2^15: one exponent per wave through LDS, merged behind the barrier that also ends the
+//     previous conv's reads of the tile;
+//   * every conv then is the barrier-free loop of resblock_pair_split.hip's phase 2: weight fragments from L2 one step ahead, each tap a
+//     shifted window of the tile, three f16 MFMAs per 16 channels and 32x32 outputs;
+//   * epilogue: the exact columns through the LDS transposition, float4 stores, the accumulate input read next to them.
+//
+// HBM traffic per block: x in, y out (+ acc in) for SIX convs; the 1-launch-per-conv form moves x, residual and y per conv.
+#include "conv_common.h"
+
+#include <algorithm>
+
+namespace vs {
+
+constexpr int RB_MAXCONV = 6;
+constexpr int RB_MP = 28;          // margin columns of the LDS tile on each side: >= (k - 1) * d / 2 (25 at k = 11, d = 5), multiple of 4
+
+struct ResblockParams {
+    const float *x;
+    long long x_bs;
+    const void *ws[RB_MAXCONV];          // f16 plane fragments Ws[m_tile][tap][chunk][plane(2)][64][8 f16] (pack_split_f16_kernel)
+    const float *bias[RB_MAXCONV];       // packed bias over rows
+    const float *wscale[RB_MAXCONV];     // {s_w, 1 / s_w} of the planes
+    int dil[RB_MAXCONV];
+    float *y;
+    const float *acc;
+    long long y_bs, acc_bs;
+    float scale;
+    int B, C, T, K, nconv, nchunks;
+    int H;                               // columns at each end of a tile that are not final outputs (sum of the pads, rounded up to 4)
+    int fast_epi;
+};
+
+template <int NT_W, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockParams p) {
+    static_assert(WAVES_M * WAVES_N == 4, "four waves");
+    constexpr int BN = 32 * NT_W * WAVES_N;
+    constexpr int WT = BN + 2 * RB_MP;             // column pitch of the tile
+    constexpr int KG = 4 * WAVES_M;                // channel groups of 8
+    constexpr int TPL = KG * WT * 4;               // dwords per plane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned *const Tb = reinterpret_cast<unsigned *>(smem);
+    int *const smax = reinterpret_cast<int *>(Tb + 2 * TPL);       // [2][4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int lhalf = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int NOUT = BN - 2 * p.H;
+    const int n0 = blockIdx.x * NOUT;              // first final output of this tile
+    const int t0 = n0 - p.H;                       // sequence position of tile column 0
+    const int KT = p.K;
+    const int nsteps = p.nchunks * KT;
+    auto acc_row = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lhalf; };
+
+    // margins of the tile: zeros, once (the waves only ever write their own BN columns)
+    for (int e = tid; e < 2 * KG * 2 * RB_MP; e += 256) {
+        const int rowi = e / (2 * RB_MP), c = e % (2 * RB_MP);
+        *reinterpret_cast<u32x4 *>(Tb + (rowi * WT + (c < RB_MP ? c : BN + c)) * 4) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- the residual stream: x in the accumulator layout, zero outside the sequence
+    bool inside[NT_W];
+    f32x16 xr[NT_W], acc[NT_W];
+    {
+        const __amdgpu_buffer_rsrc_t xsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long long)b * p.x_bs), 0, (int)((long long)p.C * p.T * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j) {
+            const int n = t0 + wn * (NT_W * 32) + j * 32 + l31;
+            inside[j] = (n >= 0) && (n < p.T);
+            const int nc = min(max(n, 0), p.T - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                xr[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, ((wm * 32 + acc_row(r)) * p.T + nc) * 4, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xr[j][r] = inside[j] ? xr[j][r] : 0.f;
+    }
+
+    // one (chunk, tap) step: NT_W column tiles x 3 cross products; the planes of tile j+1 are read under the MFMAs of tile j
+    auto mma_step = [&](const u32x4 (&acur)[2], const unsigned *xs) __attribute__((always_inline)) {
+        u32x4 bf[2], bn[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL);
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j) {
+            if (j + 1 < NT_W) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) bn[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL + (j + 1) * 128);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[ta]), __builtin_bit_cast(f16x8, bf[tb]), acc[j], 0, 0, 0);
+            };
+            mm(1, 0); mm(0, 1); mm(0, 0);        // smallest terms first
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) bf[pl] = bn[pl];
+        }
+    };
+
+    for (int c = 0; c < p.nconv; ++c) {
+        const bool second = (c & 1) != 0;
+        // ---- this conv's input in the accumulator registers: lrelu(x) (first conv of a pair) or lrelu(conv1 + b1) (second), zero outside
+        unsigned mkey = 0u;
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = second ? acc[j][r] : xr[j][r];
+                v = inside[j] ? fmaxf(v, 0.1f * v) : 0.f;
+                acc[j][r] = v;
+                mkey = f16_maxkey(mkey, v);
+            }
+        // ---- the tile's scale: largest exponent over the four waves (the barrier also ends every wave's reads of the previous tile)
+        const int ebw = wave_max_u8(f16_key_exponent(mkey));
+        int *const slot = smax + (c & 1) * 4;
+        if (lane == 0) slot[wave] = ebw;
+        __syncthreads();
+        const int eb = max(max(max(slot[0], slot[1]), max(slot[2], slot[3])), F16_EB_MIN);
+        const float sx = f16_scale(eb);
+        // ---- split and write the tile
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j) {
+            const int col = RB_MP + wn * (NT_W * 32) + j * 32 + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned d0[2], d1[2];
+                split_pair_h(acc[j][4 * g] * sx, acc[j][4 * g + 1] * sx, d0);
+                split_pair_h(acc[j][4 * g + 2] * sx, acc[j][4 * g + 3] * sx, d1);
+                unsigned *dst = Tb + ((wm * 4 + g) * WT + col) * 4 + lhalf * 2;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint2 *>(dst + pl * TPL) = make_uint2(d0[pl], d1[pl]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // ---- weight fragments of the first step, then the conv
+        const int d = p.dil[c];
+        const int pad = d * (KT - 1) / 2;
+        const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (2 * 64) + lane;
+        u32x4 a0[2], a1[2];
+        auto load_a = [&](u32x4 (&dst)[2], int chunk, int tap) __attribute__((always_inline)) {
+            const u32x4 *src = wbase + ((long long)tap * p.nchunks + chunk) * (2 * 64);
+            dst[0] = src[0];
+            dst[1] = src[64];
+        };
+        int pc = 0, pt = 0, chunk = 0, tap = 0, s = 0;
+        auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; ++pc; } };
+        load_a(a0, pc, pt); advance();
+        __syncthreads();
+        auto step = [&](u32x4 (&acur)[2], u32x4 (&apre)[2]) __attribute__((always_inline)) {
+            if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
+            mma_step(acur, Tb + ((chunk * 2 + lhalf) * WT + RB_MP + wn * (NT_W * 32) + l31 + tap * d - pad) * 4);
+            if (++tap == KT) { tap = 0; ++chunk; }
+            ++s;
+        };
+        while (s < nsteps) {
+            step(a0, a1);
+            if (s < nsteps) step(a1, a0);
+        }
+        // ---- scale out, bias in; the second conv of a pair adds the residual stream
+        const float inv = f16_inv_scale(eb) * p.wscale[c][1];
+        const float *const bias = p.bias[c] + wm * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float bv = bias[acc_row(r)];
+#pragma unroll
+            for (int j = 0; j < NT_W; ++j) {
+                const float v = fmaf(acc[j][r], inv, bv);
+                if (second) xr[j][r] += v;
+                else acc[j][r] = v;
+            }
+        }
+    }
+    __syncthreads();                         // the tile is consumed: its space becomes the epilogue's
+
+    // ---- epilogue: y = (x [+ acc]) * scale on the exact columns [H, BN - H) of the tile
+    const int tile_row0 = wm * 32;
+    const bool has_acc = p.acc != nullptr;
+    float *const yb = p.y + (long long)b * p.y_bs;
+    const float *const accp = has_acc ? p.acc + (long long)b * p.acc_bs : nullptr;
+    if (p.fast_epi && (n0 + NOUT <= p.T)) {
+        constexpr int CW = 32 * NT_W, LPR = CW / 4, RPI = 64 / LPR, NIT = 8 / RPI;
+        float *const Lw = smem + wave * 8 * CW;
+        const int lrow = lane / LPR, c4 = (lane % LPR) * 4;
+        const int ctile = wn * CW + c4;                          // column within the tile
+        const bool live = (ctile >= p.H) && (ctile < BN - p.H);  // H % 4 == 0: a float4 is all in or all out
+        const long long goff0 = (long long)(tile_row0 + lrow) * p.T + t0 + ctile;
+        float4 a4[4][NIT];
+        if (live && has_acc) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    a4[ps][it] = *reinterpret_cast<const float4 *>(accp + goff0 + (long long)(8 * ps + it * RPI) * p.T);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = xr[j][4 * ps + q];
+            if (live) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    float4 v = *reinterpret_cast<const float4 *>(Lw + (it * RPI + lrow) * CW + c4);
+                    if (has_acc) { v.x += a4[ps][it].x; v.y += a4[ps][it].y; v.z += a4[ps][it].z; v.w += a4[ps][it].w; }
+                    if (p.scale != 1.f) { v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale; }
+                    *reinterpret_cast<float4 *>(yb + goff0 + (long long)(8 * ps + it * RPI) * p.T) = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j) {
+            const int ctile = wn * (NT_W * 32) + j * 32 + l31;
+            const int n = t0 + ctile;
+            const bool okc = (ctile >= p.H) && (ctile < BN - p.H) && (n < p.T);      // (n >= 0 on exact columns: t0 + H = n0 >= 0)
+            const int nc = min(max(n, 0), p.T - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long off = (long long)(tile_row0 + acc_row(r)) * p.T + nc;
+                float v = xr[j][r];
+                if (has_acc) v += accp[off];
+                v *= p.scale;
+                if (okc) yb[off] = v;
+            }
+        }
+    }
+}
+
+template <int NT_W, int WAVES_M, int WAVES_N>
+static int launch_resblock_cfg(const ResblockParams &p, hipStream_t s) {
+    constexpr int BN = 32 * NT_W * WAVES_N, WT = BN + 2 * RB_MP, KG = 4 * WAVES_M;
+    auto kern = resblock_f16_kernel<NT_W, WAVES_M, WAVES_N>;
+    const size_t lds = std::max<size_t>((size_t)2 * KG * WT * 16 + 32, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)ceil_div(p.T, BN - 2 * p.H), 1, (unsigned)p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("resblock_f16_kernel<%d, %d, %d>", NT_W, WAVES_M, WAVES_N);
+    return VS_OK;
+}
+
+}  // namespace vs
+
+using namespace vs;
+
+extern "C" {
+
+int vs_resblock_supported(vs_conv_t *const *convs, int nconv) {
+    if (!convs || nconv < 2 || nconv > RB_MAXCONV || (nconv & 1)) return 0;
+    const vs_conv *c0 = convs[0];
+    if (!c0) return 0;
+    const int C = c0->c_in, k = c0->k;
+    if (!(C == 32 || C == 64) || !(k & 1) || k < 3 || k > 11) return 0;
+    int H = 0;
+    for (int i = 0; i < nconv; ++i) {
+        const vs_conv *c = convs[i];
+        if (!c || c->kind != VS_CONV1D || c->c_in != C || c->c_out != C || c->k != k || c->flags != 0 || c->math != VS_MATH_SPLIT3) return 0;
+        if (c->pad != c->dil * (k - 1) / 2 || c->pad > RB_MP) return 0;
+        H += c->pad;
+    }
+    H = (H + 3) & ~3;
+    return 256 - 2 * H >= 64;
+}
+
+int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *io, void *stream) {
+    VS_REQUIRE(convs && io, "vs_resblock_forward: NULL argument");
+    VS_REQUIRE(vs_resblock_supported(convs, nconv), "vs_resblock_forward: unsupported chain of convs (32 / 64 channels, one odd k <= 11, VS_MATH_SPLIT3, "
+                                                   "'same' padding, an even number of convs <= 6)");
+    VS_REQUIRE(io->x && io->out[0].y && io->B > 0 && io->B <= 65535 && io->T > 0, "vs_resblock_forward: bad io");
+    VS_REQUIRE(io->x_dtype == VS_DTYPE_F32 && io->y_dtype == VS_DTYPE_F32, "vs_resblock_forward: fp32 tensors only");
+    VS_REQUIRE(io->in_act == VS_IN_LRELU && !io->mask && !io->bias_b && !io->split_row && io->out[0].mode == VS_OUT_LINEAR &&
+                   io->out[0].out_act == VS_OUT_NONE && !io->out[0].out_mask && !io->out[0].res,
+               "vs_resblock_forward: only the unmasked leaky-relu residual form is fused (the residual input is x itself)");
+    ResblockParams p;
+    memset(&p, 0, sizeof(p));
+    const vs_conv *c0 = convs[0];
+    const int C = c0->c_in;
+    VS_REQUIRE((long long)C * io->T * 4 < (1ll << 31), "vs_resblock_forward: item exceeds the 2 GiB buffer-descriptor range");
+    const long long dflt = (long long)C * io->T;
+    p.x = io->x; p.x_bs = io->x_bs ? io->x_bs : dflt;
+    int H = 0;
+    for (int i = 0; i < nconv; ++i) {
+        const vs_conv *c = convs[i];
+        VS_REQUIRE(c->weights_set, "vs_resblock_forward: weights not set");
+        p.ws[i] = c->ws.p; p.bias[i] = c->biasp.as<float>(); p.wscale[i] = c->wsc.as<float>(); p.dil[i] = c->dil;
+        H += c->pad;
+    }
+    p.H = (H + 3) & ~3;
+    const vs_conv_out_t &o = io->out[0];
+    p.y = o.y; p.acc = o.acc;
+    p.y_bs = o.y_bs ? o.y_bs : dflt; p.acc_bs = o.acc_bs ? o.acc_bs : dflt;
+    p.scale = (o.scale == 0.f) ? 1.f : o.scale;
+    p.B = (int)io->B; p.C = C; p.T = (int)io->T; p.K = c0->k; p.nconv = nconv; p.nchunks = c0->nchunks;
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    p.fast_epi = (io->T % 4 == 0) && al16(p.y) && (p.y_bs % 4 == 0) && (!p.acc || (al16(p.acc) && p.acc_bs % 4 == 0));
+    hipStream_t s = as_stream(stream);
+    if (C == 32) return launch_resblock_cfg<2, 1, 4>(p, s);
+    return launch_resblock_cfg<4, 2, 2>(p, s);
+}
+
+}  // extern "C"

@@ -364,7 +364,8 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     p.scale = 1.0f / sqrtf((float)k_channels);
     p.part = nullptr; p.ksplit = 0;
     hipStream_t s = as_stream(stream);
-    VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6, "vs_relattn_fwd: unknown arithmetic %d", math);
+    VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6 || math == VS_MATH_SPLIT3, "vs_relattn_fwd: unknown arithmetic %d", math);
+    if (math == VS_MATH_SPLIT3) math = VS_MATH_SPLIT6;      // (the attention core has no split-f16 instance: the fp32-class split-bf16 x6 kernel serves both)
     // VS_MATH_BF16: both GEMMs on the bf16 matrix instruction (attention_bf16.hip); any other arithmetic, and shapes that kernel does
     // not take (T % 4 != 0, unaligned rows), run the exact-fp32 MFMA kernel below
     // VS_MATH_SPLIT6 (the default arithmetic of the path): the same kernel with every operand split exactly into three bf16 planes and

@@ -113,7 +113,8 @@ struct vs_conv {
     bool has_bias = false;
     int math = 0;                              // 0: fp32 MFMA / F(2,3); 6: split-bf16 x6 (fp32 class); 3: split-f16 x3 (scaled, fp32 class); 1: bf16 (conv_split.hip)
     vs::DevBuf ws;                             // bf16 / f16 plane fragments of the split engine, when math != 0
-    vs::DevBuf wsc;                            // split-f16 arithmetic (math == 3): {s_w, 1 / s_w, max |w| bits} of the packed planes
+    vs::DevBuf wsc;                            // split-f16 arithmetic (math == 3): {s_w, 1 / s_w, max |w| bits of even / odd packs} of the packed planes
+    int pack_gen = 0;                          // weight versions packed in that arithmetic (selects the max slot)
     bool wsplit = false;                       // eligible for conv_wsplit_kernel (F(2,3) on the split-bf16 x6 arithmetic)
     bool wsplit_packed = false;                // wsw holds the transformed weights of the current version
     vs::DevBuf wsw;                            // Us[m_tile][chunk][group][xi][plane][64][8 bf16] (conv_wsplit.hip)

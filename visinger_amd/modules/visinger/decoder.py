@@ -16,7 +16,7 @@ from torch.nn.utils import weight_norm, remove_weight_norm
 
 from ... import _lib as L
 from ... import autograd
-from ...ops import respair_forward, respair_supported
+from ...ops import resblock_forward, resblock_supported, respair_forward, respair_supported
 from ..commons.utils import init_weights, get_padding
 from ..hipconv import HipConv1d, HipConvTranspose1d, mask2d, _forward_only_guard
 
@@ -130,6 +130,18 @@ class ResBlock1(torch.nn.Module):
         """out = ((out if not first else 0) + resblock(x)) * scale   [* mask];  x is left untouched."""
         n = len(self.convs1)
         act = L.IN_LRELU if mask is None else L.IN_LRELU_MASK
+        if mask is None and x.dtype == torch.float32:
+            # split-f16 arithmetic, 32 / 64 channels: the whole block (or groups of its pairs) as one launch each, the residual stream in
+            # registers between the pairs (csrc/resblock_f16.hip); a tile recomputes its halo, which grows with k: see _fused_groups
+            groups = self._fused_groups()
+            if groups is not None:
+                cur = x
+                for gi, ops in enumerate(groups):
+                    last = gi == len(groups) - 1
+                    dst = out if last else torch.empty_like(x)
+                    resblock_forward(ops, cur, dst, acc=None if (first or not last) else out, scale=scale if last else 1.0)
+                    cur = dst
+                return out
         cur = x
         tmp = torch.empty_like(x)
         pp = [torch.empty_like(x) if n > 1 else None, torch.empty_like(x) if n > 2 else None]
@@ -152,6 +164,17 @@ class ResBlock1(torch.nn.Module):
                 c2.run(tmp, in_act=act, mask=mask, res=cur, acc=None if first else out, y=out, scale=scale,
                        out_mask=mask is not None)
         return out
+
+    def _fused_groups(self):
+        """the conv chain cut into launches of csrc/resblock_f16.hip, or None when it does not apply (other arithmetic / width).
+        A launch over p pairs recomputes H = sum of its pads columns at each end of a 256-column tile: k = 3 -> 12 (whole block),
+        k = 7 -> 36 (whole block: 28 % more MFMA work against a third of the tensor passes), k = 11 -> 60: one launch per pair."""
+        ops = [c._op() for pair in zip(self.convs1, self.convs2) for c in pair]
+        if ops[0].math != L.MATH_SPLIT3 or ops[0].c_in not in (32, 64):
+            return None
+        per = L.switch("VS_RESBLOCK_PAIRS") or (len(self.convs1) if ops[0].k <= 7 else 1)       # pairs per launch
+        groups = [ops[2 * i:2 * (i + per)] for i in range(0, len(self.convs1), per)]
+        return groups if all(resblock_supported(g) for g in groups) else None
 
     def forward(self, x, x_mask=None):
         if autograd.training_path(self):

@@ -445,6 +445,45 @@ def respair_supported(op1, op2, profitable_only=False):
     return (C == 32 and (k <= 7 or d > 1)) or (C == 64 and k == 3 and d > 1)
 
 
+def _handle_array(ops):
+    return (ctypes.c_void_p * len(ops))(*[op.h for op in ops])
+
+
+def resblock_supported(ops):
+    """a11: can this chain of convs (convs1[0], convs2[0], convs1[1], ...) run as ONE launch of csrc/resblock_f16.hip"""
+    if L.switch("VS_NO_RESBLOCK_FUSED") or len(ops) < 2 or len(ops) % 2:
+        return False
+    return bool(ops[0].lib.vs_resblock_supported(_handle_array(ops), len(ops)))
+
+
+def resblock_forward(ops, x, y, acc=None, scale=1.0):
+    """a11: for each pair (conv1, conv2) of `ops`: x = conv2(lrelu(conv1(lrelu(x)))) + x; y = (x [+ acc]) * scale -- one launch, the
+    residual stream in registers between the pairs (csrc/resblock_f16.hip, split-f16 arithmetic)."""
+    B, C, T = x.shape
+    io = L.ConvIO()
+    io.x, io.x_dtype = L.act_ptr(x)
+    io.x_bs, io.B, io.T = 0, B, T
+    io.in_act = L.IN_LRELU
+    o = io.out[0]
+    o.y, io.y_dtype = L.act_ptr(y)
+    o.acc = L.ptr(acc)
+    o.scale = scale
+    lib = ops[0].lib
+    if PROFILER.enabled:
+        e0, e1 = PROFILER.events()
+        e0.record()
+        L.check(lib.vs_resblock_forward(_handle_array(ops), len(ops), ctypes.byref(io), L.stream_ptr()))
+        e1.record()
+        nb = 4.0 * B * C * T * (2 + (acc is not None))
+        PROFILER.records.append((ops[0].last_kernel(), sum(op.algorithmic_flops(B, T) for op in ops), nb, e0, e1))
+    else:
+        L.check(lib.vs_resblock_forward(_handle_array(ops), len(ops), ctypes.byref(io), L.stream_ptr()))
+    name = ops[0].last_kernel()
+    for op in ops:
+        op._last_kernel = name
+    return y
+
+
 def respair_forward(op1, op2, x, y, res=None, acc=None, scale=1.0):
     """a11: y = conv2(lrelu(conv1(lrelu(x)))) + res [+ acc] [* scale] in one launch (csrc/resblock_pair.hip)."""
     B, C, T = x.shape
