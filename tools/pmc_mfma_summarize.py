@@ -4,7 +4,7 @@
     python tools/pmc_mfma_summarize.py <pass_dir> <out_prefix>
 
 <pass_dir> holds *_counter_collection.csv and *_kernel_trace.csv of
-    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \\
+    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \\
               GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"""
 import collections
 import csv
@@ -37,9 +37,9 @@ def main():
                     seen.add(r["Dispatch_Id"])
                     dur[k] += kt.get(r["Dispatch_Id"], 0)
                     cnt[k] += 1
-    out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY "
+    out = {"source": "rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY "
                      "GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline (its own "
-                     "pass); mfma_tflops_executed = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 FLOP / kernel time (one v_mfma_f32_32x32x16_bf16 = "
+                     "pass); mfma_tflops_executed = (SQ_INSTS_VALU_MFMA_MOPS_BF16 + _F16) x 512 FLOP / kernel time (one v_mfma_f32_32x32x16_bf16 = "
                      "64 MOPS = 32768 FLOP); mfma_pipe_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
                      "gfx_clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel time", "kernels": {}}
     for k in sorted(dur, key=lambda k: -dur[k]):
@@ -51,8 +51,9 @@ def main():
         d = {"launches": cnt[k], "total_ms": round(dur[k] / 1e6, 3), "gfx_clock_ghz": round(gui / t / 1e9, 3),
              "mfma_pipe_util": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * gui), 4),
              "wave_cycles_waiting_on_issue": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)}
-        if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
-            d["mfma_tflops_executed"] = round(c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512 / t / 1e12, 1)
+        mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)      # (the split-f16 kernels issue f16 MFMAs)
+        if mops:
+            d["mfma_tflops_executed"] = round(mops * 512 / t / 1e12, 1)
             d["frac_of_bf16_peak_2500"] = round(d["mfma_tflops_executed"] / 2500, 4)
         out["kernels"][k] = d
         print(k, d)

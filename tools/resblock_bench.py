@@ -55,7 +55,7 @@ def run(m, x, out, first, scale, pairs):
 
 if what in ("check", "all"):
     for C, k, B, T in ((32, 3, 2, 3000), (64, 3, 2, 1501), (32, 7, 1, 2048), (64, 7, 2, 777), (32, 11, 2, 1000), (64, 11, 1, 4096), (64, 5, 1, 100),
-                       (32, 3, 3, 7), (64, 9, 1, 232)):
+                       (32, 3, 3, 7), (64, 9, 1, 232), (128, 3, 2, 1000), (128, 7, 1, 515), (128, 11, 1, 300)):
         m = block(C, k, seed=C + k)
         set_conv_math(m, L.MATH_SPLIT3)
         x = torch.randn(B, C, T, device="cuda") * 2.0
@@ -76,14 +76,17 @@ if what in ("check", "all"):
 
 if what in ("time", "all"):
     B = int(os.environ.get("RB_B", 32))
-    for C, T in ((64, 131072), (32, 262144)):
+    for C, T in ((128, 65536), (64, 131072), (32, 262144)):
         for k in (3, 7, 11):
             m = block(C, k)
             x = torch.randn(B, C, T, device="cuda")
             out = torch.empty_like(x)
             res = []
-            for math, pairs in ((L.MATH_SPLIT6, 0), (L.MATH_SPLIT3, -1), (L.MATH_SPLIT3, 1), (L.MATH_SPLIT3, 3)):
+            for math, pairs in ((L.MATH_SPLIT6, 0), (L.MATH_SPLIT3, -1), (L.MATH_SPLIT3, 1), (L.MATH_SPLIT3, 3)) + (((L.MATH_SPLIT3, 11), (L.MATH_SPLIT3, 13)) if C == 32 else ()):
                 set_conv_math(m, math)
+                L.set_option("VS_RB_TILE256", 1 if pairs > 10 else 0)
+                if pairs > 10:
+                    pairs -= 10
                 for _ in range(2):
                     run(m, x, out, True, 1.0, pairs)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -94,7 +97,7 @@ if what in ("time", "all"):
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 3
                 fl = 6 * 2.0 * B * C * C * k * T
-                res.append(f"{'split6' if math == 6 else 'split3'} {'as today' if pairs == 0 else ('unfused' if pairs < 0 else str(pairs) + ' pair(s)/launch')}: {ms:6.2f} ms {fl / ms / 1e9:6.1f} TF")
+                res.append(f"{'split6' if math == 6 else 'split3'}{' tile256' if L.get_option('VS_RB_TILE256') else ''} {'as today' if pairs == 0 else ('unfused' if pairs < 0 else str(pairs) + ' pair(s)/launch')}: {ms:6.2f} ms {fl / ms / 1e9:6.1f} TF")
             print(f"resblock C={C} k={k} T={T}: " + " | ".join(res), flush=True)
     L.set_option("VS_RESBLOCK_PAIRS", 0)
     L.set_option("VS_NO_RESBLOCK_FUSED", 0)

@@ -28,7 +28,7 @@
 namespace vs {
 
 constexpr int RB_MAXCONV = 6;
-constexpr int RB_MP = 28;          // margin columns of the LDS tile on each side: >= (k - 1) * d / 2 (25 at k = 11, d = 5), multiple of 4
+constexpr int RB_MAXPAD = 28;      // largest pad of a conv of the chain: (k - 1) * d / 2 = 25 at k = 11, d = 5
 
 struct ResblockParams {
     const float *x;
@@ -43,6 +43,7 @@ struct ResblockParams {
     float scale;
     int B, C, T, K, nconv, nchunks;
     int H;                               // columns at each end of a tile that are not final outputs (sum of the pads, rounded up to 4)
+    int MP;                              // margin columns of the LDS tile on each side = the largest pad of the chain
     int fast_epi;
 };
 
@@ -50,9 +51,10 @@ template <int NT_W, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockParams p) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     constexpr int BN = 32 * NT_W * WAVES_N;
-    constexpr int WT = BN + 2 * RB_MP;             // column pitch of the tile
     constexpr int KG = 4 * WAVES_M;                // channel groups of 8
-    constexpr int TPL = KG * WT * 4;               // dwords per plane
+    const int MP = p.MP;
+    const int WT = BN + 2 * MP;                    // column pitch of the tile
+    const int TPL = KG * WT * 4;                   // dwords per plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned *const Tb = reinterpret_cast<unsigned *>(smem);
     int *const smax = reinterpret_cast<int *>(Tb + 2 * TPL);       // [2][4]
@@ -70,9 +72,9 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
     auto acc_row = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lhalf; };
 
     // margins of the tile: zeros, once (the waves only ever write their own BN columns)
-    for (int e = tid; e < 2 * KG * 2 * RB_MP; e += 256) {
-        const int rowi = e / (2 * RB_MP), c = e % (2 * RB_MP);
-        *reinterpret_cast<u32x4 *>(Tb + (rowi * WT + (c < RB_MP ? c : BN + c)) * 4) = u32x4{0u, 0u, 0u, 0u};
+    for (int e = tid; e < 2 * KG * 2 * MP; e += 256) {
+        const int rowi = e / (2 * MP), c = e % (2 * MP);
+        *reinterpret_cast<u32x4 *>(Tb + (rowi * WT + (c < MP ? c : BN + c)) * 4) = u32x4{0u, 0u, 0u, 0u};
     }
 
     // ---- the residual stream: x in the accumulator layout, zero outside the sequence
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
         // ---- split and write the tile
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
-            const int col = RB_MP + wn * (NT_W * 32) + j * 32 + l31;
+            const int col = MP + wn * (NT_W * 32) + j * 32 + l31;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 unsigned d0[2], d1[2];
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
         __syncthreads();
         auto step = [&](u32x4 (&acur)[2], u32x4 (&apre)[2]) __attribute__((always_inline)) {
             if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
-            mma_step(acur, Tb + ((chunk * 2 + lhalf) * WT + RB_MP + wn * (NT_W * 32) + l31 + tap * d - pad) * 4);
+            mma_step(acur, Tb + ((chunk * 2 + lhalf) * WT + MP + wn * (NT_W * 32) + l31 + tap * d - pad) * 4);
             if (++tap == KT) { tap = 0; ++chunk; }
             ++s;
         };
@@ -252,10 +254,16 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
 }
 
 template <int NT_W, int WAVES_M, int WAVES_N>
+static size_t resblock_lds(int MP) {
+    constexpr int BN = 32 * NT_W * WAVES_N, KG = 4 * WAVES_M;
+    return std::max<size_t>((size_t)2 * KG * (BN + 2 * MP) * 16 + 32, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
+}
+
+template <int NT_W, int WAVES_M, int WAVES_N>
 static int launch_resblock_cfg(const ResblockParams &p, hipStream_t s) {
-    constexpr int BN = 32 * NT_W * WAVES_N, WT = BN + 2 * RB_MP, KG = 4 * WAVES_M;
+    constexpr int BN = 32 * NT_W * WAVES_N;
     auto kern = resblock_f16_kernel<NT_W, WAVES_M, WAVES_N>;
-    const size_t lds = std::max<size_t>((size_t)2 * KG * WT * 16 + 32, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
+    const size_t lds = resblock_lds<NT_W, WAVES_M, WAVES_N>(p.MP);
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -279,21 +287,24 @@ int vs_resblock_supported(vs_conv_t *const *convs, int nconv) {
     const vs_conv *c0 = convs[0];
     if (!c0) return 0;
     const int C = c0->c_in, k = c0->k;
-    if (!(C == 32 || C == 64) || !(k & 1) || k < 3 || k > 11) return 0;
-    int H = 0;
+    if (!(C == 32 || C == 64 || C == 128) || !(k & 1) || k < 3 || k > 11) return 0;
+    int H = 0, MP = 0;
     for (int i = 0; i < nconv; ++i) {
         const vs_conv *c = convs[i];
         if (!c || c->kind != VS_CONV1D || c->c_in != C || c->c_out != C || c->k != k || c->flags != 0 || c->math != VS_MATH_SPLIT3) return 0;
-        if (c->pad != c->dil * (k - 1) / 2 || c->pad > RB_MP) return 0;
+        if (c->pad != c->dil * (k - 1) / 2 || c->pad > RB_MAXPAD) return 0;
         H += c->pad;
+        MP = std::max(MP, c->pad);
     }
     H = (H + 3) & ~3;
+    if (C == 128)       // 128-column tiles, two workgroups per CU: the all-channel tile must fit half the LDS
+        return 128 - 2 * H >= 64 && 2 * (resblock_lds<4, 4, 1>(MP) + 64) <= 160 * 1024;
     return 256 - 2 * H >= 64;
 }
 
 int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *io, void *stream) {
     VS_REQUIRE(convs && io, "vs_resblock_forward: NULL argument");
-    VS_REQUIRE(vs_resblock_supported(convs, nconv), "vs_resblock_forward: unsupported chain of convs (32 / 64 channels, one odd k <= 11, VS_MATH_SPLIT3, "
+    VS_REQUIRE(vs_resblock_supported(convs, nconv), "vs_resblock_forward: unsupported chain of convs (32 / 64 / 128 channels, one odd k <= 11, VS_MATH_SPLIT3, "
                                                    "'same' padding, an even number of convs <= 6)");
     VS_REQUIRE(io->x && io->out[0].y && io->B > 0 && io->B <= 65535 && io->T > 0, "vs_resblock_forward: bad io");
     VS_REQUIRE(io->x_dtype == VS_DTYPE_F32 && io->y_dtype == VS_DTYPE_F32, "vs_resblock_forward: fp32 tensors only");
@@ -313,6 +324,7 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
         VS_REQUIRE(c->weights_set, "vs_resblock_forward: weights not set");
         p.ws[i] = c->ws.p; p.bias[i] = c->biasp.as<float>(); p.wscale[i] = c->wsc.as<float>(); p.dil[i] = c->dil;
         H += c->pad;
+        p.MP = std::max(p.MP, c->pad);
     }
     p.H = (H + 3) & ~3;
     const vs_conv_out_t &o = io->out[0];
@@ -323,7 +335,13 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     p.fast_epi = (io->T % 4 == 0) && al16(p.y) && (p.y_bs % 4 == 0) && (!p.acc || (al16(p.acc) && p.acc_bs % 4 == 0));
     hipStream_t s = as_stream(stream);
-    if (C == 32) return launch_resblock_cfg<2, 1, 4>(p, s);
+    if (C == 32) {
+        // 512-column tiles halve the halo and the weight-fragment traffic per output; with a small halo (k = 3: 12 columns) the 256-column
+        // tile's shorter critical path per workgroup wins (tools/resblock_bench.py: k = 3 1.79 vs 1.90 ms, k = 7 3.47 vs 2.87, k = 11 4.87 vs 4.55)
+        if (opt(OPT_RB_TILE256) || p.H <= 12 || 512 - 2 * p.H > io->T + 256) return launch_resblock_cfg<2, 1, 4>(p, s);
+        return launch_resblock_cfg<4, 1, 4>(p, s);
+    }
+    if (C == 128) return launch_resblock_cfg<4, 4, 1>(p, s);
     return launch_resblock_cfg<4, 2, 2>(p, s);
 }
 

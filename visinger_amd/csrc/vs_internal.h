@@ -37,7 +37,7 @@ enum Opt {
     OPT_NO_BF16_ATTN,     // VS_NO_BF16_ATTN: VS_MATH_BF16 attention on the exact-fp32 kernel
     OPT_NO_SPLIT_ATTN,    // VS_NO_SPLIT_ATTN: VS_MATH_SPLIT6 attention on the exact-fp32 kernel
     OPT_NO_WGRAD_SPLIT,   // VS_NO_WGRAD_SPLIT: weight gradients on the exact-fp32 kernel only
-    OPT_NO_PERSIST,       // VS_NO_PERSIST: one column tile per workgroup in the split engine (no persistent tile loop)
+    OPT_RB_TILE256,       // VS_RB_TILE256: whole-resblock launch at 32 channels on 256-column tiles (default 512: half the weight-fragment traffic and halo per output)
     OPT_COUNT
 };
 long long opt(Opt o);

@@ -167,13 +167,28 @@ class ResBlock1(torch.nn.Module):
 
     def _fused_groups(self):
         """the conv chain cut into launches of csrc/resblock_f16.hip, or None when it does not apply (other arithmetic / width).
-        A launch over p pairs recomputes H = sum of its pads columns at each end of a 256-column tile: k = 3 -> 12 (whole block),
-        k = 7 -> 36 (whole block: 28 % more MFMA work against a third of the tensor passes), k = 11 -> 60: one launch per pair."""
+        A launch over p pairs recomputes H = sum of its pads columns at each end of its tile: k = 3 -> 12, k = 7 -> 36, k = 11 -> 60 for a
+        whole block: the fusion pays where a conv is short of matrix work (k = 3, 32 channels), not where the halo costs more than the saved
+        tensor passes."""
         ops = [c._op() for pair in zip(self.convs1, self.convs2) for c in pair]
-        if ops[0].math != L.MATH_SPLIT3 or ops[0].c_in not in (32, 64):
+        if ops[0].math != L.MATH_SPLIT3 or ops[0].c_in not in (32, 64, 128):
             return None
-        per = L.switch("VS_RESBLOCK_PAIRS") or (len(self.convs1) if ops[0].k <= 7 else 1)       # pairs per launch
-        groups = [ops[2 * i:2 * (i + per)] for i in range(0, len(self.convs1), per)]
+        C, k, n = ops[0].c_in, ops[0].k, len(self.convs1)
+        per = L.switch("VS_RESBLOCK_PAIRS")                                     # pairs per launch (A/B switch); 0: by measurement
+        if not per:
+            # tools/resblock_bench.py, B = 32 production shapes (ms: whole block / pair by pair / conv by conv):
+            #   32 ch:  k=3 1.8 / 2.3 / 3.6   k=7 2.9 / 3.5 / 4.5   k=11 4.6 / 4.6 / 5.5      -> whole block
+            #   64 ch:  k=3 2.7 / 3.5 / 4.4   k=7 5.7 / 5.6 / 6.1   k=11 11.0 / 8.2 / 8.0     -> whole, pairs, conv by conv
+            #   128 ch: k=3 14 / 5.1 / 5.6    k=7 - / 10.4 / 8.6    k=11 (tile does not fit)  -> pairs at k = 3 only
+            if C == 32:
+                per = n
+            elif C == 64:
+                per = n if k <= 5 else (1 if k <= 7 else 0)
+            else:
+                per = 1 if k <= 3 else 0
+            if not per:
+                return None
+        groups = [ops[2 * i:2 * (i + per)] for i in range(0, n, per)]
         return groups if all(resblock_supported(g) for g in groups) else None
 
     def forward(self, x, x_mask=None):

@@ -104,8 +104,11 @@ class VISingerTrainer(nn.Module):
     # -- the two passes of tasks/visinger.py:53-89 ----------------------------------------------------------------
     def generator_pass(self, batch):
         h = self.hp
+        # (noise_q / u_slice: optional injected RNG draws -- posterior noise [B, H, T] and segment-start uniforms [B] -- so that a sharded
+        #  run and a single-process run of the same global batch see the same random numbers: tests/test_ddp_two_ranks_gpu.py)
         out = self.model(batch["text_tokens"], batch["note_pitch"], batch["note_dur"], batch["mel2ph"], spk_id=batch.get("spk_ids"),
-                         f0=batch.get("f0"), uv=batch.get("uv"), mel=batch["mels"], infer=False)
+                         f0=batch.get("f0"), uv=batch.get("uv"), mel=batch["mels"], infer=False, noise_q=batch.get("noise_q"),
+                         u_slice=batch.get("u_slice"))
         losses = {"kl": min(self.global_step / h["kl_start_steps"], 1) * torch.clamp(out["kl"], min=h["kl_min"]) * h["lambda_kl"]}
         tgt_mel = self.mel(batch["wavs"])                                                   # [B, T, M]
         tgt_slice = slice_segments(tgt_mel.transpose(1, 2).contiguous(), out["ids_slice"], self.segment_size).transpose(1, 2)
@@ -138,18 +141,25 @@ class VISingerTrainer(nn.Module):
         """DDP entry point (the reference routes DDP.forward to training_step, ddp_utils.py:75-80)"""
         return self.generator_pass(batch) if optimizer_idx == 0 else self.discriminator_pass(batch)
 
+    def backward_pass(self, batch, opt_idx, runner=None):
+        """forward + backward of one optimizer's pass with the other network frozen (trainer.py:312-375): afterwards the gradients of
+        `own` are in place -- under DDP already all-reduced (averaged over the ranks)."""
+        runner = runner or self
+        own, other = (self.model, self.mel_disc) if opt_idx == 0 else (self.mel_disc, self.model)
+        for p in other.parameters():
+            p.requires_grad_(False)
+        for p in own.parameters():
+            p.requires_grad_(True)
+        loss, parts = runner(batch, opt_idx)
+        loss.backward()                          # under DDP: the bucketed gradient all-reduce over RCCL happens here
+        return parts
+
     def training_step(self, batch, runner=None):
         """One iteration = generator pass + discriminator pass (trainer.py:306-384).  `runner` is the (optionally
         DDP-wrapped) module to call; gradients are clipped over ALL parameters of the task, as the reference does."""
-        runner = runner or self
         logs = {}
-        for opt_idx, (opt, own, other) in enumerate(((self.opt_gen, self.model, self.mel_disc), (self.opt_disc, self.mel_disc, self.model))):
-            for p in other.parameters():
-                p.requires_grad_(False)
-            for p in own.parameters():
-                p.requires_grad_(True)
-            loss, parts = runner(batch, opt_idx)
-            loss.backward()                      # under DDP: the bucketed gradient all-reduce over RCCL happens here
+        for opt_idx, opt in enumerate((self.opt_gen, self.opt_disc)):
+            parts = self.backward_pass(batch, opt_idx, runner)
             if self.hp["clip_grad_norm"] > 0:    # (the other network holds no gradients: zeroed right after ITS step, as below)
                 torch.nn.utils.clip_grad_norm_(self.parameters(), self.hp["clip_grad_norm"])
             opt.step()
