@@ -270,9 +270,9 @@ static int wgrad_slices(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(units, ceil_div(1024, tiles)));
 }
 
-// the split-bf16 kernel: 2..12 taps, >= 64 output channels, float4-loadable gy rows, enough positions to fill its 64-position units
+// the split-bf16 kernel: 1..12 taps, >= 64 output channels, float4-loadable gy rows, enough positions to fill its 64-position units
 static bool wgrad_split_ok(int64_t B, int64_t c_out, int64_t T_out, int k) {
-    return k >= 2 && k <= WS_MAXK && c_out >= 64 && (T_out % 4) == 0 && B * T_out >= 512 && !opt(OPT_NO_WGRAD_SPLIT);
+    return k >= 1 && k <= WS_MAXK && c_out >= 64 && (T_out % 4) == 0 && B * T_out >= 512 && !opt(OPT_NO_WGRAD_SPLIT);
 }
 static int wgrad_split_slices(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out) {
     const int64_t units = B * ceil_div(T_out, WS_TU);
@@ -306,6 +306,7 @@ int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, 
         dim3 grid((unsigned)ceil_div(c_in, 32), (unsigned)ceil_div(c_out, k < 8 ? 128 : 64), (unsigned)wgrad_split_slices(B, c_out, c_in, T_out));
         hipStream_t s = as_stream(stream);
         switch (k) {      // KT = the taps a wave really has: no idle accumulator tiles, registers left for the one-tap-ahead reads
+            case 1: hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1>), grid, dim3(256), 0, s, p); break;      // 1x1 convs: a plain [Cout x B*T] . [B*T x Cin] GEMM
             case 2: hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1>), grid, dim3(256), 0, s, p); break;
             case 3: hipLaunchKernelGGL((conv_wgrad_split_kernel<3, 1>), grid, dim3(256), 0, s, p); break;
             case 4: hipLaunchKernelGGL((conv_wgrad_split_kernel<4, 1>), grid, dim3(256), 0, s, p); break;

@@ -873,28 +873,35 @@ __device__ __forceinline__ float packed_weight(const PackParams &q, int mt, int 
 
 __global__ void pack_conv_kernel(const PackParams q) {
     const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (long long)q.MT_alloc * 32) q.biasp[e] = packed_bias(q, (int)e);   // bias over virtual rows
-    if (e == 0 && q.maxbits_clear) *q.maxbits_clear = 0u;
-    float v = 0.f;
-    if (e < total) {
-        const int sub = (int)(e & 3);
-        const int lane = (int)((e >> 2) & 63);
-        const int quad = (int)((e >> 8) & 1);
-        long long t = e >> 9;
-        const int nchunks = q.CP / (CK / 2);
-        const int chunk = (int)(t % nchunks);
-        t /= nchunks;
-        const int tap = (int)(t % q.KT);
-        const int mt = (int)(t / q.KT);
-        v = packed_weight(q, mt, tap, chunk, quad, lane, sub);
-        q.wp[e] = v;
+    const long long work = max(total, (long long)q.MT_alloc * 32);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && q.maxbits_clear) *q.maxbits_clear = 0u;
+    unsigned m = 0u;
+    // grid-stride: at most 1024 blocks however large the weight (the largest |w| below is ONE atomic per block: tens of thousands of
+    // same-address atomics -- the discriminators' 1024 x 1024 x 5 convs -- serialised into most of a millisecond per pack)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < work; e += (long long)gridDim.x * blockDim.x) {
+        if (e < (long long)q.MT_alloc * 32) q.biasp[e] = packed_bias(q, (int)e);   // bias over virtual rows
+        if (e < total) {
+            const int sub = (int)(e & 3);
+            const int lane = (int)((e >> 2) & 63);
+            const int quad = (int)((e >> 8) & 1);
+            long long t = e >> 9;
+            const int nchunks = q.CP / (CK / 2);
+            const int chunk = (int)(t % nchunks);
+            t /= nchunks;
+            const int tap = (int)(t % q.KT);
+            const int mt = (int)(t / q.KT);
+            const float v = packed_weight(q, mt, tap, chunk, quad, lane, sub);
+            q.wp[e] = v;
+            m = f16_maxkey(m, v);      // (finite magnitudes only: a NaN / Inf weight must not set the scale)
+        }
     }
     if (q.maxbits) {       // (uniform over the launch) the conv's largest weight, for the scale of the f16 planes
-        unsigned m = f16_maxkey(0u, v);      // (finite magnitudes only: a NaN / Inf weight must not set the scale)
+        __shared__ unsigned red[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(q.maxbits, m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(q.maxbits, max(max(red[0], red[1]), max(red[2], red[3])));
     }
 }
 
@@ -1382,7 +1389,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         ++h->pack_gen;
         q.maxbits = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + (h->pack_gen & 1);
         q.maxbits_clear = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + ((h->pack_gen + 1) & 1);
-        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 1024)), dim3(256), 0, s, q);
         VS_TRY(pack_split_planes(h, s, true));
     } else if (h->math) {
         // bf16-pipe arithmetic: fp32 fragments + bf16 planes in one launch
@@ -1392,7 +1399,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         hipLaunchKernelGGL(pack_conv_split_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, h->ws.p, npl);
     } else {
         const long long total = std::max<long long>((long long)n, (long long)h->MT_alloc * 32);
-        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 1024)), dim3(256), 0, s, q);
     }
     h->wino_packed = false;        // (the F(2,3) transform of the fp32 engine is rebuilt from Wp by the first launch that uses it)
     if (h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & VS_CONV_ADJOINT)) {

@@ -367,10 +367,9 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
     gy, x = gy.contiguous().float(), x.contiguous().float()
     B, Cout, Tout = gy.shape
     Cin, Tin = x.shape[1], x.shape[2]
-    if k == 1 and pad == 0 and Tin == Tout and Cout * Cin >= 64 * 64 and not L.switch("VS_NO_WGRAD_GEMM"):
-        # a 1x1 conv's weight gradient is a plain GEMM [Cout x B*T] . [B*T x Cin]: library territory (hipBLASLt through torch, as the
-        # wide discriminator layers already do); vs_conv_wgrad's 32 x 32 tiles with the positions split over the waves ran it at
-        # 7-9 TFLOP/s (tools/wgrad_breakdown.py: 94 calls, 11.8 ms of the config-3 step)
+    if k == 1 and pad == 0 and Tin == Tout and Cout * Cin >= 64 * 64 and L.switch("VS_WGRAD_GEMM"):
+        # A/B switch only (VS_WGRAD_GEMM=1): the library GEMM rounds 1-2 used for the 1x1 weight gradients; since round 3 they run on the
+        # split-bf16 weight-gradient kernel (csrc/conv_backward.hip conv_wgrad_split_kernel<1, 1>) like every other tap count
         PROFILER.note("wgrad 1x1 (library GEMM)", 2.0 * B * Cout * Cin * Tout)
         return torch.einsum("bot,bit->oi", gy, x).unsqueeze(2)
     if gy.data_ptr() % 16:       # (an offset view that is contiguous: the split kernel loads float4 rows of gy)
