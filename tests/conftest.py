@@ -23,10 +23,37 @@ def load_golden(name):
     return w, a
 
 
+def usable_cores():
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 cores under a quota of
+    16: OpenMP / OpenBLAS defaults oversubscribe 16-fold and the oracle-bound tests take minutes instead of seconds)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import visinger_oracle as orc
     orc.build()
+    n = usable_cores()
+    orc.set_threads(n)
+    try:                                  # numpy's BLAS (the oracle's attention matmuls) likewise
+        import threadpoolctl
+        orc._blas_limit = threadpoolctl.threadpool_limits(limits=n)
+    except Exception:
+        pass
     return orc
 
 

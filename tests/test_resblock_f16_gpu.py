@@ -30,7 +30,8 @@ def _block(C, k, seed):
 
 
 @pytest.mark.parametrize("C,k,B,T", [(32, 3, 2, 3000), (64, 3, 2, 1501), (32, 7, 1, 2048), (64, 7, 2, 777), (32, 11, 2, 1000), (64, 11, 1, 4096),
-                                     (64, 5, 1, 100), (32, 3, 3, 7), (64, 9, 1, 232), (32, 5, 1, 233)])
+                                     (64, 5, 1, 100), (32, 3, 3, 7), (64, 9, 1, 232), (32, 5, 1, 233), (128, 3, 2, 1000), (128, 7, 1, 515),
+                                     (128, 11, 1, 300), (32, 7, 2, 5000)])
 @pytest.mark.parametrize("pairs", [3, 1])
 def test_whole_resblock_launch_vs_oracle(oracle, vs_option, C, k, B, T, pairs):
     m, sd = _block(C, k, C + k)

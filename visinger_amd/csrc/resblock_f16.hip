@@ -43,21 +43,25 @@ struct ResblockParams {
     float scale;
     int B, C, T, K, nconv, nchunks;
     int H;                               // columns at each end of a tile that are not final outputs (sum of the pads, rounded up to 4)
-    int MP;                              // margin columns of the LDS tile on each side = the largest pad of the chain
+    int MP;                              // the largest pad of the chain (the kernel instance's margin is the next of 8 / 16 / 28)
     int fast_epi;
 };
 
-template <int NT_W, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockParams p) {
-    static_assert(WAVES_M * WAVES_N == 4, "four waves");
+// MP: margin columns of the tile on each side (>= the largest pad of the chain: 8 / 16 / 28 for k = 3 / 7 / 11).  A template constant: with
+// a run-time pitch the sixteen (column tile, channel group) cell addresses of the tile writes were hoisted out of the conv loop as
+// registers and spilled (112 B of scratch per lane: 0.5 GB of scratch stores per launch in the WRITE_SIZE counter, 27 reloads per conv);
+// with a constant pitch they are immediate offsets.
+template <int NT_W, int WAVES_M, int WAVES_N, int MP>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel(const ResblockParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;          // four waves (two workgroups per CU) or eight (one: 128 channels on 256-column tiles)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int KG = 4 * WAVES_M;                // channel groups of 8
-    const int MP = p.MP;
-    const int WT = BN + 2 * MP;                    // column pitch of the tile
-    const int TPL = KG * WT * 4;                   // dwords per plane
+    constexpr int WT = BN + 2 * MP;                // column pitch of the tile
+    constexpr int TPL = KG * WT * 4;               // dwords per plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned *const Tb = reinterpret_cast<unsigned *>(smem);
-    int *const smax = reinterpret_cast<int *>(Tb + 2 * TPL);       // [2][4]
+    int *const smax = reinterpret_cast<int *>(Tb + 2 * TPL);       // [2][NW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
     auto acc_row = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lhalf; };
 
     // margins of the tile: zeros, once (the waves only ever write their own BN columns)
-    for (int e = tid; e < 2 * KG * 2 * MP; e += 256) {
+    for (int e = tid; e < 2 * KG * 2 * MP; e += 64 * NW) {
         const int rowi = e / (2 * MP), c = e % (2 * MP);
         *reinterpret_cast<u32x4 *>(Tb + (rowi * WT + (c < MP ? c : BN + c)) * 4) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -122,6 +126,11 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
 
     for (int c = 0; c < p.nconv; ++c) {
         const bool second = (c & 1) != 0;
+        // (an opaque copy of the lane id per conv: the LDS addresses below are a few VALU to rebuild -- hoisted out of this loop as
+        //  loop-invariant registers they were spilled and reloaded once per conv)
+        int lane_c = lane;
+        asm volatile("" : "+v"(lane_c));
+        const int lh = lane_c >> 5, l5 = lane_c & 31;
         // ---- this conv's input in the accumulator registers: lrelu(x) (first conv of a pair) or lrelu(conv1 + b1) (second), zero outside
         unsigned mkey = 0u;
 #pragma unroll
@@ -135,21 +144,22 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
             }
         // ---- the tile's scale: largest exponent over the four waves (the barrier also ends every wave's reads of the previous tile)
         const int ebw = wave_max_u8(f16_key_exponent(mkey));
-        int *const slot = smax + (c & 1) * 4;
+        int *const slot = smax + (c & 1) * NW;
         if (lane == 0) slot[wave] = ebw;
         __syncthreads();
-        const int eb = max(max(max(slot[0], slot[1]), max(slot[2], slot[3])), F16_EB_MIN);
+        int eb = max(max(max(slot[0], slot[1]), max(slot[2], slot[3])), F16_EB_MIN);
+        if constexpr (NW == 8) eb = max(eb, max(max(slot[4], slot[5]), max(slot[6], slot[7])));
         const float sx = f16_scale(eb);
         // ---- split and write the tile
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
-            const int col = MP + wn * (NT_W * 32) + j * 32 + l31;
+            const int col = MP + wn * (NT_W * 32) + j * 32 + l5;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 unsigned d0[2], d1[2];
                 split_pair_h(acc[j][4 * g] * sx, acc[j][4 * g + 1] * sx, d0);
                 split_pair_h(acc[j][4 * g + 2] * sx, acc[j][4 * g + 3] * sx, d1);
-                unsigned *dst = Tb + ((wm * 4 + g) * WT + col) * 4 + lhalf * 2;
+                unsigned *dst = Tb + ((wm * 4 + g) * WT + col) * 4 + lh * 2;
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint2 *>(dst + pl * TPL) = make_uint2(d0[pl], d1[pl]);
             }
@@ -161,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
         // ---- weight fragments of the first step, then the conv
         const int d = p.dil[c];
         const int pad = d * (KT - 1) / 2;
-        const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (2 * 64) + lane;
+        const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (2 * 64) + lane_c;
         u32x4 a0[2], a1[2];
         auto load_a = [&](u32x4 (&dst)[2], int chunk, int tap) __attribute__((always_inline)) {
             const u32x4 *src = wbase + ((long long)tap * p.nchunks + chunk) * (2 * 64);
@@ -174,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
         __syncthreads();
         auto step = [&](u32x4 (&acur)[2], u32x4 (&apre)[2]) __attribute__((always_inline)) {
             if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
-            mma_step(acur, Tb + ((chunk * 2 + lhalf) * WT + MP + wn * (NT_W * 32) + l31 + tap * d - pad) * 4);
+            mma_step(acur, Tb + ((chunk * 2 + lh) * WT + MP + wn * (NT_W * 32) + l5 + tap * d - pad) * 4);
             if (++tap == KT) { tap = 0; ++chunk; }
             ++s;
         };
@@ -187,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
         const float *const bias = p.bias[c] + wm * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bv = bias[acc_row(r)];
+            const float bv = bias[(r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
             for (int j = 0; j < NT_W; ++j) {
                 const float v = fmaf(acc[j][r], inv, bv);
@@ -199,6 +209,8 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
     __syncthreads();                         // the tile is consumed: its space becomes the epilogue's
 
     // ---- epilogue: y = (x [+ acc]) * scale on the exact columns [H, BN - H) of the tile
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     const int tile_row0 = wm * 32;
     const bool has_acc = p.acc != nullptr;
     float *const yb = p.y + (long long)b * p.y_bs;
@@ -206,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
     if (p.fast_epi && (n0 + NOUT <= p.T)) {
         constexpr int CW = 32 * NT_W, LPR = CW / 4, RPI = 64 / LPR, NIT = 8 / RPI;
         float *const Lw = smem + wave * 8 * CW;
-        const int lrow = lane / LPR, c4 = (lane % LPR) * 4;
+        const int lrow = lane_e / LPR, c4 = (lane_e % LPR) * 4;
         const int ctile = wn * CW + c4;                          // column within the tile
         const bool live = (ctile >= p.H) && (ctile < BN - p.H);  // H % 4 == 0: a float4 is all in or all out
         const long long goff0 = (long long)(tile_row0 + lrow) * p.T + t0 + ctile;
@@ -223,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < NT_W; ++j) Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = xr[j][4 * ps + q];
+                for (int j = 0; j < NT_W; ++j) Lw[(q + 4 * (lane_e >> 5)) * CW + 32 * j + (lane_e & 31)] = xr[j][4 * ps + q];
             if (live) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
@@ -253,27 +265,38 @@ __global__ void __launch_bounds__(256, 2) resblock_f16_kernel(const ResblockPara
     }
 }
 
+static int margin_of(int maxpad) { return maxpad <= 8 ? 8 : (maxpad <= 16 ? 16 : RB_MAXPAD); }
+
 template <int NT_W, int WAVES_M, int WAVES_N>
 static size_t resblock_lds(int MP) {
     constexpr int BN = 32 * NT_W * WAVES_N, KG = 4 * WAVES_M;
-    return std::max<size_t>((size_t)2 * KG * (BN + 2 * MP) * 16 + 32, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
+    return std::max<size_t>((size_t)2 * KG * (BN + 2 * MP) * 16 + 64, (size_t)WAVES_M * WAVES_N * 8 * (32 * NT_W) * sizeof(float));
 }
 
-template <int NT_W, int WAVES_M, int WAVES_N>
-static int launch_resblock_cfg(const ResblockParams &p, hipStream_t s) {
+template <int NT_W, int WAVES_M, int WAVES_N, int MP>
+static int launch_resblock_mp(const ResblockParams &p, hipStream_t s) {
     constexpr int BN = 32 * NT_W * WAVES_N;
-    auto kern = resblock_f16_kernel<NT_W, WAVES_M, WAVES_N>;
-    const size_t lds = resblock_lds<NT_W, WAVES_M, WAVES_N>(p.MP);
+    auto kern = resblock_f16_kernel<NT_W, WAVES_M, WAVES_N, MP>;
+    const size_t lds = resblock_lds<NT_W, WAVES_M, WAVES_N>(MP);
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)ceil_div(p.T, BN - 2 * p.H), 1, (unsigned)p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("resblock_f16_kernel<%d, %d, %d>", NT_W, WAVES_M, WAVES_N);
+    set_last_kernel("resblock_f16_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, MP);
     return VS_OK;
+}
+
+template <int NT_W, int WAVES_M, int WAVES_N>
+static int launch_resblock_cfg(const ResblockParams &p, hipStream_t s) {
+    switch (margin_of(p.MP)) {
+        case 8: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, 8>(p, s);
+        case 16: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, 16>(p, s);
+        default: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, RB_MAXPAD>(p, s);
+    }
 }
 
 }  // namespace vs
@@ -297,8 +320,8 @@ int vs_resblock_supported(vs_conv_t *const *convs, int nconv) {
         MP = std::max(MP, c->pad);
     }
     H = (H + 3) & ~3;
-    if (C == 128)       // 128-column tiles, two workgroups per CU: the all-channel tile must fit half the LDS
-        return 128 - 2 * H >= 64 && 2 * (resblock_lds<4, 4, 1>(MP) + 64) <= 160 * 1024;
+    if (C == 128)       // 256-column tiles on eight waves, one workgroup per CU (160 KB of LDS hold the all-channel tile up to a margin of 28)
+        return 256 - 2 * H >= 64 && resblock_lds<4, 4, 2>(margin_of(MP)) <= 160 * 1024;
     return 256 - 2 * H >= 64;
 }
 
@@ -341,7 +364,13 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
         if (opt(OPT_RB_TILE256) || p.H <= 12 || 512 - 2 * p.H > io->T + 256) return launch_resblock_cfg<2, 1, 4>(p, s);
         return launch_resblock_cfg<4, 1, 4>(p, s);
     }
-    if (C == 128) return launch_resblock_cfg<4, 4, 1>(p, s);
+    if (C == 128) {
+        // a single pair: 128-column tiles on four waves, two workgroups per CU (4.4 against 4.6 ms at k = 3), while the tile fits half the LDS;
+        // longer chains: 256 columns on eight waves, one workgroup per CU -- half the halo per output (whole k = 3 block 4.0 against 4.25 ms)
+        if (nconv == 2 && 128 - 2 * p.H >= 64 && 2 * (resblock_lds<4, 4, 1>(margin_of(p.MP)) + 64) <= 160 * 1024)
+            return launch_resblock_cfg<4, 4, 1>(p, s);
+        return launch_resblock_cfg<4, 4, 2>(p, s);
+    }
     return launch_resblock_cfg<4, 2, 2>(p, s);
 }
 

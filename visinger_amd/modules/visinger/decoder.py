@@ -177,15 +177,15 @@ class ResBlock1(torch.nn.Module):
         per = L.switch("VS_RESBLOCK_PAIRS")                                     # pairs per launch (A/B switch); 0: by measurement
         if not per:
             # tools/resblock_bench.py, B = 32 production shapes (ms: whole block / pair by pair / conv by conv):
-            #   32 ch:  k=3 1.8 / 2.3 / 3.6   k=7 2.9 / 3.5 / 4.5   k=11 4.6 / 4.6 / 5.5      -> whole block
-            #   64 ch:  k=3 2.7 / 3.5 / 4.4   k=7 5.7 / 5.6 / 6.1   k=11 11.0 / 8.2 / 8.0     -> whole, pairs, conv by conv
-            #   128 ch: k=3 14 / 5.1 / 5.6    k=7 - / 10.4 / 8.6    k=11 (tile does not fit)  -> pairs at k = 3 only
+            #   32 ch:  k=3 1.6 / 2.1 / 3.6   k=7 2.6 / 3.0 / 4.5   k=11 4.0 / 4.1 / 5.4      -> whole block
+            #   64 ch:  k=3 2.3 / 2.8 / 4.3   k=7 5.3 / 4.9 / 6.0   k=11 10.4 / 7.3 / 7.9     -> whole, pairs, pairs
+            #   128 ch: k=3 4.0 / 4.4 / 5.2   k=7 10.3 / 9.0 / 8.6  k=11 21 / 14 / 11.9       -> whole block at k = 3 only (8 waves, 256 columns)
             if C == 32:
                 per = n
             elif C == 64:
-                per = n if k <= 5 else (1 if k <= 7 else 0)
+                per = n if k <= 5 else 1
             else:
-                per = 1 if k <= 3 else 0
+                per = n if k <= 3 else 0
             if not per:
                 return None
         groups = [ops[2 * i:2 * (i + per)] for i in range(0, n, per)]
