@@ -152,8 +152,9 @@ VS_API int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream);
  * a11  A whole MRF residual block (or any even-length prefix / suffix of its conv chain) in ONE launch on the split-f16 arithmetic:
  *      for each pair (conv1, conv2):  x = conv2(lrelu(conv1(lrelu(x)))) + x;   y = (x [+ io->out[0].acc]) * io->out[0].scale
  *      (modules/visinger/decoder.py:91-104; the accumulate input and the scale carry the MRF sum of decoder.py:52-56).
- *      convs = {convs1[0], convs2[0], convs1[1], convs2[1], ...}: 2, 4 or 6 handles of 32 or 64 channels, one odd kernel size <= 11,
- *      "same" padding, all in VS_MATH_SPLIT3.  The residual stream stays in registers (fp32) between the pairs; each tile recomputes
+ *      convs = {convs1[0], convs2[0], convs1[1], convs2[1], ...}: 2, 4 or 6 handles of 32, 64 or 128 channels, one odd kernel size <= 11,
+ *      "same" padding, all in VS_MATH_SPLIT3 (x / acc / y fp32 tensors) or all in VS_MATH_BF16 (x / acc / y bf16-RESIDENT, x_dtype =
+ *      y_dtype = VS_DTYPE_BF16: BASELINE.json configs[4]); the other combinations are refused.  The residual stream stays in registers (fp32) between the pairs; each tile recomputes
  *      its receptive halo instead of exchanging it.  io: x, B, T, in_act = VS_IN_LRELU, out[0].y / acc / scale; nothing else.        */
 VS_API int vs_resblock_supported(vs_conv_t *const *convs, int nconv);
 VS_API int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *io, void *stream);

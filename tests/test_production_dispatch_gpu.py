@@ -171,6 +171,8 @@ def test_config5_whole_model_bf16_resident_vs_oracle(oracle, capsys):
     wav, f0_pred = ret["wav_out"], ret["f0_pred"]
     assert wav.shape == (B, T * 256) and bool(torch.isfinite(wav).all())
     assert any(n.startswith("conv_split_kernel_bf16io<") for n in names) and "relattn_bf16_kernel<8, 32, 1>" in names, sorted(names)
+    for must in ("resblock_bf16_kernel<2, 1, 4, 8>", "resblock_bf16_kernel<4, 1, 4, 16>", "resblock_bf16_kernel<4, 2, 2, 8>", "resblock_bf16_kernel<4, 4, 2, 8>"):
+        assert must in names, (must, sorted(names))            # whole MRF blocks on bf16-resident tensors
     oracle.set_threads(bench.usable_cores())
     voiced_dev = (f0_pred[:, :, 1] <= 0).cpu().numpy()
     # (the voicing decision is a threshold on a bf16-computed value: every frame takes the device's decision; agreement is asserted

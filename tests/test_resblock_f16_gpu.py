@@ -2,6 +2,8 @@
 arithmetic, against the fp64 oracle's ResBlock1: every kernel size of the generator and two more, both widths, the whole block and pair by
 pair, tiles in the interior / at both ends of the sequence / a sequence shorter than one tile / lengths that are no multiple of 4
 (element-wise epilogue), the MRF accumulate input and scale, non-finite inputs, and the dispatch of ResBlock1 itself."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -82,3 +84,85 @@ def test_resblock_nonfinite_inputs_stay_local():
     assert bool((bad <= want).all()) and bool(bad[1000]) and bool(bad[3000])       # nothing outside the receptive cone
     ok = ~want
     assert float((y[0][:, ok] - clean[0][:, ok]).abs().max()) <= 1e-5 * float(clean.abs().max())
+
+
+def _bf16_emulation(m, x, acc=None, scale=1.0, pairs=3):
+    """resblock_bf16_kernel's arithmetic restated with torch fp64 convs: leaky-relu in fp32, operands rounded to bf16 (RNE), exact products,
+    residual stream and bias in fp32 registers (here fp64: the difference is the fp32 accumulation order), ONE rounding to bf16 at the end
+    of a launch (`pairs` pairs per launch: the tensors between launches are bf16-resident)"""
+    import torch.nn.functional as F
+    bf = lambda t: t.float().bfloat16().double()
+    cur = x.double()
+    n = len(m.convs1)
+    for i, (c1, c2) in enumerate(zip(m.convs1, m.convs2)):
+        def w(c):
+            from visinger_amd.ops import weightnorm_fold
+            return bf(weightnorm_fold(c.weight_v.detach(), c.weight_g.detach()))       # the fp32 weight the library rounds (a12)
+        xt = F.conv1d(bf(F.leaky_relu(cur.float(), 0.1)), w(c1), c1.bias.double(), padding=c1.padding[0], dilation=c1.dilation[0])
+        xt = F.conv1d(bf(F.leaky_relu(xt.float(), 0.1)), w(c2), c2.bias.double(), padding=c2.padding[0])
+        cur = xt + cur
+        if (i + 1) % pairs == 0 and i + 1 < n:
+            cur = bf(cur)
+    if acc is not None:
+        cur = cur + acc.double()
+    return cur * scale
+
+
+@pytest.mark.parametrize("C,k,B,T", [(32, 3, 2, 3000), (64, 3, 2, 1501), (32, 7, 1, 2048), (64, 7, 2, 777), (32, 11, 2, 1000), (64, 11, 1, 1024),
+                                     (32, 3, 3, 7), (64, 9, 1, 232), (128, 3, 2, 1000), (128, 7, 1, 515), (128, 11, 1, 300)])
+@pytest.mark.parametrize("pairs", [3, 1])
+def test_bf16_resident_resblock_launch_vs_its_arithmetic(vs_option, C, k, B, T, pairs):
+    """resblock_bf16_kernel (VS_MATH_BF16 on bf16-RESIDENT tensors, BASELINE configs[4]): the launch against an fp64 restatement of exactly
+    its arithmetic (bf16 roundings of operands, weights as the library folds them, bf16 tensors between launches, one final rounding).
+    What may differ is the order of the fp32 accumulation, i.e. values that sit on a bf16 rounding boundary."""
+    from visinger_amd.modules.hipconv import set_conv_math
+    m, _ = _block(C, k, C + k)
+    set_conv_math(m, L.MATH_BF16)
+    vs_option("VS_RESBLOCK_PAIRS", pairs)
+    g = torch.Generator(device="cuda").manual_seed(C * 7 + k + T)
+    x = (2.0 * torch.randn(B, C, T, device="cuda", generator=g)).bfloat16()
+    acc = torch.randn(B, C, T, device="cuda", generator=g).bfloat16()
+    x0 = x.clone()
+    with torch.no_grad():
+        y = m._run_fused(x, torch.empty_like(x), first=True, scale=1.0)
+        name = m.convs1[0]._op().kernel_instance()
+        acc_t = acc.clone()
+        m._run_fused(x, acc_t, first=False, scale=1.0 / 3.0)
+        want = _bf16_emulation(m, x, pairs=pairs)
+        want_acc = _bf16_emulation(m, x, acc, 1.0 / 3.0, pairs=pairs)
+    assert name.startswith("resblock_bf16_kernel<"), name
+    assert y.dtype == torch.bfloat16 and torch.equal(x, x0)
+    for got, ref in ((y, want), (acc_t, want_acc)):
+        r = ref.float().bfloat16()
+        same = float((got == r).float().mean())
+        rms = float(ref.pow(2).mean().sqrt())
+        ulp = ref.abs().clamp_min(1e-30).log2().floor().exp2() * 2.0 ** -7            # spacing of bf16 at the reference value
+        excess = float(((got.double() - ref).abs() - 0.5 * ulp).clamp_min(0).max()) / rms
+        if os.environ.get("VS_TEST_VERBOSE"):
+            print(f"\n   C={C} k={k} T={T} pairs={pairs}: bit-identical {same:.5f}, beyond half an ulp by at most {excess:.2e} of the rms")
+        # the launch = the restated arithmetic up to the error of the fp32 accumulation chains: an operand of a later conv, a tensor
+        # between two launches, or the output itself may sit on a bf16 boundary and round the other way (torch's own fp32 conv in place
+        # of the fp64 one leaves 91-99 % of these outputs bit-identical; the MFMA's summation order 79-99.9 %).  Every output within half
+        # a bf16 ulp of the restatement + 1.5e-2 of the rms (one such flip carried down the residual stream), the rms difference at the
+        # size of the final rounding alone (2^-9 / sqrt(3) relative); the arithmetic's own error against fp64 is 3e-3 of the rms
+        assert excess <= 1.5e-2, excess
+        assert same >= 0.75, same
+        assert float((got.double() - ref).pow(2).mean().sqrt()) <= 2e-3 * rms
+
+
+def test_resblock_arithmetic_and_tensor_type_must_agree():
+    """VS_MATH_SPLIT3 takes fp32 tensors and VS_MATH_BF16 bf16-resident ones: the C ABI refuses the cross combinations (no silent conversion)"""
+    from visinger_amd.modules.hipconv import set_conv_math
+    from visinger_amd.ops import resblock_forward
+    m, _ = _block(32, 3, 1)
+    ops = [c._op() for pair in zip(m.convs1, m.convs2) for c in pair]
+    xb = torch.randn(1, 32, 256, device="cuda").bfloat16()
+    with pytest.raises(L.VisingerHipError, match="fp32 tensors with VS_MATH_SPLIT3"):
+        resblock_forward(ops, xb, torch.empty_like(xb))
+    set_conv_math(m, L.MATH_BF16)
+    ops = [c._op() for pair in zip(m.convs1, m.convs2) for c in pair]
+    xf = torch.randn(1, 32, 256, device="cuda")
+    with pytest.raises(L.VisingerHipError, match="bf16-resident tensors with VS_MATH_BF16"):
+        resblock_forward(ops, xf, torch.empty_like(xf))
+    with pytest.raises(L.VisingerHipError, match="acc is"):
+        resblock_forward(ops, xb, torch.empty_like(xb), acc=xf)

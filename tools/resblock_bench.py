@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The whole-resblock launch (csrc/resblock_f16.hip, VS_MATH_SPLIT3) against an fp64 torch resblock (parity) and against the
 one-launch-per-conv / one-launch-per-pair forms (time) at the generator's production shapes.  GPU only.
-   python tools/resblock_bench.py [check|time|all]"""
+   python tools/resblock_bench.py [check|time|all|bf16]
+(bf16: resblock_bf16_kernel -- plain bf16 operands on bf16-resident tensors, BASELINE config 5 -- against fp64 and against the per-pair /
+per-conv bf16 launches, parity and time)"""
 import os
 import sys
 
@@ -101,3 +103,38 @@ if what in ("time", "all"):
             print(f"resblock C={C} k={k} T={T}: " + " | ".join(res), flush=True)
     L.set_option("VS_RESBLOCK_PAIRS", 0)
     L.set_option("VS_NO_RESBLOCK_FUSED", 0)
+
+
+if what == "bf16":
+    from visinger_amd.modules.hipconv import set_activation_storage
+    B = int(os.environ.get("RB_B", 8))
+    for C, T in ((128, 65536), (64, 131072), (32, 262144)):
+        for k in (3, 7, 11):
+            m = block(C, k)
+            set_conv_math(m, L.MATH_BF16)
+            x = torch.randn(B, C, T, device="cuda").bfloat16()
+            want = ref64(m, x[:1, :, :4096].float())
+            rms = want.pow(2).mean().sqrt().item()
+            res = []
+            for label, fused, pairs, norespair in (("conv by conv", 0, 0, 1), ("respair (round 2)", 0, 0, 0), ("1 pair/launch", 1, 1, 0), ("whole block", 1, 3, 0)):
+                L.set_option("VS_RESBLOCK_PAIRS", pairs)
+                L.set_option("VS_NO_RESBLOCK_FUSED", 0 if fused else 1)
+                L.set_option("VS_NO_RESPAIR", norespair)
+                out = torch.empty_like(x)
+                with torch.no_grad():
+                    for _ in range(2):
+                        m._run_fused(x, out, first=True, scale=1.0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        m._run_fused(x, out, first=True, scale=1.0)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    small = torch.empty_like(x[:1, :, :4096])
+                    m._run_fused(x[:1, :, :4096].contiguous(), small, first=True, scale=1.0)
+                err = (small.double() - want).pow(2).mean().sqrt().item() / rms
+                ms = e0.elapsed_time(e1) / 3
+                res.append(f"{label}: {ms:6.2f} ms rms err {err:.1e} [{m.convs1[0]._op().kernel_instance()}]")
+            print(f"bf16 resblock C={C} k={k} B={B} T={T}: " + " | ".join(res), flush=True)
+    for o in ("VS_RESBLOCK_PAIRS", "VS_NO_RESBLOCK_FUSED", "VS_NO_RESPAIR"):
+        L.set_option(o, 0)

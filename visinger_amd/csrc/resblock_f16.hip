@@ -45,23 +45,28 @@ struct ResblockParams {
     int H;                               // columns at each end of a tile that are not final outputs (sum of the pads, rounded up to 4)
     int MP;                              // the largest pad of the chain (the kernel instance's margin is the next of 8 / 16 / 28)
     int fast_epi;
+    int bf16;                            // VS_MATH_BF16 on bf16-resident tensors (x, y, acc point at bf16 elements; strides in elements)
 };
 
 // MP: margin columns of the tile on each side (>= the largest pad of the chain: 8 / 16 / 28 for k = 3 / 7 / 11).  A template constant: with
 // a run-time pitch the sixteen (column tile, channel group) cell addresses of the tile writes were hoisted out of the conv loop as
 // registers and spilled (112 B of scratch per lane: 0.5 GB of scratch stores per launch in the WRITE_SIZE counter, 27 reloads per conv);
 // with a constant pitch they are immediate offsets.
-template <int NT_W, int WAVES_M, int WAVES_N, int MP>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel(const ResblockParams p) {
+// PLANES = 2: the split-f16 x3 arithmetic (VS_MATH_SPLIT3).  PLANES = 1: operands rounded to bf16, one product (VS_MATH_BF16, BASELINE.json's
+// long-form configuration): no scale, half the tile; PB: x, acc and y are bf16-RESIDENT tensors (vs_dtype; only with PLANES = 1).
+template <int NT_W, int WAVES_M, int WAVES_N, int MP, int PLANES, bool PB>
+__device__ __forceinline__ void resblock_body(const ResblockParams &p) {
     constexpr int NW = WAVES_M * WAVES_N;          // four waves (two workgroups per CU) or eight (one: 128 channels on 256-column tiles)
     static_assert(NW == 4 || NW == 8, "four or eight waves");
+    static_assert(PLANES == 2 || (PLANES == 1), "two f16 planes or one bf16 plane");
+    static_assert(!PB || PLANES == 1, "bf16-resident tensors go with the plain-bf16 arithmetic");
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int KG = 4 * WAVES_M;                // channel groups of 8
     constexpr int WT = BN + 2 * MP;                // column pitch of the tile
     constexpr int TPL = KG * WT * 4;               // dwords per plane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned *const Tb = reinterpret_cast<unsigned *>(smem);
-    int *const smax = reinterpret_cast<int *>(Tb + 2 * TPL);       // [2][NW]
+    int *const smax = reinterpret_cast<int *>(Tb + PLANES * TPL);  // [2][NW]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
     auto acc_row = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lhalf; };
 
     // margins of the tile: zeros, once (the waves only ever write their own BN columns)
-    for (int e = tid; e < 2 * KG * 2 * MP; e += 64 * NW) {
+    for (int e = tid; e < PLANES * KG * 2 * MP; e += 64 * NW) {
         const int rowi = e / (2 * MP), c = e % (2 * MP);
         *reinterpret_cast<u32x4 *>(Tb + (rowi * WT + (c < MP ? c : BN + c)) * 4) = u32x4{0u, 0u, 0u, 0u};
     }
@@ -85,16 +90,21 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
     bool inside[NT_W];
     f32x16 xr[NT_W], acc[NT_W];
     {
+        const char *const xbase = reinterpret_cast<const char *>(p.x) + (long long)b * p.x_bs * (PB ? 2 : 4);
         const __amdgpu_buffer_rsrc_t xsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + (long long)b * p.x_bs), 0, (int)((long long)p.C * p.T * 4), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)xbase, 0, (int)((long long)p.C * p.T * (PB ? 2 : 4)), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
             const int n = t0 + wn * (NT_W * 32) + j * 32 + l31;
             inside[j] = (n >= 0) && (n < p.T);
             const int nc = min(max(n, 0), p.T - 1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                xr[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, ((wm * 32 + acc_row(r)) * p.T + nc) * 4, 0, 0));
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (PB)
+                    xr[j][r] = u2f((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(xsrc, ((wm * 32 + acc_row(r)) * p.T + nc) * 2, 0, 0) << 16);
+                else
+                    xr[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, ((wm * 32 + acc_row(r)) * p.T + nc) * 4, 0, 0));
+            }
         }
 #pragma unroll
         for (int j = 0; j < NT_W; ++j)
@@ -103,24 +113,28 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
     }
 
     // one (chunk, tap) step: NT_W column tiles x 3 cross products; the planes of tile j+1 are read under the MFMAs of tile j
-    auto mma_step = [&](const u32x4 (&acur)[2], const unsigned *xs) __attribute__((always_inline)) {
-        u32x4 bf[2], bn[2];
+    auto mma_step = [&](const u32x4 (&acur)[PLANES], const unsigned *xs) __attribute__((always_inline)) {
+        u32x4 bf[PLANES], bn[PLANES];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL);
+        for (int pl = 0; pl < PLANES; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL);
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
             if (j + 1 < NT_W) {
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) bn[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL + (j + 1) * 128);
+                for (int pl = 0; pl < PLANES; ++pl) bn[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL + (j + 1) * 128);
             }
             __builtin_amdgcn_sched_barrier(0);
-            auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[ta]), __builtin_bit_cast(f16x8, bf[tb]), acc[j], 0, 0, 0);
-            };
-            mm(1, 0); mm(0, 1); mm(0, 0);        // smallest terms first
+            if constexpr (PLANES == 2) {
+                auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[ta]), __builtin_bit_cast(f16x8, bf[tb]), acc[j], 0, 0, 0);
+                };
+                mm(1, 0); mm(0, 1); mm(0, 0);        // smallest terms first
+            } else {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[0]), __builtin_bit_cast(bf16x8, bf[0]), acc[j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) bf[pl] = bn[pl];
+            for (int pl = 0; pl < PLANES; ++pl) bf[pl] = bn[pl];
         }
     };
 
@@ -140,28 +154,39 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
                 float v = second ? acc[j][r] : xr[j][r];
                 v = inside[j] ? fmaxf(v, 0.1f * v) : 0.f;
                 acc[j][r] = v;
-                mkey = f16_maxkey(mkey, v);
+                if constexpr (PLANES == 2) mkey = f16_maxkey(mkey, v);
             }
         // ---- the tile's scale: largest exponent over the four waves (the barrier also ends every wave's reads of the previous tile)
-        const int ebw = wave_max_u8(f16_key_exponent(mkey));
-        int *const slot = smax + (c & 1) * NW;
-        if (lane == 0) slot[wave] = ebw;
-        __syncthreads();
-        int eb = max(max(max(slot[0], slot[1]), max(slot[2], slot[3])), F16_EB_MIN);
-        if constexpr (NW == 8) eb = max(eb, max(max(slot[4], slot[5]), max(slot[6], slot[7])));
-        const float sx = f16_scale(eb);
+        int eb = 127;
+        float sx = 1.f;
+        if constexpr (PLANES == 2) {
+            const int ebw = wave_max_u8(f16_key_exponent(mkey));
+            int *const slot = smax + (c & 1) * NW;
+            if (lane == 0) slot[wave] = ebw;
+            __syncthreads();
+            eb = max(max(max(slot[0], slot[1]), max(slot[2], slot[3])), F16_EB_MIN);
+            if constexpr (NW == 8) eb = max(eb, max(max(slot[4], slot[5]), max(slot[6], slot[7])));
+            sx = f16_scale(eb);
+        } else {
+            __syncthreads();
+        }
         // ---- split and write the tile
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
             const int col = MP + wn * (NT_W * 32) + j * 32 + l5;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                unsigned d0[2], d1[2];
-                split_pair_h(acc[j][4 * g] * sx, acc[j][4 * g + 1] * sx, d0);
-                split_pair_h(acc[j][4 * g + 2] * sx, acc[j][4 * g + 3] * sx, d1);
+                unsigned d0[PLANES], d1[PLANES];
+                if constexpr (PLANES == 2) {
+                    split_pair_h(acc[j][4 * g] * sx, acc[j][4 * g + 1] * sx, d0);
+                    split_pair_h(acc[j][4 * g + 2] * sx, acc[j][4 * g + 3] * sx, d1);
+                } else {
+                    split_pair<1>(acc[j][4 * g], acc[j][4 * g + 1], d0);
+                    split_pair<1>(acc[j][4 * g + 2], acc[j][4 * g + 3], d1);
+                }
                 unsigned *dst = Tb + ((wm * 4 + g) * WT + col) * 4 + lh * 2;
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) *reinterpret_cast<uint2 *>(dst + pl * TPL) = make_uint2(d0[pl], d1[pl]);
+                for (int pl = 0; pl < PLANES; ++pl) *reinterpret_cast<uint2 *>(dst + pl * TPL) = make_uint2(d0[pl], d1[pl]);
             }
         }
 #pragma unroll
@@ -171,18 +196,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
         // ---- weight fragments of the first step, then the conv
         const int d = p.dil[c];
         const int pad = d * (KT - 1) / 2;
-        const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (2 * 64) + lane_c;
-        u32x4 a0[2], a1[2];
-        auto load_a = [&](u32x4 (&dst)[2], int chunk, int tap) __attribute__((always_inline)) {
-            const u32x4 *src = wbase + ((long long)tap * p.nchunks + chunk) * (2 * 64);
-            dst[0] = src[0];
-            dst[1] = src[64];
+        const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (PLANES * 64) + lane_c;
+        u32x4 a0[PLANES], a1[PLANES];
+        auto load_a = [&](u32x4 (&dst)[PLANES], int chunk, int tap) __attribute__((always_inline)) {
+            const u32x4 *src = wbase + ((long long)tap * p.nchunks + chunk) * (PLANES * 64);
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) dst[pl] = src[pl * 64];
         };
         int pc = 0, pt = 0, chunk = 0, tap = 0, s = 0;
         auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; ++pc; } };
         load_a(a0, pc, pt); advance();
         __syncthreads();
-        auto step = [&](u32x4 (&acur)[2], u32x4 (&apre)[2]) __attribute__((always_inline)) {
+        auto step = [&](u32x4 (&acur)[PLANES], u32x4 (&apre)[PLANES]) __attribute__((always_inline)) {
             if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
             mma_step(acur, Tb + ((chunk * 2 + lh) * WT + MP + wn * (NT_W * 32) + l5 + tap * d - pad) * 4);
             if (++tap == KT) { tap = 0; ++chunk; }
@@ -193,7 +218,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
             if (s < nsteps) step(a1, a0);
         }
         // ---- scale out, bias in; the second conv of a pair adds the residual stream
-        const float inv = f16_inv_scale(eb) * p.wscale[c][1];
+        const float inv = (PLANES == 2) ? f16_inv_scale(eb) * p.wscale[c][1] : 1.f;
         const float *const bias = p.bias[c] + wm * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -215,6 +240,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
     const bool has_acc = p.acc != nullptr;
     float *const yb = p.y + (long long)b * p.y_bs;
     const float *const accp = has_acc ? p.acc + (long long)b * p.acc_bs : nullptr;
+    unsigned short *const yh = reinterpret_cast<unsigned short *>(p.y) + (long long)b * p.y_bs;                 // PB: bf16 elements
+    const unsigned short *const acch = reinterpret_cast<const unsigned short *>(p.acc) + (long long)b * p.acc_bs;
     if (p.fast_epi && (n0 + NOUT <= p.T)) {
         constexpr int CW = 32 * NT_W, LPR = CW / 4, RPI = 64 / LPR, NIT = 8 / RPI;
         float *const Lw = smem + wave * 8 * CW;
@@ -227,8 +254,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)
-                    a4[ps][it] = *reinterpret_cast<const float4 *>(accp + goff0 + (long long)(8 * ps + it * RPI) * p.T);
+                for (int it = 0; it < NIT; ++it) {
+                    if constexpr (PB) a4[ps][it] = bf4_to_f4(*reinterpret_cast<const uint2 *>(acch + goff0 + (long long)(8 * ps + it * RPI) * p.T));
+                    else a4[ps][it] = *reinterpret_cast<const float4 *>(accp + goff0 + (long long)(8 * ps + it * RPI) * p.T);
+                }
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -242,7 +271,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
                     float4 v = *reinterpret_cast<const float4 *>(Lw + (it * RPI + lrow) * CW + c4);
                     if (has_acc) { v.x += a4[ps][it].x; v.y += a4[ps][it].y; v.z += a4[ps][it].z; v.w += a4[ps][it].w; }
                     if (p.scale != 1.f) { v.x *= p.scale; v.y *= p.scale; v.z *= p.scale; v.w *= p.scale; }
-                    *reinterpret_cast<float4 *>(yb + goff0 + (long long)(8 * ps + it * RPI) * p.T) = v;
+                    if constexpr (PB) *reinterpret_cast<uint2 *>(yh + goff0 + (long long)(8 * ps + it * RPI) * p.T) = f4_to_bf4(v);
+                    else *reinterpret_cast<float4 *>(yb + goff0 + (long long)(8 * ps + it * RPI) * p.T) = v;
                 }
             }
         }
@@ -257,27 +287,44 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel
             for (int r = 0; r < 16; ++r) {
                 const long long off = (long long)(tile_row0 + acc_row(r)) * p.T + nc;
                 float v = xr[j][r];
-                if (has_acc) v += accp[off];
-                v *= p.scale;
-                if (okc) yb[off] = v;
+                if constexpr (PB) {
+                    if (has_acc) v += u2f((unsigned)acch[off] << 16);
+                    v *= p.scale;
+                    if (okc) yh[off] = (unsigned short)(rne_bf16(v) >> 16);
+                } else {
+                    if (has_acc) v += accp[off];
+                    v *= p.scale;
+                    if (okc) yb[off] = v;
+                }
             }
         }
     }
 }
 
+template <int NT_W, int WAVES_M, int WAVES_N, int MP>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_f16_kernel(const ResblockParams p) {
+    resblock_body<NT_W, WAVES_M, WAVES_N, MP, 2, false>(p);
+}
+
+// VS_MATH_BF16 on bf16-resident tensors (BASELINE.json configs[4])
+template <int NT_W, int WAVES_M, int WAVES_N, int MP>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N, 2) resblock_bf16_kernel(const ResblockParams p) {
+    resblock_body<NT_W, WAVES_M, WAVES_N, MP, 1, true>(p);
+}
+
 static int margin_of(int maxpad) { return maxpad <= 8 ? 8 : (maxpad <= 16 ? 16 : RB_MAXPAD); }
 
 template <int NT_W, int WAVES_M, int WAVES_N>
-static size_t resblock_lds(int MP) {
+static size_t resblock_lds(int MP, int planes = 2) {
     constexpr int BN = 32 * NT_W * WAVES_N, KG = 4 * WAVES_M;
-    return std::max<size_t>((size_t)2 * KG * (BN + 2 * MP) * 16 + 64, (size_t)WAVES_M * WAVES_N * 8 * (32 * NT_W) * sizeof(float));
+    return std::max<size_t>((size_t)planes * KG * (BN + 2 * MP) * 16 + 64, (size_t)WAVES_M * WAVES_N * 8 * (32 * NT_W) * sizeof(float));
 }
 
-template <int NT_W, int WAVES_M, int WAVES_N, int MP>
+template <int NT_W, int WAVES_M, int WAVES_N, int MP, bool BF>
 static int launch_resblock_mp(const ResblockParams &p, hipStream_t s) {
     constexpr int BN = 32 * NT_W * WAVES_N;
-    auto kern = resblock_f16_kernel<NT_W, WAVES_M, WAVES_N, MP>;
-    const size_t lds = resblock_lds<NT_W, WAVES_M, WAVES_N>(MP);
+    auto kern = BF ? resblock_bf16_kernel<NT_W, WAVES_M, WAVES_N, MP> : resblock_f16_kernel<NT_W, WAVES_M, WAVES_N, MP>;
+    const size_t lds = resblock_lds<NT_W, WAVES_M, WAVES_N>(MP, BF ? 1 : 2);
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -286,17 +333,22 @@ static int launch_resblock_mp(const ResblockParams &p, hipStream_t s) {
     dim3 grid((unsigned)ceil_div(p.T, BN - 2 * p.H), 1, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WAVES_M * WAVES_N), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("resblock_f16_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, MP);
+    set_last_kernel(BF ? "resblock_bf16_kernel<%d, %d, %d, %d>" : "resblock_f16_kernel<%d, %d, %d, %d>", NT_W, WAVES_M, WAVES_N, MP);
     return VS_OK;
+}
+
+template <int NT_W, int WAVES_M, int WAVES_N, bool BF>
+static int launch_resblock_margin(const ResblockParams &p, hipStream_t s) {
+    switch (margin_of(p.MP)) {
+        case 8: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, 8, BF>(p, s);
+        case 16: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, 16, BF>(p, s);
+        default: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, RB_MAXPAD, BF>(p, s);
+    }
 }
 
 template <int NT_W, int WAVES_M, int WAVES_N>
 static int launch_resblock_cfg(const ResblockParams &p, hipStream_t s) {
-    switch (margin_of(p.MP)) {
-        case 8: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, 8>(p, s);
-        case 16: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, 16>(p, s);
-        default: return launch_resblock_mp<NT_W, WAVES_M, WAVES_N, RB_MAXPAD>(p, s);
-    }
+    return p.bf16 ? launch_resblock_margin<NT_W, WAVES_M, WAVES_N, true>(p, s) : launch_resblock_margin<NT_W, WAVES_M, WAVES_N, false>(p, s);
 }
 
 }  // namespace vs
@@ -311,17 +363,19 @@ int vs_resblock_supported(vs_conv_t *const *convs, int nconv) {
     if (!c0) return 0;
     const int C = c0->c_in, k = c0->k;
     if (!(C == 32 || C == 64 || C == 128) || !(k & 1) || k < 3 || k > 11) return 0;
+    if (c0->math != VS_MATH_SPLIT3 && c0->math != VS_MATH_BF16) return 0;
+    const int planes = c0->math == VS_MATH_BF16 ? 1 : 2;
     int H = 0, MP = 0;
     for (int i = 0; i < nconv; ++i) {
         const vs_conv *c = convs[i];
-        if (!c || c->kind != VS_CONV1D || c->c_in != C || c->c_out != C || c->k != k || c->flags != 0 || c->math != VS_MATH_SPLIT3) return 0;
+        if (!c || c->kind != VS_CONV1D || c->c_in != C || c->c_out != C || c->k != k || c->flags != 0 || c->math != c0->math) return 0;
         if (c->pad != c->dil * (k - 1) / 2 || c->pad > RB_MAXPAD) return 0;
         H += c->pad;
         MP = std::max(MP, c->pad);
     }
     H = (H + 3) & ~3;
     if (C == 128)       // 256-column tiles on eight waves, one workgroup per CU (160 KB of LDS hold the all-channel tile up to a margin of 28)
-        return 256 - 2 * H >= 64 && resblock_lds<4, 4, 2>(margin_of(MP)) <= 160 * 1024;
+        return 256 - 2 * H >= 64 && resblock_lds<4, 4, 2>(margin_of(MP), planes) <= 160 * 1024;
     return 256 - 2 * H >= 64;
 }
 
@@ -330,7 +384,9 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
     VS_REQUIRE(vs_resblock_supported(convs, nconv), "vs_resblock_forward: unsupported chain of convs (32 / 64 / 128 channels, one odd k <= 11, VS_MATH_SPLIT3, "
                                                    "'same' padding, an even number of convs <= 6)");
     VS_REQUIRE(io->x && io->out[0].y && io->B > 0 && io->B <= 65535 && io->T > 0, "vs_resblock_forward: bad io");
-    VS_REQUIRE(io->x_dtype == VS_DTYPE_F32 && io->y_dtype == VS_DTYPE_F32, "vs_resblock_forward: fp32 tensors only");
+    const bool bf = convs[0]->math == VS_MATH_BF16;
+    VS_REQUIRE(io->x_dtype == (bf ? VS_DTYPE_BF16 : VS_DTYPE_F32) && io->y_dtype == io->x_dtype,
+               "vs_resblock_forward: fp32 tensors with VS_MATH_SPLIT3, bf16-resident tensors with VS_MATH_BF16");
     VS_REQUIRE(io->in_act == VS_IN_LRELU && !io->mask && !io->bias_b && !io->split_row && io->out[0].mode == VS_OUT_LINEAR &&
                    io->out[0].out_act == VS_OUT_NONE && !io->out[0].out_mask && !io->out[0].res,
                "vs_resblock_forward: only the unmasked leaky-relu residual form is fused (the residual input is x itself)");
@@ -338,9 +394,10 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
     memset(&p, 0, sizeof(p));
     const vs_conv *c0 = convs[0];
     const int C = c0->c_in;
+    p.bf16 = bf;
     VS_REQUIRE((long long)C * io->T * 4 < (1ll << 31), "vs_resblock_forward: item exceeds the 2 GiB buffer-descriptor range");
     const long long dflt = (long long)C * io->T;
-    p.x = io->x; p.x_bs = io->x_bs ? io->x_bs : dflt;
+    p.x = static_cast<const float *>(io->x); p.x_bs = io->x_bs ? io->x_bs : dflt;
     int H = 0;
     for (int i = 0; i < nconv; ++i) {
         const vs_conv *c = convs[i];
@@ -351,12 +408,14 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
     }
     p.H = (H + 3) & ~3;
     const vs_conv_out_t &o = io->out[0];
-    p.y = o.y; p.acc = o.acc;
+    p.y = static_cast<float *>(o.y); p.acc = static_cast<const float *>(o.acc);
     p.y_bs = o.y_bs ? o.y_bs : dflt; p.acc_bs = o.acc_bs ? o.acc_bs : dflt;
     p.scale = (o.scale == 0.f) ? 1.f : o.scale;
     p.B = (int)io->B; p.C = C; p.T = (int)io->T; p.K = c0->k; p.nconv = nconv; p.nchunks = c0->nchunks;
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    p.fast_epi = (io->T % 4 == 0) && al16(p.y) && (p.y_bs % 4 == 0) && (!p.acc || (al16(p.acc) && p.acc_bs % 4 == 0));
+    auto al8 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
+    p.fast_epi = (io->T % 4 == 0) && (p.y_bs % 4 == 0) && (!p.acc || p.acc_bs % 4 == 0) &&
+                 (bf ? al8(p.y) && (!p.acc || al8(p.acc)) : al16(p.y) && (!p.acc || al16(p.acc)));
     hipStream_t s = as_stream(stream);
     if (C == 32) {
         // 512-column tiles halve the halo and the weight-fragment traffic per output; with a small halo (k = 3: 12 columns) the 256-column
@@ -367,7 +426,7 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
     if (C == 128) {
         // a single pair: 128-column tiles on four waves, two workgroups per CU (4.4 against 4.6 ms at k = 3), while the tile fits half the LDS;
         // longer chains: 256 columns on eight waves, one workgroup per CU -- half the halo per output (whole k = 3 block 4.0 against 4.25 ms)
-        if (nconv == 2 && 128 - 2 * p.H >= 64 && 2 * (resblock_lds<4, 4, 1>(margin_of(p.MP)) + 64) <= 160 * 1024)
+        if (nconv == 2 && 128 - 2 * p.H >= 64 && 2 * (resblock_lds<4, 4, 1>(margin_of(p.MP), bf ? 1 : 2) + 64) <= 160 * 1024)
             return launch_resblock_cfg<4, 4, 1>(p, s);
         return launch_resblock_cfg<4, 4, 2>(p, s);
     }

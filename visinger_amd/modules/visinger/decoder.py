@@ -117,6 +117,15 @@ class Generator(nn.Module):
             block.remove_weight_norm()
 
 
+# (channels, k) whose whole block is one launch of resblock_bf16_kernel; the others keep the per-pair / per-conv launches.  `tools/resblock_bench.py bf16`, B = 8,
+# ms per block (whole block / one pair per launch / respair_split_kernel of round 2 / conv by conv):
+#   128 ch: k=3 0.55 / 0.69 / 0.83 / 0.86   k=7 1.31 / 1.31 / 1.18 / 1.30   k=11 2.52 / 2.14 / 1.52 / 1.68
+#   64 ch:  k=3 0.32 / 0.46 / 0.43 / 0.81   k=7 0.73 / 0.74 / 0.73 / 1.12   k=11 1.37 / 1.17 / 0.98 / 1.31
+#   32 ch:  k=3 0.23 / 0.32 / 0.33 / 0.61   k=7 0.39 / 0.47 / 0.45 / 0.78   k=11 0.56 / 0.59 / 0.55 / 0.88
+# (ties go to the whole block: its residual stream stays in fp32 registers, rms error 3.0e-3 against 3.7e-3 of the bf16-resident chain)
+BF16_WHOLE_BLOCK = {(128, 3), (64, 3), (64, 5), (64, 7), (32, 3), (32, 5), (32, 7), (32, 9), (32, 11)}
+
+
 class ResBlock1(torch.nn.Module):
     """decoder.py:68-110"""
 
@@ -130,10 +139,10 @@ class ResBlock1(torch.nn.Module):
         """out = ((out if not first else 0) + resblock(x)) * scale   [* mask];  x is left untouched."""
         n = len(self.convs1)
         act = L.IN_LRELU if mask is None else L.IN_LRELU_MASK
-        if mask is None and x.dtype == torch.float32:
+        if mask is None and x.dtype in (torch.float32, torch.bfloat16):
             # split-f16 arithmetic, 32 / 64 channels: the whole block (or groups of its pairs) as one launch each, the residual stream in
             # registers between the pairs (csrc/resblock_f16.hip); a tile recomputes its halo, which grows with k: see _fused_groups
-            groups = self._fused_groups()
+            groups = self._fused_groups(x.dtype)
             if groups is not None:
                 cur = x
                 for gi, ops in enumerate(groups):
@@ -165,13 +174,16 @@ class ResBlock1(torch.nn.Module):
                        out_mask=mask is not None)
         return out
 
-    def _fused_groups(self):
+    def _fused_groups(self, dtype=torch.float32):
         """the conv chain cut into launches of csrc/resblock_f16.hip, or None when it does not apply (other arithmetic / width).
         A launch over p pairs recomputes H = sum of its pads columns at each end of its tile: k = 3 -> 12, k = 7 -> 36, k = 11 -> 60 for a
         whole block: the fusion pays where a conv is short of matrix work (k = 3, 32 channels), not where the halo costs more than the saved
         tensor passes."""
         ops = [c._op() for pair in zip(self.convs1, self.convs2) for c in pair]
-        if ops[0].math != L.MATH_SPLIT3 or ops[0].c_in not in (32, 64, 128):
+        if ops[0].c_in not in (32, 64, 128):
+            return None
+        # fp32 tensors on the split-f16 arithmetic, or bf16-RESIDENT tensors on plain bf16 operands (resblock_bf16_kernel)
+        if (ops[0].math, dtype) not in ((L.MATH_SPLIT3, torch.float32), (L.MATH_BF16, torch.bfloat16)):
             return None
         C, k, n = ops[0].c_in, ops[0].k, len(self.convs1)
         per = L.switch("VS_RESBLOCK_PAIRS")                                     # pairs per launch (A/B switch); 0: by measurement
@@ -180,7 +192,9 @@ class ResBlock1(torch.nn.Module):
             #   32 ch:  k=3 1.6 / 2.1 / 3.6   k=7 2.6 / 3.0 / 4.5   k=11 4.0 / 4.1 / 5.4      -> whole block
             #   64 ch:  k=3 2.3 / 2.8 / 4.3   k=7 5.3 / 4.9 / 6.0   k=11 10.4 / 7.3 / 7.9     -> whole, pairs, pairs
             #   128 ch: k=3 4.0 / 4.4 / 5.2   k=7 10.3 / 9.0 / 8.6  k=11 21 / 14 / 11.9       -> whole block at k = 3 only (8 waves, 256 columns)
-            if C == 32:
+            if dtype == torch.bfloat16:
+                per = n if (C, k) in BF16_WHOLE_BLOCK else 0
+            elif C == 32:
                 per = n
             elif C == 64:
                 per = n if k <= 5 else 1

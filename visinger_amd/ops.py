@@ -457,7 +457,8 @@ def resblock_supported(ops):
 
 def resblock_forward(ops, x, y, acc=None, scale=1.0):
     """a11: for each pair (conv1, conv2) of `ops`: x = conv2(lrelu(conv1(lrelu(x)))) + x; y = (x [+ acc]) * scale -- one launch, the
-    residual stream in registers between the pairs (csrc/resblock_f16.hip, split-f16 arithmetic)."""
+    residual stream in registers between the pairs (csrc/resblock_f16.hip: split-f16 arithmetic on fp32 tensors, or plain bf16 operands on
+    bf16-resident tensors)."""
     B, C, T = x.shape
     io = L.ConvIO()
     io.x, io.x_dtype = L.act_ptr(x)
@@ -465,7 +466,9 @@ def resblock_forward(ops, x, y, acc=None, scale=1.0):
     io.in_act = L.IN_LRELU
     o = io.out[0]
     o.y, io.y_dtype = L.act_ptr(y)
-    o.acc = L.ptr(acc)
+    o.acc, adt = L.act_ptr(acc)
+    if acc is not None and adt != io.y_dtype:
+        raise L.VisingerHipError(f"resblock_forward: acc is {acc.dtype}, y is {y.dtype}")
     o.scale = scale
     lib = ops[0].lib
     if PROFILER.enabled:
@@ -473,7 +476,7 @@ def resblock_forward(ops, x, y, acc=None, scale=1.0):
         e0.record()
         L.check(lib.vs_resblock_forward(_handle_array(ops), len(ops), ctypes.byref(io), L.stream_ptr()))
         e1.record()
-        nb = 4.0 * B * C * T * (2 + (acc is not None))
+        nb = float(x.element_size()) * B * C * T * (2 + (acc is not None))
         PROFILER.records.append((ops[0].last_kernel(), sum(op.algorithmic_flops(B, T) for op in ops), nb, e0, e1))
     else:
         L.check(lib.vs_resblock_forward(_handle_array(ops), len(ops), ctypes.byref(io), L.stream_ptr()))
