@@ -38,7 +38,7 @@ VS_API const char *vs_last_error(void);
  * this library, so a caller that attributes per-launch timings to kernel instances (bench.py's roofline line) reads it back
  * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
 VS_API const char *vs_last_kernel_name(void);
-VS_API int vs_abi_version(void);          /* 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
+VS_API int vs_abi_version(void);          /* 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
 /* Dispatch switches (A/B comparisons and debugging; never needed for correct results).  The library reads the environment
  * variables of the same names ONCE, when it is loaded; afterwards only these calls change a switch, and no launch path touches
  * the environment.  Names and meanings: INTEGRATION.md "Switches".  Unknown name -> VS_EINVAL.  (No reference counterpart: the
@@ -202,6 +202,17 @@ VS_API int vs_relattn_fwd_ksplit(const float *q, const float *k, const float *v,
                                  const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
                                  int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,
                                  void *stream);
+
+/* The same with caller-provided scratch for PRE-PACKED keys / values (VS_MATH_BF16, long sequences): every 32- / 64-key tile of K and V
+ * is converted to bf16 and laid out as the attention kernel's LDS image ONCE per launch (attn_pack_kv_kernel) instead of once per
+ * 128-query block inside it (T / 128 times).  vs_relattn_kv_work_bytes() tells how many bytes `kv_work` (16-byte aligned) must hold for
+ * a launch, 0 where pre-packing does not apply (other arithmetics, T < 1024, VS_NO_ATTN_KVPACK); with kv_work NULL or too small the
+ * call behaves exactly as vs_relattn_fwd_ksplit.  Outputs are bit-identical either way (the same bf16 operands in the same order).   */
+VS_API size_t vs_relattn_kv_work_bytes(int64_t B, int n_heads, int k_channels, int64_t T, int math);
+VS_API int vs_relattn_fwd_work(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                               const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                               int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,
+                               void *kv_work, size_t kv_work_bytes, void *stream);
 
 /* a7  channel LayerNorm with its neighbours fused (rel_transformer.py:24-42; call sites 297-299, 305-307, 314-316):
  *     y = ((LayerNorm_C(a + r) * gamma + beta) + g) * mask      r, g, mask optional.

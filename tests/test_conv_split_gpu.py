@@ -384,6 +384,37 @@ def test_key_split_attention_equals_one_pass(dk, nh, T, ws, share, B, math):
     assert float((split - one).abs().max()) <= tol * max(1.0, float(one.abs().max())), float((split - one).abs().max())
 
 
+@pytest.mark.parametrize("dk,nh,T,ws,share,B", [(256, 2, 1028, 4, True, 2), (96, 2, 1024, 4, True, 3), (64, 2, 1100, 4, False, 2), (128, 1, 2048, None, True, 1),
+                                                (192, 1, 1032, 7, True, 2), (32, 4, 1024, 4, True, 1), (256, 2, 4096, 4, True, 1)])
+def test_prepacked_kv_attention_is_bit_identical(vs_option, dk, nh, T, ws, share, B):
+    """vs_relattn_fwd_work (ABI 5): on sequences of 1024 frames and more the plain-bf16 attention kernel takes its K / V tiles as LDS images
+    packed once per launch (attn_pack_kv_kernel) instead of converting fp32 -> bf16 in every query block.  The same bf16 operands in the
+    same order: the output equals the in-place kernel's bit for bit -- every head-width instance, key tiles cut by T, ragged masks with an
+    all-padding item, with and without the key split; below 1024 frames and with VS_NO_ATTN_KVPACK the library asks for no scratch."""
+    from visinger_amd.ops import rel_attention
+    g = torch.Generator().manual_seed(dk * 3 + T)
+    C = dk * nh
+    qkv = torch.randn(B, 3 * C, T, generator=g).cuda()
+    nrel = 0 if ws is None else 2 * ws + 1
+    rel_k = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5).cuda() if nrel else None
+    rel_v = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5).cuda() if nrel else None
+    lens = torch.tensor([T, (2 * T) // 3, 0][:B])
+    mask = (torch.arange(T)[None] < lens[:, None]).float().cuda()
+    lib = L.lib()
+    assert lib.vs_relattn_kv_work_bytes(B, nh, dk, T, L.MATH_BF16) > 0
+    assert lib.vs_relattn_kv_work_bytes(B, nh, dk, 512, L.MATH_BF16) == 0 and lib.vs_relattn_kv_work_bytes(B, nh, dk, T, L.MATH_SPLIT6) == 0
+    for auto in (False, True):
+        packed = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=auto)
+        name = lib.vs_last_kernel_name().decode()
+        assert name.startswith("relattn_bf16_kernel<") and name.endswith(", true>"), name
+        vs_option("VS_NO_ATTN_KVPACK", 1)
+        assert lib.vs_relattn_kv_work_bytes(B, nh, dk, T, L.MATH_BF16) == 0
+        plain = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=auto)
+        assert not lib.vs_last_kernel_name().decode().endswith(", true>")
+        vs_option("VS_NO_ATTN_KVPACK", 0)
+        assert torch.equal(packed, plain)
+
+
 def test_bf16_resident_tensors_random_sweep():
     """Randomised version of the two tests above: 160 random (shape, dilation / stride, fused option) cases of the plain-bf16 conv on
     bf16-RESIDENT tensors, each bit for bit against the same launch on the same values held in fp32 (output rounded once)."""

@@ -367,3 +367,42 @@ def test_training_transformer_layer_uses_the_streaming_attention(vs_option):
         assert (a is None) == (b is None)
         if a is not None:
             assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
+
+
+def test_training_step_packs_each_weight_version_once(vs_option):
+    """ConvOp.set_weights_from / autograd.param_key: within one optimizer step the discriminators' convs see their (unchanged)
+    parameters three times (real + generated batch in the generator pass, both in the discriminator pass) and every handle packs them
+    once; after an optimizer step the versions differ and they are packed again.  The cached and the uncached run produce the SAME
+    losses and parameters bit for bit (the packed bytes are identical), at fewer packs."""
+    from visinger_amd import ops
+    from visinger_amd.train import VISingerTrainer, synthetic_train_batch
+    hp = json.load(open(os.path.join(GOLDEN, "visinger_tiny_hparams.json")))
+    hp = dict(hp, use_pitch_embed=True, pitch_predictor_layers=1, segment_size=8, p_dropout=0.0)
+
+    def run(no_cache):
+        vs_option("VS_NO_PACK_CACHE", 1 if no_cache else 0)
+        torch.manual_seed(0)
+        tr = VISingerTrainer(64, 117, 131, hp, dict(fft_size=64, win_size=32, num_mel_bins=16, fmin=0.0, fmax=4000.0, sample_rate=8000))
+        tr = tr.cuda().train().configure()
+        batch = synthetic_train_batch(2, 48, 6, tr.hop, 64, hp["num_linear_bins"], 1, "cuda")
+        g = torch.Generator().manual_seed(3)
+        batch["noise_q"] = torch.randn(2, hp["hidden_size"], 48, generator=g).cuda()
+        batch["u_slice"] = torch.rand(2, generator=g).cuda()
+        packs, orig = [0], ops.ConvOp.set_weights_from
+
+        def counting(self, w, bias, key):
+            packs[0] += 1
+            return orig(self, w, bias, key)
+
+        ops.ConvOp.set_weights_from = counting
+        try:
+            logs = [tr.training_step(batch) for _ in range(3)]
+        finally:
+            ops.ConvOp.set_weights_from = orig
+        return logs, packs[0], [p.detach().clone() for p in tr.parameters()]
+
+    logs_c, packs_c, params_c = run(False)
+    logs_u, packs_u, params_u = run(True)
+    assert packs_c < 0.8 * packs_u, (packs_c, packs_u)
+    assert logs_c == logs_u                                                   # three steps, every loss term, bit for bit
+    assert all(torch.equal(a, b) for a, b in zip(params_c, params_u))

@@ -22,7 +22,7 @@ FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 MATH_F32, MATH_BF16, MATH_SPLIT3, MATH_SPLIT6 = 0, 1, 3, 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
-EXPECTED_ABI = 4          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
+EXPECTED_ABI = 5          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
 
 _f32p = ctypes.c_void_p
 
@@ -87,6 +87,10 @@ def lib():
     i64, ci, vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
     L.vs_relattn_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, i64, ci, ci, i64, ci, ci, ci, vp]
     L.vs_relattn_fwd_ksplit.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, i64, ci, ci, i64, ci, ci, ci, _f32p, ci, vp]
+    L.vs_relattn_fwd_work.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, i64, ci, ci, i64, ci, ci, ci, _f32p, ci, vp,
+                                      ctypes.c_size_t, vp]
+    L.vs_relattn_kv_work_bytes.argtypes = [i64, ci, ci, i64, ci]
+    L.vs_relattn_kv_work_bytes.restype = ctypes.c_size_t
     L.vs_layernorm_c_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, i64, ci, _f32p, _f32p, i64, i64, i64,
                                      ctypes.c_float, vp]
     L.vs_gate_fwd.argtypes = [_f32p, _f32p, i64, _f32p, i64, i64, i64, vp]
@@ -122,7 +126,7 @@ def lib():
 # (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
 PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
                for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
-                            "VS_WGRAD_GEMM", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS")}
+                            "VS_WGRAD_GEMM", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE")}
 
 
 def switch(name):

@@ -22,6 +22,29 @@ from .ops import PROFILER, ConvOp, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_wei
 LRELU_SLOPE = 0.1
 
 
+def param_key(holder):
+    """Identity and in-place versions of the PARAMETERS the live weight / bias of a conv holder derive from: (weight_v, weight_g) under
+    torch.nn.utils.weight_norm, else the plain weight parameter; None when the weight is not a function of parameters alone (spectral
+    norm runs a power iteration per forward).  Optimizer steps, load_state_dict and every other in-place write bump the versions; a
+    handle whose packed weights carry the same key need not be packed again (ConvOp.has_weights_of)."""
+    if L.switch("VS_NO_PACK_CACHE"):
+        return None
+    sources = holder.__dict__.get("_key_sources")
+    if sources is not None:                   # a fused projection (_ConvHolder): the concatenation of several modules' weights
+        keys = tuple(param_key(m_) for m_ in sources)
+        return None if any(k is None for k in keys) else keys
+    if not isinstance(holder, torch.nn.Module):
+        return None
+    if hasattr(holder, "weight_g") and hasattr(holder, "weight_v"):
+        ps = (holder.weight_v, holder.weight_g)
+    elif isinstance(holder._parameters.get("weight"), torch.nn.Parameter):
+        ps = (holder.weight,)
+    else:
+        return None
+    bias = getattr(holder, "bias", None)
+    return tuple((t.data_ptr(), t._version) for t in ps) + (None if bias is None else (bias.data_ptr(), bias._version),)
+
+
 class HipConvFn(torch.autograd.Function):
     """y = conv(x, w, b) with the forward on the HIP engine and the backward through torch.nn.functional."""
 
@@ -29,7 +52,9 @@ class HipConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, module):
         x = x.contiguous().float()
         op = module._op(bind=False)
-        op.set_weights(w.detach().contiguous(), None, None if b is None else b.detach(), force=True)
+        key = param_key(module)
+        if not op.has_weights_of(key):
+            op.set_weights_from(w, b, key)
         y = op.forward(x)
         ctx.module = module
         ctx.save_for_backward(x, w, b if b is not None else x.new_empty(0))
@@ -77,7 +102,9 @@ def conv_backward(m, x, w, gy, need_x, need_w):
             assert pb >= 0, "conv backward-data: padding larger than the receptive field is not supported"
             # (the handle packs the adjoint -- channel transpose + tap reversal -- of the forward weight by index arithmetic)
             op = _bwd_op(m, "dxa", L.CONV1D, Cout, Cin, K, d, pb, L.CONV_ADJOINT)
-            op.set_weights(w.detach().contiguous(), None, None, force=True)
+            key = param_key(m)
+            if not op.has_weights_of(key):
+                op.set_weights_from(w, None, key)
             gx = op.forward(gy)
         if need_w:
             gw = conv_wgrad(gy, x, K, d, p)
@@ -91,9 +118,11 @@ def conv_backward(m, x, w, gy, need_x, need_w):
         gyp = F.pad(gy, (p, max(right, 0)))[:, :, :Mq * u]
         G = gyp.view(B, Cout, Mq, u).permute(0, 3, 1, 2).reshape(B, u * Cout, Mq)
         if need_x:
-            wq = F.pad(w.detach(), (0, Q * u - K)).view(Cin, Cout, Q, u).permute(0, 3, 1, 2).reshape(Cin, u * Cout, Q)
             op = _bwd_op(m, "dx", L.CONV1D, u * Cout, Cin, Q, 1, 0, 0)
-            op.set_weights(wq.contiguous(), None, None, force=True)
+            key = param_key(m)
+            if not op.has_weights_of(key):
+                wq = F.pad(w.detach(), (0, Q * u - K)).view(Cin, Cout, Q, u).permute(0, 3, 1, 2).reshape(Cin, u * Cout, Q)
+                op.set_weights_from(wq, None, key)
             gx = op.forward(G.contiguous())                                             # [B, Cin, Mq - Q + 1 = T]
         if need_w:
             # gw2[ci, j, q] = sum_{b,m} x[b, ci, m] * G[b, j, m + q]: the same kernel with x in the role of the output gradient
@@ -149,20 +178,21 @@ class StridedConv1dFn(torch.autograd.Function):
         XF = torch.empty((1, stride * C, Lf + Q - 1), device=x.device, dtype=torch.float32)
         L.check(lib.vs_phase_stack(ctypes.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), x.stride(2), L.ptr(XF), N, C, T, stride, pad, Hq,
                                    Lf + Q - 1, L.stream_ptr()))
-        w2 = _phase_weights(w, stride, Q) if stride > 1 else w
         op = _cached_op(holder, ("fwd", C, Cout, K, stride), L.CONV1D, stride * C, Cout, Q, 1, 0, 0)
-        op.set_weights(w2.detach(), None, None if b is None else b.detach(), force=True)
+        key = param_key(holder)
+        if not op.has_weights_of(key):
+            op.set_weights_from(_phase_weights(w.detach(), stride, Q) if stride > 1 else w, b, key)
         yF = op.forward(XF)                                                                     # [1, Cout, N*Hq]
-        ctx.save_for_backward(XF, w2)
+        ctx.save_for_backward(XF, w)
         ctx.cfg = (N, C, T, K, stride, pad, Q, Hq, Tout, b is not None, holder)
         return yF.view(Cout, N, Hq)[:, :, :Tout].permute(1, 0, 2)
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.require_gpu()
-        XF, w2 = ctx.saved_tensors
+        XF, w = ctx.saved_tensors
         N, C, T, K, stride, pad, Q, Hq, Tout, has_bias, holder = ctx.cfg
-        Cout = w2.shape[0]
+        Cout = w.shape[0]
         Lf = N * Hq
         gy = gy.contiguous().float()
         gyF = torch.empty((1, Cout, Lf), device=gy.device, dtype=torch.float32)
@@ -170,7 +200,9 @@ class StridedConv1dFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             op = _cached_op(holder, ("dxa", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, L.CONV_ADJOINT)
-            op.set_weights(w2, None, None, force=True)
+            key = param_key(holder)
+            if not op.has_weights_of(key):      # (the handle packs the adjoint of the phase-stacked forward weight)
+                op.set_weights_from(_phase_weights(w.detach(), stride, Q) if stride > 1 else w, None, key)
             gXF = op.forward(gyF)                                                               # [1, s*C, N*Hq + Q - 1]
             gx = torch.empty((N, C, T), device=gy.device, dtype=torch.float32)
             L.check(lib.vs_phase_unstack(L.ptr(gXF), Lf + Q - 1, L.ptr(gx), N, C, T, stride, pad, Hq, L.stream_ptr()))
@@ -521,6 +553,7 @@ def attention(m, x, frame_mask):
             holder = m.__dict__.get("_hip_qkv")
             if holder is None:
                 holder = m.__dict__["_hip_qkv"] = _ConvHolder(m.conv_q.in_channels, 3 * C)
+                holder._key_sources = (m.conv_q, m.conv_k, m.conv_v)
             arith = m.conv_q.__dict__.get("_hip_math")
             if arith is not None:
                 holder.__dict__["_hip_math"] = arith

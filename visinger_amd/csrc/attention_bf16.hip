@@ -26,9 +26,14 @@ namespace vs {
 // probabilities split EXACTLY into three bf16 planes, six cross products per product: fp32-class scores and outputs at 16/6 of the
 // fp32 matrix rate (VS_MATH_SPLIT6, the default arithmetic of the path); three times the LDS per tile, so 32-key tiles, ONE K / V
 // buffer (two barriers per tile) and two workgroups per CU that overlap each other; heads of up to 128 channels.
-template <int DT, int AKT, int TERMS>
+// PK: the K / V tiles arrive as ready LDS images (AttnParams::kvimg, attn_pack_kv_kernel): a tile is 9 (DT = 8) 16-byte loads and LDS
+// writes per thread, no conversion -- in place, the fp32 -> bf16 conversion of a tile (64 values per thread at 256 channels: ~300 VALU
+// instructions next to 32 MFMAs per wave, one wave per SIMD) and its 64 KB of fp32 loads were repeated by every one of the T / 128 query
+// blocks.
+template <int DT, int AKT, int TERMS, bool PK = false>
 __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(const AttnParams p) {
     static_assert(TERMS == 1 || TERMS == 6, "plain bf16 or split-bf16 x6");
+    static_assert(!PK || TERMS == 1, "pre-packed tiles: plain-bf16 arithmetic");
     constexpr int NPL = (TERMS == 6) ? 3 : 1;
     constexpr int NBUF = (TERMS == 6) ? 1 : 2;
     constexpr int DKR = DT * 32;                     // padded head dim
@@ -137,10 +142,23 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     }
 
     // ---- K / V tile staging ----
-    float kst[KCPT][8][KW];
-    float4 vst[VCPT];
+    constexpr int KU4 = KPL / 4, VU4 = VPL / 4;                          // 16-byte units of the K / V images (PK)
+    constexpr int KIPT = (KU4 + 255) / 256, VIPT = (VU4 + 255) / 256;
+    constexpr int IMG = KPL + VPL + AKT;                                  // dwords of a tile image: K, V, key mask
+    float kst[PK ? 1 : KCPT][8][KW];
+    float4 vst[PK ? 1 : VCPT];
+    u32x4 kimg[PK ? KIPT : 1], vimg[PK ? VIPT : 1];
     float mst = 1.f;
+    const unsigned *const imgb = PK ? p.kvimg + ((long long)(b * p.nh + h) * ((T + AKT - 1) / AKT)) * IMG : nullptr;
     auto load_k = [&](int jt) __attribute__((always_inline)) {
+        if constexpr (PK) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(imgb + (long long)jt * IMG);
+#pragma unroll
+            for (int i = 0; i < KIPT; ++i)
+                if (KU4 % 256 == 0 || tid + 256 * i < KU4) kimg[i] = src[tid + 256 * i];
+            if (tid < AKT) mst = u2f(imgb[(long long)jt * IMG + KPL + VPL + tid]);
+            return;
+        }
         const int j0 = jt * AKT;
 #pragma unroll
         for (int i = 0; i < KCPT; ++i) {
@@ -162,6 +180,13 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         if (tid < AKT) mst = maskb ? maskb[min(j0 + tid, T - 1)] : 1.f;
     };
     auto load_v = [&](int jt) __attribute__((always_inline)) {
+        if constexpr (PK) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(imgb + (long long)jt * IMG + KPL);
+#pragma unroll
+            for (int i = 0; i < VIPT; ++i)
+                if (VU4 % 256 == 0 || tid + 256 * i < VU4) vimg[i] = src[tid + 256 * i];
+            return;
+        }
         const int j0 = jt * AKT;
 #pragma unroll
         for (int i = 0; i < VCPT; ++i) {
@@ -174,6 +199,13 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     auto store_k = [&](int jt, int buf) __attribute__((always_inline)) {
         const int j0 = jt * AKT;
         unsigned *Kb = Ks + buf * KBUF;
+        if constexpr (PK) {
+#pragma unroll
+            for (int i = 0; i < KIPT; ++i)
+                if (KU4 % 256 == 0 || tid + 256 * i < KU4) reinterpret_cast<u32x4 *>(Kb)[tid + 256 * i] = kimg[i];
+            if (tid < AKT) Ms[buf * AKT + tid] = mst;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KCPT; ++i) {
             const int c = tid + 256 * i;
@@ -197,6 +229,12 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     auto store_v = [&](int jt, int buf) __attribute__((always_inline)) {
         const int j0 = jt * AKT;
         unsigned *Vb = Vs + buf * VBUF;
+        if constexpr (PK) {
+#pragma unroll
+            for (int i = 0; i < VIPT; ++i)
+                if (VU4 % 256 == 0 || tid + 256 * i < VU4) reinterpret_cast<u32x4 *>(Vb)[tid + 256 * i] = vimg[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < VCPT; ++i) {
             const int c = tid + 256 * i;
@@ -405,6 +443,71 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     }
 }
 
+// The LDS images of the K / V tiles of one (batch, head), written once per launch (AttnParams::kvimg): exactly the bytes store_k / store_v
+// of relattn_bf16_kernel<DT, AKT, 1> put into LDS -- same cells, same key order, same zero fill beyond T and dk, RNE to bf16 -- followed
+// by the tile's key mask.  blockIdx = (key tile, head, batch).
+template <int DT, int AKT>
+__global__ void __launch_bounds__(256) attn_pack_kv_kernel(const AttnParams p) {
+    constexpr int DKR = DT * 32, KQ = AKT / 4, AVP = AKT / 2 + 4;
+    constexpr int KCELLS = (DKR / 8) * KQ, VCELLS = DKR * KQ;
+    constexpr int KPL = (DKR / 8) * AKT * 4, VPL = DKR * AVP, IMG = KPL + VPL + AKT;
+    const int tid = threadIdx.x, jt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int dk = p.dk, T = p.T, j0 = jt * AKT;
+    const float *kb = p.k + (long long)b * p.bs + (long long)h * dk * T;
+    const float *vb = p.v + (long long)b * p.bs + (long long)h * dk * T;
+    unsigned *img = p.kvimg + ((long long)(b * p.nh + h) * gridDim.x + jt) * IMG;
+    for (int c = tid; c < KCELLS; c += 256) {
+        const int kq = c % KQ, d8 = c / KQ;
+        const int jc = min(j0 + 4 * kq, T - 4);
+        const bool okj = (j0 + 4 * kq < T);
+        float kv[8][4];
+#pragma unroll
+        for (int jd = 0; jd < 8; ++jd) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(kb + (long long)min(8 * d8 + jd, dk - 1) * T + jc);
+            const bool ok = okj && (8 * d8 + jd < dk);
+            kv[jd][0] = ok ? t4.x : 0.f; kv[jd][1] = ok ? t4.y : 0.f; kv[jd][2] = ok ? t4.z : 0.f; kv[jd][3] = ok ? t4.w : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u32x4 f;
+            f.x = pack_hi(rne_bf16(kv[0][e]), rne_bf16(kv[1][e])); f.y = pack_hi(rne_bf16(kv[2][e]), rne_bf16(kv[3][e]));
+            f.z = pack_hi(rne_bf16(kv[4][e]), rne_bf16(kv[5][e])); f.w = pack_hi(rne_bf16(kv[6][e]), rne_bf16(kv[7][e]));
+            *reinterpret_cast<u32x4 *>(img + (d8 * AKT + 4 * kq + e) * 4) = f;
+        }
+    }
+    // (the four pad dwords at the end of every V row are never read)
+    for (int c = tid; c < VCELLS; c += 256) {
+        const int kq = c % KQ, d = c / KQ;
+        const int jc = min(j0 + 4 * kq, T - 4);
+        const bool ok = (j0 + 4 * kq < T) && (d < dk);
+        const float4 t4 = *reinterpret_cast<const float4 *>(vb + (long long)min(d, dk - 1) * T + jc);
+        const int slot = ((kq & 1) << 1) | ((kq >> 1) & 1);
+        *reinterpret_cast<uint2 *>(img + KPL + d * AVP + (kq >> 2) * 8 + slot * 2) =
+            make_uint2(pack_hi(rne_bf16(ok ? t4.x : 0.f), rne_bf16(ok ? t4.y : 0.f)), pack_hi(rne_bf16(ok ? t4.z : 0.f), rne_bf16(ok ? t4.w : 0.f)));
+    }
+    if (tid < AKT) {
+        const float m = (p.mask && j0 + tid < T) ? p.mask[(long long)b * T + j0 + tid] : 1.f;
+        img[KPL + VPL + tid] = f2u(m);
+    }
+}
+
+static int akt_of(int DT) { return DT <= 4 ? 64 : 32; }
+static size_t kv_image_dwords(int DT) {
+    const int AKT = akt_of(DT), DKR = DT * 32;
+    return (size_t)(DKR / 8) * AKT * 4 + (size_t)DKR * (AKT / 2 + 4) + AKT;
+}
+static int dt_instance(int dk) {
+    const int DT = (int)ceil_div(dk, 32);
+    return DT <= 2 ? 2 : (DT <= 4 ? DT : (DT <= 6 ? 6 : 8));
+}
+
+// pre-packing pays once a tile is used by enough query blocks: T >= 1024 (eight blocks of 128 queries)
+size_t attn_kv_work_bytes(long long B, int nh, int dk, long long T) {
+    if (dk > 256 || T < 1024 || (T % 4) != 0 || opt(OPT_NO_ATTN_KVPACK)) return 0;
+    const int DT = dt_instance(dk);
+    return (size_t)B * nh * ceil_div(T, akt_of(DT)) * kv_image_dwords(DT) * 4;
+}
+
 // merge of the key ranges: out[d] = (sum_k O_k[d] e^{m_k - m}) / L + sum_r e^{s_r - m} / L * rel_v[r][d],
 // m = max_k m_k, L = sum_k l_k e^{m_k - m}, s_r = the in-window score (owned by exactly one range; -inf elsewhere).
 // Block = 64 queries x 4 channel groups, blockIdx.x = query block * CG + channel-group block: each thread re-derives the weights of its
@@ -471,11 +574,16 @@ bool attn_bf16_supported(const AttnParams &p, int terms) {
     return p.dk <= (terms == 6 ? 128 : 256) && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
 }
 
-template <int DT, int AKT, int TERMS>
+template <int DT, int AKT, int TERMS, bool PK = false>
 static int launch_bf16(const AttnParams &p, hipStream_t s) {
     constexpr int DKR = DT * 32, AVP = AKT / 2 + 4, NPL = (TERMS == 6) ? 3 : 1, NBUF = (TERMS == 6) ? 1 : 2;
     const size_t lds = 4 * ((size_t)NBUF * NPL * (DKR / 8) * AKT * 4 + (size_t)NBUF * NPL * DKR * AVP + 2 * AKT + 2 * 4 * 32 * ATT_QRS);
-    auto kern = relattn_bf16_kernel<DT, AKT, TERMS>;
+    auto kern = relattn_bf16_kernel<DT, AKT, TERMS, PK>;
+    if constexpr (PK) {
+        dim3 pgrid((unsigned)ceil_div(p.T, AKT), (unsigned)p.nh, (unsigned)p.B);
+        hipLaunchKernelGGL((attn_pack_kv_kernel<DT, AKT>), pgrid, dim3(256), 0, s, p);
+        VS_CHECK_HIP(hipGetLastError());
+    }
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -486,7 +594,8 @@ static int launch_bf16(const AttnParams &p, hipStream_t s) {
     dim3 grid((unsigned)(ceil_div(p.T, 128) * ks), (unsigned)p.nh, (unsigned)p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("relattn_bf16_kernel<%d, %d, %d>", DT, AKT, TERMS);
+    if (PK) set_last_kernel("relattn_bf16_kernel<%d, %d, %d, true>", DT, AKT, TERMS);
+    else set_last_kernel("relattn_bf16_kernel<%d, %d, %d>", DT, AKT, TERMS);
     if (ks > 1) return launch_attn_combine(p, s);
     return VS_OK;
 }
@@ -497,6 +606,13 @@ int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s) {
         if (DT <= 2) return launch_bf16<2, 32, 6>(p, s);
         if (DT == 3) return launch_bf16<3, 32, 6>(p, s);
         return launch_bf16<4, 32, 6>(p, s);
+    }
+    if (p.kvimg) {
+        if (DT <= 2) return launch_bf16<2, 64, 1, true>(p, s);
+        if (DT == 3) return launch_bf16<3, 64, 1, true>(p, s);
+        if (DT == 4) return launch_bf16<4, 64, 1, true>(p, s);
+        if (DT <= 6) return launch_bf16<6, 32, 1, true>(p, s);
+        return launch_bf16<8, 32, 1, true>(p, s);
     }
     if (DT <= 2) return launch_bf16<2, 64, 1>(p, s);
     if (DT == 3) return launch_bf16<3, 64, 1>(p, s);

@@ -21,7 +21,15 @@ struct AttnParams {
     // its un-normalised output rows, row maximum, row sum and in-window scores to `part`, a second kernel combines them
     float *part;                  // [B * nh * ksplit][dk + 2 + nrel][T], or null
     int ksplit;                   // >= 2 with part, else 0 / 1
+    // pre-packed keys / values (attention_bf16.hip, plain-bf16 arithmetic, long sequences): the LDS image of every 32- / 64-key tile
+    // -- K as [d/8][key][8 bf16], V as [d][permuted keys] + row padding, the tile's key mask -- built ONCE per launch by
+    // attn_pack_kv_kernel instead of once per query block (T / 128 times) inside the attention kernel; null: convert in the kernel
+    unsigned *kvimg;              // [B][nh][key tiles][attn_kv_image_dwords(dk)] or null
 };
+
+// bytes of the pre-packed K / V images for a launch of the plain-bf16 kernel, 0 where the kernel converts in place (short sequences,
+// shapes attention_bf16.hip does not take)
+size_t attn_kv_work_bytes(long long B, int nh, int dk, long long T);
 
 // attention_bf16.hip: both GEMMs on the bf16 matrix instruction, fp32 softmax / accumulation; terms = 1: bf16 operands (dk <= 256),
 // terms = 6: the exact three-plane split with six cross products (fp32 class, dk <= 128).  Needs T % 4 == 0 and 16-byte aligned

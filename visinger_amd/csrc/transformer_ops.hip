@@ -328,13 +328,14 @@ extern "C" {
 
 static int relattn_fwd_impl(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                             const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
-                            int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit, void *stream);
+                            int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,
+                            void *kv_work, size_t kv_work_bytes, void *stream);
 
 int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                    const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
                    int k_channels, int64_t T, int window_size, int n_heads_rel, int math, void *stream) {
     return relattn_fwd_impl(q, k, v, qkv_batch_stride, rel_k, rel_v, mask, out, out_batch_stride, B, n_heads, k_channels, T, window_size,
-                            n_heads_rel, math, nullptr, 0, stream);
+                            n_heads_rel, math, nullptr, 0, nullptr, 0, stream);
 }
 
 int vs_relattn_fwd_ksplit(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
@@ -342,12 +343,28 @@ int vs_relattn_fwd_ksplit(const float *q, const float *k, const float *v, int64_
                           int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit, void *stream) {
     VS_REQUIRE(ksplit >= 1 && ksplit <= 16 && (ksplit == 1 || work), "vs_relattn_fwd_ksplit: ksplit in 1..16, work buffer for ksplit > 1");
     return relattn_fwd_impl(q, k, v, qkv_batch_stride, rel_k, rel_v, mask, out, out_batch_stride, B, n_heads, k_channels, T, window_size,
-                            n_heads_rel, math, work, ksplit, stream);
+                            n_heads_rel, math, work, ksplit, nullptr, 0, stream);
+}
+
+size_t vs_relattn_kv_work_bytes(int64_t B, int n_heads, int k_channels, int64_t T, int math) {
+    if (math != VS_MATH_BF16 || B <= 0 || n_heads <= 0 || k_channels <= 0 || T <= 0 || opt(OPT_NO_BF16_ATTN)) return 0;
+    return attn_kv_work_bytes(B, n_heads, k_channels, T);
+}
+
+int vs_relattn_fwd_work(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
+                        const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
+                        int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,
+                        void *kv_work, size_t kv_work_bytes, void *stream) {
+    VS_REQUIRE(ksplit >= 1 && ksplit <= 16 && (ksplit == 1 || work), "vs_relattn_fwd_work: ksplit in 1..16, work buffer for ksplit > 1");
+    VS_REQUIRE(!kv_work || (reinterpret_cast<uintptr_t>(kv_work) & 15u) == 0, "vs_relattn_fwd_work: kv_work must be 16-byte aligned");
+    return relattn_fwd_impl(q, k, v, qkv_batch_stride, rel_k, rel_v, mask, out, out_batch_stride, B, n_heads, k_channels, T, window_size,
+                            n_heads_rel, math, work, ksplit, kv_work, kv_work_bytes, stream);
 }
 
 static int relattn_fwd_impl(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                             const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
-                            int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit, void *stream) {
+                            int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,
+                            void *kv_work, size_t kv_work_bytes, void *stream) {
     VS_REQUIRE(q && k && v && out, "vs_relattn_fwd: NULL tensor");
     VS_REQUIRE(B > 0 && B <= 65535 && n_heads > 0 && k_channels > 0 && T > 0, "vs_relattn_fwd: bad dims");
     VS_REQUIRE(window_size < 0 || (rel_k && rel_v), "vs_relattn_fwd: window given but relative embeddings are NULL");
@@ -362,7 +379,7 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     p.out_bs = out_batch_stride ? out_batch_stride : (long long)n_heads * k_channels * T;
     p.B = (int)B; p.nh = n_heads; p.dk = k_channels; p.T = (int)T; p.ws = window_size; p.nh_rel = n_heads_rel;
     p.scale = 1.0f / sqrtf((float)k_channels);
-    p.part = nullptr; p.ksplit = 0;
+    p.part = nullptr; p.ksplit = 0; p.kvimg = nullptr;
     hipStream_t s = as_stream(stream);
     VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6 || math == VS_MATH_SPLIT3, "vs_relattn_fwd: unknown arithmetic %d", math);
     if (math == VS_MATH_SPLIT3) math = VS_MATH_SPLIT6;      // (the attention core has no split-f16 instance: the fp32-class split-bf16 x6 kernel serves both)
@@ -372,7 +389,12 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     // six cross products per product -- fp32-class scores and outputs at 16/6 of the fp32 matrix rate; VS_MATH_F32: the kernel below
     // (key split: only the bf16-pipe kernels take it; the number of ranges is capped by the key tiles of the kernel, 32 keys each at least)
     if (work && ksplit > 1 && T / 64 >= ksplit) { p.part = work; p.ksplit = ksplit; }
-    if (math == VS_MATH_BF16 && attn_bf16_supported(p, 1) && !opt(OPT_NO_BF16_ATTN)) return launch_attn_bf16(p, 1, s);
+    if (math == VS_MATH_BF16 && attn_bf16_supported(p, 1) && !opt(OPT_NO_BF16_ATTN)) {
+        // pre-packed K / V tile images when the caller brought the scratch for them (vs_relattn_kv_work_bytes)
+        const size_t need = attn_kv_work_bytes(B, n_heads, k_channels, T);
+        if (kv_work && need && kv_work_bytes >= need) p.kvimg = static_cast<unsigned *>(kv_work);
+        return launch_attn_bf16(p, 1, s);
+    }
     if (math == VS_MATH_SPLIT6 && attn_bf16_supported(p, 6) && !opt(OPT_NO_SPLIT_ATTN)) return launch_attn_bf16(p, 6, s);
     p.part = nullptr; p.ksplit = 0;
     const int DT = (int)ceil_div(k_channels, 32);

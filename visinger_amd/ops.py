@@ -176,6 +176,20 @@ class ConvOp:
                                              L.ptr(None if bias is None else bias.contiguous()), L.stream_ptr()))
         self._wkey = None if force else key
 
+    def has_weights_of(self, key):
+        """True when the packed weights were derived from the parameters identified by `key` (set_weights_from)"""
+        return key is not None and key == self._wkey
+
+    def set_weights_from(self, w, bias, key):
+        """Training path: pack `w` / `bias`, TEMPORARIES derived from parameters identified by `key` = their (data_ptr, in-place version)
+        tuples (autograd.param_key), or None when the derivation is not a function of the parameters alone (spectral norm: a power
+        iteration per forward).  Within one optimizer step the same parameters reach a handle several times -- the discriminators see
+        the real and the generated batch in the generator pass and both again in the discriminator pass -- and every pack is one or
+        two launches + the weight's bytes: the caller asks has_weights_of(key) first and skips deriving `w` altogether."""
+        L.check(self.lib.vs_conv_set_weights(self.h, L.ptr(w.detach().contiguous()), None,
+                                             L.ptr(None if bias is None else bias.detach().contiguous()), L.stream_ptr()))
+        self._wkey = key
+
     def forward(self, x, *, B=None, T=None, x_bs=0, in_act=L.IN_NONE, mask=None, bias_b=None, bias_b_bs=0,
                 y=None, y_bs=0, res=None, res_bs=0, acc=None, acc_bs=0, scale=1.0, out_act=L.OUT_NONE, out_mask=False,
                 mode=L.MODE_LINEAR, split_row=0, out1=None, pair_mode=L.PAIR_GATE, logdet=None,
@@ -280,14 +294,19 @@ def rel_attention(qkv, n_heads, rel_k=None, rel_v=None, mask=None, window_size=N
     if ksplit > 1:
         R = 0 if rel_k is None else rel_k.shape[1]
         work = torch.empty((B * n_heads * ksplit * (C // n_heads + 2 + R) * T,), device=qkv.device, dtype=torch.float32)
+    # plain-bf16 arithmetic on long sequences: scratch for the K / V tile images the library then packs once per launch instead of once
+    # per query block (vs_relattn_fwd_work); 0 bytes: not applicable
+    kv_bytes = int(lib.vs_relattn_kv_work_bytes(B, n_heads, C // n_heads, T, int(math)))
+    kv_work = torch.empty((kv_bytes,), device=qkv.device, dtype=torch.uint8) if kv_bytes else None
     if PROFILER.enabled:
         e0, e1 = PROFILER.events()
         e0.record()
-    L.check(lib.vs_relattn_fwd_ksplit(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
-                                      L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
-                                      L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
-                                      C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
-                                      int(math), L.ptr(work), ksplit, L.stream_ptr()))
+    L.check(lib.vs_relattn_fwd_work(_off(qkv, 0), _off(qkv, C * T), _off(qkv, 2 * C * T), C3 * T,
+                                    L.ptr(None if rel_k is None else rel_k.detach().contiguous()),
+                                    L.ptr(None if rel_v is None else rel_v.detach().contiguous()), L.ptr(mask), L.ptr(out),
+                                    C * T, B, n_heads, C // n_heads, T, ws, 1 if rel_k is None else rel_k.shape[0],
+                                    int(math), L.ptr(work), ksplit,
+                                    None if kv_work is None else ctypes.c_void_p(kv_work.data_ptr()), kv_bytes, L.stream_ptr()))
     if PROFILER.enabled:
         e1.record()      # algorithmic work: Q K^T and P V over the full [T, T] score matrix = 4 * T * T * k_channels per head
         PROFILER.records.append((lib.vs_last_kernel_name().decode(), 4.0 * B * C * T * T, 4.0 * B * 4 * C * T, e0, e1))

@@ -165,11 +165,14 @@ class VISingerTrainer(nn.Module):
             opt.step()
             opt.zero_grad(set_to_none=True)      # trainer.py:373-374: no stale gradients in the next pass's clip norm
             self.on_after_optimization()
-            logs.update({k: float(v.detach()) for k, v in parts.items()})
+            logs.update({k: v.detach() for k, v in parts.items()})
         for p in self.parameters():
             p.requires_grad_(True)
         self.global_step += 1
-        return logs
+        # the loss values go to the host ONCE, at the end of the step: reading the generator pass's values before launching the
+        # discriminator pass drained the queue in the middle of every step (tools/train_phases.py: 15 ms of host wait, after which the
+        # discriminator pass started on an idle GPU)
+        return {k: float(v) for k, v in logs.items()}
 
 
 def synthetic_train_batch(B, T, Tph, hop, ph_dict, n_bins, seed, device):
