@@ -94,25 +94,29 @@ def test_latest_round2_profile_agrees_and_pair_kernel_traffic_is_compulsory():
     assert "hbm_frac_of_8tbps" in c5["roofline"]
 
 
-def test_round3_profile_split_f16_engine_and_whole_resblock_launches():
-    """profiles/r03_c_* (end of round 3, `tools/profile_round.sh r03_c`): the dominant instance is the split-f16 x3 conv (TERMS = 3), its
+import pytest
+
+
+@pytest.mark.parametrize("tag", ["r03_c", "r03_d"])
+def test_round3_profile_split_f16_engine_and_whole_resblock_launches(tag):
+    """profiles/r03_d_* (end of round 3, `tools/profile_round.sh r03_d`; r03_c_*: the same six hours earlier): the dominant instance is the split-f16 x3 conv (TERMS = 3), its
     `peak` is the f16 MFMA peak / 3 cross products, rocprofv3's average launch equals the HIP-event average of the same run, the line
     carries the waveform check against the oracle, configs 2 / 3 / 5 and the previous default engine
     timed in the same process; the whole-resblock launches write y exactly once and move at most ~3.6 tensor passes (x, MRF accumulator,
     y + the halo columns of the tile under the doubled FETCH_SIZE, an upper bound) where the per-pair launches of round 2 moved 2.3 passes
     PER PAIR (three pairs per block)."""
     dom = "conv_split_kernel<1, 8, 4, 1, 3>"
-    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r03_c_")
-    line = json.load(open(os.path.join(ROOT, "profiles", "r03_c_bench_line_profiled.json")))
+    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r03_d_")          # the newest committed summary is the one bench.py cites
+    line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line_profiled.json")))
     r = line["roofline"]
     assert r["kernel"] == dom and r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 3.0) < 1e-6
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["executed_tflops"] - 3.0 * r["achieved"]) < 1e-6
-    with open(os.path.join(ROOT, "profiles", "r03_c_bench_kernel_stats.csv"), newline="") as f:
+    with open(os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv"), newline="") as f:
         rows = {row["Name"]: row for row in csv.DictReader(f)}
     avg_ms = float(rows["void vs::%s(vs::ConvParams)" % dom]["AverageNs"]) * 1e-6
     assert abs(avg_ms - r["avg_launch_ms"]) <= 0.02 * avg_ms
     assert not any("respair" in n for n in rows)               # the fp32 headline no longer launches per-pair kernels
-    full = json.load(open(os.path.join(ROOT, "profiles", "r03_c_full_bench_line.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", tag + "_full_bench_line.json")))
     assert full["steps"] == 30 and full["warmup"] == 10 and full["value"] > 100e6 and full["ms_per_step"] < 82.0
     assert full["flow_logdet_rel_err"] <= 1e-4
     assert full["waveform_max_abs_err"] <= 1e-4 and full["cpu_baseline"]["waveform_max_abs_err"] == full["waveform_max_abs_err"]
@@ -124,14 +128,14 @@ def test_round3_profile_split_f16_engine_and_whole_resblock_launches():
     assert oc["2"]["config"]["baseline_config"] == 2 and oc["2"]["cpu_baseline"]["waveform_max_abs_err"] <= 1e-4 and oc["2"]["ms_per_step"] < 13.0
     assert oc["3"]["config"]["baseline_config"] == 3 and oc["3"]["config"]["p_dropout"] == 0.1 and oc["3"]["ms_per_step"] < 120.0
     assert oc["5"]["config"]["baseline_config"] == 5 and "bf16-resident" in oc["5"]["dtype"] and oc["5"]["ms_per_step"] < 75.0
-    t = json.load(open(os.path.join(ROOT, "profiles", "r03_c_pmc_traffic.json")))["kernels"]
+    t = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json")))["kernels"]
     one = 32 * 32 * 256 * 1024 * 4.0                                                   # one tensor pass of a generator stage, B = 32
     for name, k in t.items():
         if name.startswith("resblock_f16_kernel<"):
             assert abs(k["write_size_bytes_per_launch"] - one) <= 0.01 * one, name     # y exactly once, no scratch stores
             assert k["hbm_bytes_per_launch_corrected"] <= 3.6 * one, (name, k["hbm_bytes_per_launch_corrected"] / one)
     assert sum(n.startswith("resblock_f16_kernel<") for n in t) == 7
-    m = json.load(open(os.path.join(ROOT, "profiles", "r03_c_pmc_mfma_busy.json")))["kernels"]
+    m = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_mfma_busy.json")))["kernels"]
     assert abs(m["conv_split_kernel<1,8,4,1,3>"]["mfma_tflops_executed"] - r["executed_tflops"]) <= 0.03 * r["executed_tflops"]
 
 
