@@ -415,6 +415,41 @@ def test_prepacked_kv_attention_is_bit_identical(vs_option, dk, nh, T, ws, share
         assert torch.equal(packed, plain)
 
 
+def test_prepacked_kv_attention_replays_from_a_hip_graph():
+    """ops.rel_attention takes the scratch of the K / V tile images from torch's caching allocator, so the packed path stays capturable:
+    pack kernel + attention kernel recorded into a HIP graph, replayed on NEW q | k | v values in the static input buffer, bit-identical
+    to an eager launch on those values."""
+    from visinger_amd.ops import rel_attention
+    g = torch.Generator().manual_seed(11)
+    B, nh, dk, T, ws = 2, 2, 64, 1024, 4
+    C = nh * dk
+    qkv = torch.randn(B, 3 * C, T, generator=g).cuda()
+    rel_k = (torch.randn(1, 2 * ws + 1, dk, generator=g) * dk ** -0.5).cuda()
+    rel_v = (torch.randn(1, 2 * ws + 1, dk, generator=g) * dk ** -0.5).cuda()
+    mask = (torch.arange(T)[None] < torch.tensor([T, 700])[:, None]).float().cuda()
+    out = torch.empty(B, C, T, device="cuda")
+
+    def step():
+        return rel_attention(qkv, nh, rel_k, rel_v, mask, ws, out=out, math=L.MATH_BF16, ksplit_auto=False)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    assert L.lib().vs_last_kernel_name().decode().endswith(", true>")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    new = torch.randn(B, 3 * C, T, generator=g).cuda()
+    qkv.copy_(new)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = out.clone()
+    assert torch.equal(replayed, rel_attention(new, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=False))
+
+
 def test_bf16_resident_tensors_random_sweep():
     """Randomised version of the two tests above: 160 random (shape, dilation / stride, fused option) cases of the plain-bf16 conv on
     bf16-RESIDENT tensors, each bit for bit against the same launch on the same values held in fp32 (output rounded once)."""
