@@ -135,15 +135,18 @@ __device__ __forceinline__ float f16_inv_scale(int eb) { return u2f((unsigned)(e
 // planes under the scale of its finite neighbours and poisons exactly the outputs whose receptive field holds it, as in fp32.
 __device__ __forceinline__ unsigned f16_maxkey(unsigned key, float v) { return max(key, (f2u(v) << 1) + 0x01000000u); }
 __device__ __forceinline__ int f16_key_exponent(unsigned key) { return max((int)(key >> 24) - 1, 0); }      // biased exponent of the largest finite magnitude
-// largest value of a wave-uniform-to-be 8-bit quantity over the 64 lanes, by bisection with ballots (no LDS, result in an SGPR)
+// largest value of a non-negative quantity over the 64 lanes of a wave, result wave-uniform: an inclusive max-scan in six DPP steps (shifts
+// by 1, 2, 4, 8 inside the rows of 16 lanes with 0 shifted in, then row_bcast:15 / row_bcast:31 across the rows) whose last lane holds the
+// maximum -- ~60 cycles.  (The bisection with eight dependent ballots it replaces cost 660 cycles per staged chunk: a third of the fixed
+// cost of a chunk on the 32-row tiles, tools/conv_stamps.py with -DVS_SPLIT_PERTURB.)
 __device__ __forceinline__ int wave_max_u8(int v) {
-    int cur = 0;
-#pragma unroll
-    for (int bit = 7; bit >= 0; --bit) {
-        const int cand = cur | (1 << bit);
-        if (__builtin_amdgcn_ballot_w64(v >= cand) != 0ull) cur = cand;
-    }
-    return cur;
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));      // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));      // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));      // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));      // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // conv_split.hip
