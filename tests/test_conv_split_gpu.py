@@ -415,6 +415,34 @@ def test_prepacked_kv_attention_is_bit_identical(vs_option, dk, nh, T, ws, share
         assert torch.equal(packed, plain)
 
 
+@pytest.mark.parametrize("cin,cout,k,u,T,B", [(128, 64, 4, 2, 8192, 8), (64, 32, 4, 2, 30000, 4), (256, 128, 16, 8, 1024, 8), (512, 256, 16, 8, 300, 4),
+                                              (128, 64, 7, 3, 7777, 4), (96, 32, 11, 5, 5150, 6)])
+def test_transposed_conv_polyphase_store_path_is_bit_identical(vs_option, cin, cout, k, u, T, B):
+    """conv_split_tr_kernel (csrc/conv_epilogue_tr.inc): the transposed convs between the generator stages store their polyphase outputs
+    with one buffer_store per element (per-lane column offset + wave-uniform row offset) on interior tiles and fall through to the generic
+    epilogue at the edges.  Same accumulators, same finishing fma: bit-identical to the generic instance (VS_NO_TR_EPI), and within the
+    arithmetic's error of the fp64 oracle -- the generator's own strides (2, 8), the hop-300 generator's (3, 5), lengths that end inside
+    a tile, item counts > 1."""
+    from visinger_amd.ops import ConvOp
+    g = torch.Generator().manual_seed(cin + k + T)
+    pad = (k - u) // 2
+    op = ConvOp(L.CONV_TRANSPOSE1D, cin, cout, k, u, pad)
+    w = (torch.randn(cin, cout, k, generator=g) * (cin * k / u) ** -0.5).cuda()
+    bias = (0.1 * torch.randn(cout, generator=g)).cuda()
+    op.set_weights(w, None, bias)
+    x = torch.randn(B, cin, T, generator=g).cuda()
+    y = op.forward(x, in_act=L.IN_LRELU)
+    name = op.kernel_instance()
+    assert name.startswith("conv_split_tr_kernel<"), name
+    vs_option("VS_NO_TR_EPI", 1)
+    y0 = op.forward(x, in_act=L.IN_LRELU)
+    assert op.kernel_instance().startswith("conv_split_kernel<")
+    assert torch.equal(y, y0)
+    ref = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x.double(), 0.1), w.double(), bias.double(), stride=u, padding=pad)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_prepacked_kv_attention_replays_from_a_hip_graph():
     """ops.rel_attention takes the scratch of the K / V tile images from torch's caching allocator, so the packed path stays capturable:
     pack kernel + attention kernel recorded into a HIP graph, replayed on NEW q | k | v values in the static input buffer, bit-identical

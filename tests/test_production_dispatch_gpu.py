@@ -123,7 +123,7 @@ def test_headline_batch_items_against_the_oracle(oracle, capsys):
     assert wav.shape == (B, T * 256) and bool(torch.isfinite(wav).all())
     for must in ("conv_split_kernel<1, 8, 4, 1, 3>", "conv_split_kernel<1, 4, 2, 2, 3>", "conv_split_kernel<2, 2, 2, 2, 3>",
                  "resblock_f16_kernel<2, 1, 4, 8>", "resblock_f16_kernel<4, 1, 4, 16>", "resblock_f16_kernel<4, 2, 2, 8>", "resblock_f16_kernel<4, 4, 2, 8>",
-                 "relattn_bf16_kernel<3, 32, 6>"):
+                 "conv_split_tr_kernel<1, 8, 4, 1, 3>", "conv_split_tr_kernel<1, 4, 2, 2, 3>", "relattn_bf16_kernel<3, 32, 6>"):
         assert must in names, (must, sorted(names))
     oracle.set_threads(bench.usable_cores())
     tol_v = 1e-3          # voicing threshold (pred[..., 1] <= 0): frames the oracle itself puts within tol_v of 0 take the device's decision

@@ -45,6 +45,16 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams p) 
 #undef VS_EPILOGUE_INC
 }
 
+// Transposed convs: the same body with the polyphase stores of conv_epilogue_tr.inc in front of the generic epilogue.  A kernel template
+// of its own so that the instances every other conv runs stay byte-identical.
+template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
+__global__ void __launch_bounds__(256, 2) conv_split_tr_kernel(const ConvParams p) {
+    constexpr bool XB = false;
+#define VS_EPILOGUE_INC "conv_epilogue_tr.inc"
+#include "conv_split_body.inc"
+#undef VS_EPILOGUE_INC
+}
+
 // bf16-RESIDENT tensors (plain-bf16 arithmetic only, BASELINE config 5): IO bit 0 -- x holds bf16 elements (widened on the way into LDS:
 // every product of this arithmetic rounds its operands to bf16 anyway), bit 1 -- y / res / acc do (rounded to nearest even once, after
 // residual / accumulate / scale / activation in fp32).  A kernel template of its own over the same body: generalising the fp32 instances
@@ -164,6 +174,25 @@ static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
     constexpr int BN = 32 * NT_W * WAVES_N;
     constexpr int BM_TILES = MT_W * WAVES_M;
     constexpr int NPL = (TERMS == 1) ? 1 : (TERMS == 3 ? 2 : 3);
+    // (transposed convs on the 128- / 64-row tiles of the split-f16 arithmetic: the instance with the polyphase store path)
+    constexpr bool HAS_TR = (IO == 0) && (TERMS == 3) && (MT_W == 1) && (WAVES_M > 1);
+    if constexpr (HAS_TR) {
+        if (p.kind == VS_CONV_TRANSPOSE1D && !opt(OPT_NO_TR_EPI)) {
+            auto kt = conv_split_tr_kernel<MT_W, NT_W, WAVES_M, WAVES_N, TERMS>;
+            p.W = BN + span;
+            const size_t lds_t = std::max<size_t>((size_t)2 * NPL * 2 * p.W * 16 + 32, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
+            static bool attr_set_t = false;
+            if (!attr_set_t) {
+                VS_CHECK_HIP(hipFuncSetAttribute((const void *)kt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set_t = true;
+            }
+            dim3 grid_t((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, BM_TILES), (unsigned)p.B);
+            hipLaunchKernelGGL(kt, grid_t, dim3(256), lds_t, s, p);
+            VS_CHECK_HIP(hipGetLastError());
+            set_last_kernel("conv_split_tr_kernel<%d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS);
+            return VS_OK;
+        }
+    }
     auto kern = [] {
         if constexpr (IO == 0) return conv_split_kernel<MT_W, NT_W, WAVES_M, WAVES_N, TERMS>;
         else return conv_split_kernel_bf16io<MT_W, NT_W, WAVES_M, WAVES_N, TERMS, IO>;

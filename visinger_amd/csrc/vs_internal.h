@@ -39,6 +39,7 @@ enum Opt {
     OPT_NO_WGRAD_SPLIT,   // VS_NO_WGRAD_SPLIT: weight gradients on the exact-fp32 kernel only
     OPT_RB_TILE256,       // VS_RB_TILE256: whole-resblock launch at 32 channels on 256-column tiles (default 512: half the weight-fragment traffic and halo per output)
     OPT_NO_ATTN_KVPACK,   // VS_NO_ATTN_KVPACK: the plain-bf16 attention kernel converts K / V tiles in place (no pre-packed images)
+    OPT_NO_TR_EPI,        // VS_NO_TR_EPI: transposed convs on the generic instances (element-wise polyphase stores)
     OPT_COUNT
 };
 long long opt(Opt o);
