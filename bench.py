@@ -198,7 +198,7 @@ def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
     return res
 
 
-PROFILE_TAGS = ("r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e", "r01_c")      # newest first: profiles/<tag>_pmc_*.json
+PROFILE_TAGS = ("r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e", "r01_c")      # newest first: profiles/<tag>_pmc_*.json
 
 
 def _norm(kernel):

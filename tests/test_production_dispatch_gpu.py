@@ -100,7 +100,8 @@ def test_config2_flow_inverse_and_generator_at_full_size(oracle, capsys):
     assert ez[0] <= 5e-5
     assert ew[0] <= 1e-4                                         # waveform: 1e-4 abs (north_star)
     # at this size the launches fill the chip: the production instances, not the small-grid tiles of the T_mel <= 24 tests
-    for must in ("conv_split_kernel<1, 8, 4, 1, 3>", "conv_split_kernel<1, 4, 2, 2, 3>", "resblock_f16_kernel<2, 1, 4, 8>", "resblock_f16_kernel<4, 2, 2, 8>"):
+    for must in ("conv_split_kernel<1, 8, 4, 1, 3>", "conv_split_tr_kernel<1, 8, 4, 1, 3>", "conv_split_tr_kernel<1, 4, 2, 2, 3>", "resblock_f16_kernel<2, 1, 4, 8>",
+                 "resblock_f16_kernel<4, 2, 2, 8>"):
         assert must in names, (must, sorted(names))
 
 

@@ -97,16 +97,16 @@ def test_latest_round2_profile_agrees_and_pair_kernel_traffic_is_compulsory():
 import pytest
 
 
-@pytest.mark.parametrize("tag", ["r03_c", "r03_d", "r03_e"])
+@pytest.mark.parametrize("tag", ["r03_c", "r03_d", "r03_e", "r03_f"])
 def test_round3_profile_split_f16_engine_and_whole_resblock_launches(tag):
-    """profiles/r03_e_* (end of round 3, `tools/profile_round.sh r03_e`; r03_c_* / r03_d_*: the same six / two hours earlier): the dominant instance is the split-f16 x3 conv (TERMS = 3), its
+    """profiles/r03_f_* (end of round 3, `tools/profile_round.sh r03_f`; r03_c_* / r03_d_* / r03_e_*: the same earlier that day): the dominant instance is the split-f16 x3 conv (TERMS = 3), its
     `peak` is the f16 MFMA peak / 3 cross products, rocprofv3's average launch equals the HIP-event average of the same run, the line
     carries the waveform check against the oracle, configs 2 / 3 / 5 and the previous default engine
     timed in the same process; the whole-resblock launches write y exactly once and move at most ~3.6 tensor passes (x, MRF accumulator,
     y + the halo columns of the tile under the doubled FETCH_SIZE, an upper bound) where the per-pair launches of round 2 moved 2.3 passes
     PER PAIR (three pairs per block)."""
     dom = "conv_split_kernel<1, 8, 4, 1, 3>"
-    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r03_e_")          # the newest committed summary is the one bench.py cites
+    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r03_f_")          # the newest committed summary is the one bench.py cites
     line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line_profiled.json")))
     r = line["roofline"]
     assert r["kernel"] == dom and r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 3.0) < 1e-6
