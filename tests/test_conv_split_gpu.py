@@ -312,7 +312,9 @@ def test_bf16_resident_tensors_are_the_bf16_arithmetic_on_rounded_tensors(kind, 
             assert op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 1>", op.kernel_instance()
         y3 = op.forward(xb, res=resb if use_res else None, acc=accb if use_acc else None, y_dtype=torch.bfloat16, **kw)        # bf16 in / out
         assert y3.dtype == torch.bfloat16 and torch.equal(y3, ref.bfloat16()), (kw, float((y3.float() - ref).abs().max()))
-        assert op.kernel_instance().startswith("conv_split_kernel_bf16io<1, ") and op.kernel_instance().endswith(", 1, 3>"), op.kernel_instance()
+        # (a transposed conv with bf16 in AND out runs the instance with the polyphase store path, csrc/conv_epilogue_tr_bf16.inc)
+        assert op.kernel_instance().startswith(("conv_split_kernel_bf16io<1, ", "conv_split_tr_kernel_bf16io<1, ")) and \
+            op.kernel_instance().endswith(", 1, 3>"), op.kernel_instance()
         if not use_res and wide:
             y2 = op.forward(xb.float(), y_dtype=torch.bfloat16, **kw)                                                        # fp32 in, bf16 out
             assert torch.equal(y2, ref.bfloat16()) and op.kernel_instance() == "conv_split_kernel_bf16io<1, 8, 4, 1, 1, 2>"
@@ -441,6 +443,17 @@ def test_transposed_conv_polyphase_store_path_is_bit_identical(vs_option, cin, c
     ref = torch.nn.functional.conv_transpose1d(torch.nn.functional.leaky_relu(x.double(), 0.1), w.double(), bias.double(), stride=u, padding=pad)
     assert y.shape == ref.shape
     assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # the same on bf16-RESIDENT tensors in the plain-bf16 arithmetic (BASELINE config 5): conv_split_tr_kernel_bf16io against its generic instance
+    vs_option("VS_NO_TR_EPI", 0)
+    op.set_math(L.MATH_BF16)
+    xb = x.bfloat16()
+    yb = op.forward(xb, in_act=L.IN_LRELU, y_dtype=torch.bfloat16)
+    if u * cout >= 64:
+        assert op.kernel_instance().startswith("conv_split_tr_kernel_bf16io<"), op.kernel_instance()
+    vs_option("VS_NO_TR_EPI", 1)
+    yb0 = op.forward(xb, in_act=L.IN_LRELU, y_dtype=torch.bfloat16)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, yb0)
+    assert float((yb.double() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
 
 
 def test_prepacked_kv_attention_replays_from_a_hip_graph():

@@ -69,6 +69,16 @@ __global__ void __launch_bounds__(256, 2) conv_split_kernel_bf16io(const ConvPar
 #undef VS_EPILOGUE_INC
 }
 
+template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS, int IO>
+__global__ void __launch_bounds__(256, 2) conv_split_tr_kernel_bf16io(const ConvParams p) {
+    static_assert(TERMS == 1 && IO == 3, "bf16-resident x and y");
+    constexpr bool XB = true;
+    constexpr bool EPI_YB = true;
+#define VS_EPILOGUE_INC "conv_epilogue_tr_bf16.inc"
+#include "conv_split_body.inc"
+#undef VS_EPILOGUE_INC
+}
+
 // Ws[m_tile][tap][chunk][plane][64 lanes][8 bf16] from the fp32 fragment-order weights Wp[m_tile][tap][chunk][quad(2)][64][4]
 // (pack_conv_kernel: lane l of quad qd, element e <-> row l&31, channel chunk*16 + 2*(4*qd + e) + (l>>5)); here lane l,
 // element j <-> row l&31, channel chunk*16 + 8*(l>>5) + j.
@@ -175,10 +185,13 @@ static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
     constexpr int BM_TILES = MT_W * WAVES_M;
     constexpr int NPL = (TERMS == 1) ? 1 : (TERMS == 3 ? 2 : 3);
     // (transposed convs on the 128- / 64-row tiles of the split-f16 arithmetic: the instance with the polyphase store path)
-    constexpr bool HAS_TR = (IO == 0) && (TERMS == 3) && (MT_W == 1) && (WAVES_M > 1);
+    constexpr bool HAS_TR = ((IO == 0 && TERMS == 3) || (IO == 3 && TERMS == 1)) && (MT_W == 1) && (WAVES_M > 1);
     if constexpr (HAS_TR) {
         if (p.kind == VS_CONV_TRANSPOSE1D && !opt(OPT_NO_TR_EPI)) {
-            auto kt = conv_split_tr_kernel<MT_W, NT_W, WAVES_M, WAVES_N, TERMS>;
+            auto kt = [] {
+                if constexpr (IO == 0) return conv_split_tr_kernel<MT_W, NT_W, WAVES_M, WAVES_N, TERMS>;
+                else return conv_split_tr_kernel_bf16io<MT_W, NT_W, WAVES_M, WAVES_N, TERMS, IO>;
+            }();
             p.W = BN + span;
             const size_t lds_t = std::max<size_t>((size_t)2 * NPL * 2 * p.W * 16 + 32, (size_t)4 * 8 * (32 * NT_W) * sizeof(float));
             static bool attr_set_t = false;
@@ -189,7 +202,8 @@ static int launch_split_cfg(ConvParams p, int span, hipStream_t s) {
             dim3 grid_t((unsigned)ceil_div(p.N, BN), (unsigned)ceil_div(p.MT, BM_TILES), (unsigned)p.B);
             hipLaunchKernelGGL(kt, grid_t, dim3(256), lds_t, s, p);
             VS_CHECK_HIP(hipGetLastError());
-            set_last_kernel("conv_split_tr_kernel<%d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS);
+            if (IO) set_last_kernel("conv_split_tr_kernel_bf16io<%d, %d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS, IO);
+            else set_last_kernel("conv_split_tr_kernel<%d, %d, %d, %d, %d>", MT_W, NT_W, WAVES_M, WAVES_N, TERMS);
             return VS_OK;
         }
     }
