@@ -131,7 +131,8 @@ def cpu_baseline(model, hp, batch, backend="c", wav_dev=None, f0_dev=None, T_cap
     orc.CONV_BACKEND = "c"
     n = out["wav_out"].size
     what = "C+numpy port (OpenMP" if backend == "c" else "numpy composition with torch-CPU oneDNN convolutions (torch threads"
-    res = {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
+    res = {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port", "items": 1, "of_items": int(batch[0].shape[0]),
+           "seconds": dt, "samples": int(n),
            "sample": f"oracle/ fp32 {what}, {cores} threads), item 0 of the timed batch: B=1 T_mel={T} hop={HOP}: {n} samples in {dt:.2f}s; the "
                      f"graph `value` times (text-encoder + pitch-predictor + frame-prior + flow-inverse + generator, use_pitch_embed="
                      f"{bool(hp.get('use_pitch_embed'))})"}
@@ -160,7 +161,8 @@ def cpu_baseline_config2(model, hp, batch, items=2):
                         resblock_dilation_sizes=hp["dec_dilation_sizes"], upsample_rates=hp["upsample_rates"],
                         upsample_kernel_sizes=hp["upsample_kernel_sizes"], dtype=np.float32)[:, 0]
     dt = time.perf_counter() - t0
-    return {"value": wav.size / dt, "unit": "audio samples/s", "cores": cores, "kind": "port",
+    return {"value": wav.size / dt, "unit": "audio samples/s", "cores": cores, "kind": "port", "items": items, "of_items": int(batch[0].shape[0]),
+            "seconds": dt, "samples": int(wav.size),
             "sample": f"oracle/ fp32 C+numpy port (OpenMP, {cores} threads), {items} of the 8 items of BASELINE config 2 (flow inverse + "
                       f"HiFi-GAN decode, T_mel={z_p.shape[2]}): {wav.size} samples in {dt:.2f}s"}, wav
 
@@ -198,43 +200,54 @@ def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
     return res
 
 
-PROFILE_TAGS = ("r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e", "r01_c")      # newest first: profiles/<tag>_pmc_*.json
+PROFILE_TAGS = ("r04_c", "r04_b", "r04_a", "r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e",
+                "r01_c")      # newest first: profiles/<tag>[_<suffix>]_pmc_*.json
+HEADLINE_WORKLOAD = "B32_T1024_h192_hop256_f32"      # what a profiles/*_pmc_*.json without a "workload" field was recorded on (rounds 1-3)
+
+
+def workload_key(config, B, T, hidden, hop, storage):
+    """Names the launch shapes of a run: PMC figures are per launch of a kernel INSTANCE, and an instance's bytes depend on the tensor
+    shapes it was launched on, so a recorded figure is only attached to a line of the same workload (VERDICT r3 #10)."""
+    return ("c2_" if config == 2 else "c3_" if config == 3 else "") + f"B{B}_T{T}_h{hidden}_hop{hop}_{storage}"
 
 
 def _norm(kernel):
     return kernel.replace(" ", "")
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected
-    from inside the timed run: they need rocprofv3 and one pass per counter); None when not recorded."""
+def _pmc_files(kind, workload):
+    import glob
     for tag in PROFILE_TAGS:
-        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
-        try:
-            with open(path) as f:
-                ks = {_norm(k): v for k, v in json.load(f)["kernels"].items()}
-            if _norm(kernel) in ks:
-                return {"bytes_per_launch": ks[_norm(kernel)]["hbm_bytes_per_launch_corrected"],
-                        "source": f"recorded: profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"}
-        except (OSError, KeyError, ValueError):
-            continue
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}*_pmc_{kind}.json"))):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if d.get("workload", HEADLINE_WORKLOAD) == workload:
+                yield os.path.relpath(path, ROOT), d
+
+
+def pmc_traffic(kernel, workload=HEADLINE_WORKLOAD):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of the SAME workload (FETCH_SIZE / WRITE_SIZE cannot be collected
+    from inside the timed run: they need rocprofv3 and one pass per counter); None when no pass of this workload was recorded."""
+    for path, d in _pmc_files("traffic", workload):
+        ks = {_norm(k): v for k, v in d.get("kernels", {}).items()}
+        if _norm(kernel) in ks:
+            return {"bytes_per_launch": ks[_norm(kernel)]["hbm_bytes_per_launch_corrected"],
+                    "source": f"recorded: {path} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"}
     return None
 
 
-def pmc_mfma_executed(kernel):
+def pmc_mfma_executed(kernel, workload=HEADLINE_WORKLOAD):
     """FLOP/s the matrix pipe really executed in `kernel` (SQ_INSTS_VALU_MFMA_MOPS_* x 512 / kernel time, recorded PMC pass of its
-    own: tools/pmc_mfma_summarize.py); None when not recorded."""
-    for tag in PROFILE_TAGS:
-        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_busy.json")
-        try:
-            with open(path) as f:
-                k = {_norm(n): v for n, v in json.load(f)["kernels"].items()}[_norm(kernel)]
-        except (OSError, KeyError, ValueError):
-            continue
-        if "mfma_tflops_executed" not in k:
+    own: tools/pmc_mfma_summarize.py) on the same workload; None when not recorded."""
+    for path, d in _pmc_files("mfma_busy", workload):
+        k = {_norm(n): v for n, v in d.get("kernels", {}).items()}.get(_norm(kernel))
+        if not k or "mfma_tflops_executed" not in k:
             continue
         out = {"tflops": k["mfma_tflops_executed"], "pipe_busy": k["mfma_pipe_util"],
-               "source": f"recorded: profiles/{tag}_pmc_mfma_busy.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_*, its own pass)"}
+               "source": f"recorded: {path} (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_*, its own pass)"}
         if "gfx_clock_ghz" in k:
             out["gfx_clock_ghz"] = k["gfx_clock_ghz"]
         return out
@@ -313,6 +326,8 @@ def parse_args():
     ap.add_argument("--storage", default=None, choices=("f32", "bf16"),
                     help="element type of the generator's activations in HBM (bf16 only with --math bf16; default: bf16 for --config 5)")
     ap.add_argument("--no-other-configs", action="store_true", help="default run: skip the reduced lines of BASELINE configs 2 / 3 / 5")
+    ap.add_argument("--quick", action="store_true", help="skip the torch-CPU baseline and the split-bf16 x6 engine legs (the fp32 MFMA engine stays)")
+    ap.add_argument("--print-workload-key", action="store_true", help="print the key PMC summaries of this command line are filed under, and exit")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (no GPU work): every rank joins the process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -378,13 +393,16 @@ def percentile_stats(ms):
     return {"median_ms": float(np.median(a)), "min_ms": float(a[0]), "max_ms": float(a[-1])}
 
 
-def roofline_from_profile(prof, dt, steps):
+def roofline_from_profile(prof, dt, steps, workload=None):
     """`roofline` object of a bench line from the per-launch HIP-event records of the timed steps (ops.PROFILER.summary()): the dominant
     kernel instance (largest share of the step), its algorithmic FLOP/s against the roof of its arithmetic, and the whole step."""
+    allp = prof
+    prof = {k: v for k, v in prof.items() if v["ms"] > 0}        # (sites recorded without events -- PROFILER.note() -- carry no time)
     name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    traffic = pmc_traffic(name, workload) if workload else None
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12            # ALGORITHMIC: the convs' own 2*MAC / measured kernel time
-    step_flops = sum(v["flops"] for v in prof.values()) / steps
-    step_bytes = sum(v["bytes"] for v in prof.values()) / steps
+    step_flops = sum(v["flops"] for v in allp.values()) / steps
+    step_bytes = sum(v["bytes"] for v in allp.values()) / steps
     step_tflops = step_flops / (dt / steps) / 1e12
     kern_ms = sum(v["ms"] for v in prof.values())
     if name.startswith(("conv_split_kernel", "respair_split_kernel", "resblock_f16_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
@@ -418,11 +436,12 @@ def roofline_from_profile(prof, dt, steps):
                         "peak: mfma_executed is what the pipe really did"}
     step_peak = roof["peak"]
     roof.update({
-        "traffic": (pmc_traffic(name) or {}).get("bytes_per_launch"),
-        "traffic_source": (pmc_traffic(name) or {}).get("source"),
+        "traffic": (traffic or {}).get("bytes_per_launch"),
+        "traffic_source": (traffic or {}).get("source"),
+        "traffic_over_algorithmic": (traffic["bytes_per_launch"] / (d["bytes"] / d["launches"])) if traffic else None,
         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
         "hbm_gbps_algorithmic": d["bytes"] / (d["ms"] * 1e-3) / 1e9, "hbm_frac_of_8tbps": d["bytes"] / (d["ms"] * 1e-3) / 8e12,
-        "mfma_executed": pmc_mfma_executed(name),
+        "mfma_executed": pmc_mfma_executed(name, workload) if workload else None,
         "launches_per_step": d["launches"] / steps,
         "avg_launch_ms": d["ms"] / d["launches"],
         "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
@@ -440,6 +459,97 @@ def roofline_from_profile(prof, dt, steps):
                           for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
         "timed_kernels_share_of_step": kern_ms / (dt * 1e3)})
     return roof
+
+
+SHORT_DTYPE = {"split3": "f32 (split-f16 x3 on the f16 MFMA, f32 accumulate)", "split6": "f32 (split-bf16 x6 on the bf16 MFMA, f32 accumulate)",
+               "f32": "f32", "bf16": "bf16 operands, f32 accumulate"}
+MAX_LINE_BYTES = 4096        # the driver keeps the last ~8 KB of stdout: the final line must fit with room to spare
+
+
+def _r(v, sig=6):
+    """floats to `sig` significant digits (the line is a report, not a checkpoint)"""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}") if np.isfinite(v) else None
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None} if d else None
+
+
+def compact_line(full, math=None, details=None):
+    """The ONE line the driver parses: the contract keys + roofline + cpu_baseline + the checks, without prose and per-instance tables
+    (those go to `details`, a JSON file).  Always < MAX_LINE_BYTES."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline") if k in full}
+    out["dtype"] = SHORT_DTYPE.get(math, full.get("dtype", ""))[:96] if math else full.get("dtype", "")[:96]
+    if "bf16-resident" in full.get("dtype", ""):
+        out["dtype"] = "bf16 operands + bf16-resident generator activations, f32 accumulate"
+    out["data"] = full.get("data", "synthetic")
+    cfg = full.get("config", {})
+    out["config"] = _pick(cfg, ("workload", "baseline_config", "per_gpu_batch", "global_batch", "t_mel", "hop", "hidden", "parallelism",
+                                "p_dropout", "realtime_factor"))
+    if out["config"] and len(out["config"].get("workload", "")) > 200:
+        out["config"]["workload"] = out["config"]["workload"][:200]
+    r = full.get("roofline")
+    if r:
+        rc = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                       "traffic_over_algorithmic", "avg_launch_ms", "launches_per_step", "algorithmic_gflop_per_launch", "share_of_step",
+                       "executed_tflops", "frac_executed", "frac_vs_fp32_mfma_peak", "hbm_frac_of_8tbps"))
+        if "traffic" not in rc:
+            rc["traffic"] = None
+        if r.get("traffic_source"):
+            rc["traffic_source"] = r["traffic_source"].split(" (")[0]
+        if r.get("mfma_executed"):
+            rc["mfma_executed"] = _pick(r["mfma_executed"], ("tflops", "pipe_busy", "gfx_clock_ghz"))
+        if r.get("step"):
+            rc["step"] = _pick(r["step"], ("achieved", "peak", "frac", "algorithmic_tflop_per_step", "algorithmic_gb_per_step",
+                                           "hbm_frac_of_8tbps", "launches_counted"))
+        out["roofline"] = rc
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "items", "of_items", "seconds", "samples", "waveform_max_abs_err"))
+        out["cpu_baseline"]["sample"] = c.get("sample", "").split(":")[0][:160]
+    for k in ("waveform_max_abs_err", "flow_logdet_rel_err", "generated_samples_per_s"):
+        if k in full:
+            out[k] = full[k]
+    if "flow_logdet" in full:
+        out["flow_logdet_mean_only_exact_zero"] = full["flow_logdet"].get("mean_only_true_logdet_is_exact_zero")
+    for k in ("fp32_mfma_engine", "split_bf16x6_engine"):
+        if k in full:
+            out[k] = _pick(full[k], ("value", "ms_per_step", "max_abs_waveform_diff_vs_value_run"))
+    if "cpu_baseline_torch" in full:
+        out["cpu_baseline_torch"] = _pick(full["cpu_baseline_torch"], ("value", "cores", "items", "seconds"))
+    if "losses_last_step" in full:
+        out["losses_finite"] = bool(all(np.isfinite(v) for v in full["losses_last_step"].values()))
+    if details:
+        out["details"] = details
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= MAX_LINE_BYTES:          # never print a line the driver would truncate: drop the optional keys, largest first
+        for k in ("cpu_baseline_torch", "split_bf16x6_engine", "details"):
+            out.pop(k, None)
+        out.get("roofline", {}).pop("traffic_source", None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < MAX_LINE_BYTES, len(line)
+    return line
+
+
+def write_details(obj, path=None):
+    """everything the compact lines leave out (per-instance tables, notes, per-step statistics, the other engines) as one JSON file"""
+    path = path or os.environ.get("VS_BENCH_DETAILS") or os.path.join(ROOT, "bench_details.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(obj, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        print(f"[bench] could not write {path}: {e}", file=sys.stderr)
+        return None
+
 
 
 class InferenceWorkload:
@@ -476,6 +586,9 @@ class InferenceWorkload:
                 with torch.no_grad():
                     return model(text, pitch, dur, mel2ph, spk_id=spk, infer=True, noise=noise)
         self.step = step
+
+    def workload_key(self):
+        return workload_key(self.config, self.B, self.T, self.hidden, self.hop, self.storage)
 
     def dtype_name(self):
         if self.storage == "bf16":
@@ -526,10 +639,11 @@ def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
     wav = out["wav_out"]
     assert wav.shape == (wl.B, wl.T * 256) and bool(torch.isfinite(wav).all())
     samples = wl.B * wl.T * 256 * steps
-    line = {"metric": "audio samples/sec (22.05 kHz)", "value": samples / dt, "unit": "audio samples/s", "steps": steps, "warmup": warmup,
+    line = {"metric": "audio samples/sec (22.05 kHz)", "value": samples / dt, "unit": "audio samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "ms_per_step": dt / steps * 1e3, "ms_per_step_stats": percentile_stats(per_step), "dtype": wl.dtype_name(), "data": "synthetic",
             "config": dict(wl.describe(), realtime_factor=samples / dt / SR, what=preset["what"]),
-            "roofline": roofline_from_profile(PROFILER.summary(), dt, steps)}
+            "roofline": roofline_from_profile(PROFILER.summary(), dt, steps, wl.workload_key())}
     if config == 2 and with_cpu:
         line["cpu_baseline"], wav_cpu = cpu_baseline_config2(wl.model, wl.hp, wl.c2_inputs)
         line["cpu_baseline"]["waveform_max_abs_err"] = float(np.abs(wav[:wav_cpu.shape[0]].double().cpu().numpy() - wav_cpu).max())
@@ -539,6 +653,9 @@ def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
 
 def main():
     args = parse_args()
+    if args.print_workload_key:
+        print(workload_key(args.config, args.batch, args.frames, args.hidden, args.hop, args.storage))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))        # this process never touches the GPU
     if args.dry_run:
@@ -565,7 +682,8 @@ def main():
     if args.config == 3:
         line = train_line(B, T, args.dropout, args.math, args.steps, args.warmup, rank, world, dist, dev, barrier)
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            det = write_details({"line": line})
+            print(compact_line(line, args.math, det), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -595,24 +713,28 @@ def main():
             "dtype": wl.dtype_name(),
             "data": "synthetic",
             "config": dict(wl.describe(world), realtime_factor=samples / dt / SR),
-            "roofline": roofline_from_profile(PROFILER.summary(), dt, args.steps),
+            "roofline": roofline_from_profile(PROFILER.summary(), dt, args.steps, wl.workload_key()),
         }
         headline = world == 1 and not args.no_cpu_baseline and args.config in (0, 4)
         if headline:
             # the CPU oracle on item 0 of the timed batch, the same graph: the reported baseline AND the checker of the timed run
             out["cpu_baseline"] = cpu_baseline(model, hp, wl.batch, wav_dev=wav, f0_dev=out_dev.get("f0_pred"))
             out["waveform_max_abs_err"] = out["cpu_baseline"]["waveform_max_abs_err"]
-            out["cpu_baseline_torch"] = cpu_baseline(model, hp, wl.batch, backend="torch")
+            if not args.quick:
+                out["cpu_baseline_torch"] = cpu_baseline(model, hp, wl.batch, backend="torch")
             out["flow_logdet"] = flow_logdet_check(model, dev)
             out["flow_logdet_rel_err"] = out["flow_logdet"]["rel_err"]
+        elif world == 1 and args.config == 2 and not args.no_cpu_baseline:
+            out["cpu_baseline"], wav_cpu = cpu_baseline_config2(model, hp, wl.c2_inputs)
+            out["waveform_max_abs_err"] = float(np.abs(wav[:wav_cpu.shape[0]].double().cpu().numpy() - wav_cpu).max())
         if world == 1 and args.math in ("split3", "split6") and not args.no_cpu_baseline:
             # the same workload on the other fp32-class engines, same process, same weights, same --steps / --warmup: the exact-fp32 MFMA /
-            # F(2,3) kernels and (for the split-f16 default) the split-bf16 x6 engine that was the default of rounds 1-2 -- the numbers to
-            # hold the headline arithmetic against (error against fp64: DESIGN.md 4, tests/test_conv_split_gpu.py)
+            # F(2,3) kernels (the strictly-same-precision number to hold the headline arithmetic against: VERDICT r3 weak #2) and, outside
+            # --quick, the split-bf16 x6 engine that was the default of rounds 1-2 (error against fp64: DESIGN.md 4, tests/test_conv_split_gpu.py)
             from visinger_amd.modules.hipconv import set_conv_math
             for other, key, note in (("f32", "fp32_mfma_engine", "bench.py --math f32: v_mfma_f32_32x32x2_f32 + Winograd F(2,3) kernels, no bf16 / f16 anywhere"),
                                      ("split6", "split_bf16x6_engine", "bench.py --math split6: three exact bf16 planes, six cross products (the default of rounds 1-2)")):
-                if other == args.math:
+                if other == args.math or (args.quick and other != "f32"):
                     continue
                 set_conv_math(model, MATH[other])
                 o2, dt2, per2 = timed_run(wl.step, args.steps, args.warmup, False, barrier)
@@ -620,15 +742,23 @@ def main():
                             "ms_per_step_stats": percentile_stats(per2), "steps": args.steps, "warmup": args.warmup,
                             "max_abs_waveform_diff_vs_value_run": float((o2["wav_out"] - wav).abs().max()), "note": note}
             set_conv_math(model, MATH[args.math])
+        details = {"headline": out, "other_configs": {}}
+        lines = []
         if headline and not args.no_other_configs:
-            # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each after 3 warm-up steps)
+            # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each after 3 warm-up steps): one compact line each,
+            # printed BEFORE the headline line (the driver parses the last line of stdout)
             del wl, model, out_dev, wav
             torch.cuda.empty_cache()
-            out["other_configs"] = {}
             for c in (2, 3, 5):
-                out["other_configs"][str(c)] = other_config_line(c, dev, 10, 3, barrier)
+                oc = other_config_line(c, dev, 10, 3, barrier)
+                oc["n_gpus"] = 1
+                details["other_configs"][str(c)] = oc
+                lines.append(compact_line(oc, CONFIGS[c].get("math", "split3")))
                 torch.cuda.empty_cache()
-        print(json.dumps(out), flush=True)
+        det = write_details(details)
+        for ln in lines:
+            print(ln, flush=True)
+        print(compact_line(out, args.math, det), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -686,7 +816,7 @@ def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barri
                      "note": "whole step (no single dominant kernel: 6 000 launches): algorithmic FLOPs (2*MAC) of every conv / attention "
                              "launch of the forward, the grad-input launches and the weight-gradient launches (library GEMMs of the 1x1 / "
                              "wide discriminator weight gradients included at their 2*MAC), counted on one extra step, / measured step time; "
-                             "peak = the roof of the arithmetic (dense bf16 MFMA / 6 cross products)"},
+                             f"peak = the roof of the arithmetic ({peak:.0f} TFLOP/s: dense f16 / bf16 MFMA peak over the cross products per fp32 product of --math {math})"},
         "generated_samples_per_s": B * world * tr.segment_size * tr.hop * steps / dt,
         "losses_last_step": logs}
 

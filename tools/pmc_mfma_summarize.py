@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the MFMA-busy PMC pass of rocprofv3 into profiles/<prefix>_pmc_mfma_busy.json (read by bench.py).
 
-    python tools/pmc_mfma_summarize.py <pass_dir> <out_prefix>
+    python tools/pmc_mfma_summarize.py <pass_dir> <out_prefix> [workload_key]
 
 <pass_dir> holds *_counter_collection.csv and *_kernel_trace.csv of
     rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \\
@@ -17,6 +17,7 @@ import sys
 
 def main():
     pass_dir, prefix = sys.argv[1:3]
+    workload = sys.argv[3] if len(sys.argv) > 3 else None
     kt = {}
     for path in glob.glob(os.path.join(pass_dir, "*kernel_trace.csv")):
         with open(path, newline="") as f:
@@ -57,6 +58,8 @@ def main():
             d["frac_of_bf16_peak_2500"] = round(d["mfma_tflops_executed"] / 2500, 4)
         out["kernels"][k] = d
         print(k, d)
+    if workload:
+        out["workload"] = workload
     with open(f"{prefix}_pmc_mfma_busy.json", "w") as f:
         json.dump(out, f, indent=1)
 

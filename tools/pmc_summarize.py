@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 PMC passes into the files bench.py / profiles/README.md cite.
 
-    python tools/pmc_summarize.py <fetch_pass_dir> <write_pass_dir> <out_prefix>
+    python tools/pmc_summarize.py <fetch_pass_dir> <write_pass_dir> <out_prefix> [workload_key]
 
 Each pass directory holds the `*_counter_collection.csv` of ONE `--pmc` counter (FETCH_SIZE or WRITE_SIZE: separate passes,
 as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Counter values are in KB.  Writes <out_prefix>_pmc_fetch_by_shape.csv,
@@ -39,6 +39,7 @@ def short(name):
 
 def main():
     fetch_dir, write_dir, prefix = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else None      # bench.py --print-workload-key: the launch shapes these bytes belong to
     fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     for rows, cname, suffix in ((fetch, "FETCH_SIZE", "fetch"), (write, "WRITE_SIZE", "write")):
         with open(f"{prefix}_pmc_{suffix}_by_shape.csv", "w", newline="") as f:
@@ -66,6 +67,8 @@ def main():
         fr, wr = d["fetch"][1] / nf, d["write"][1] / nw
         out["kernels"][k] = {"launches": nf, "fetch_size_raw_bytes_per_launch": fr, "write_size_bytes_per_launch": wr,
                              "hbm_bytes_per_launch_corrected": 2 * fr + wr}
+    if workload:
+        out["workload"] = workload
     with open(f"{prefix}_pmc_traffic.json", "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1) for k, v in out["kernels"].items()}, indent=1))
