@@ -39,6 +39,10 @@ VS_API const char *vs_last_error(void);
  * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
 VS_API const char *vs_last_kernel_name(void);
 VS_API int vs_abi_version(void);          /* 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
+/* sha256 (hex) over the sources this library was compiled from (kernels, headers, textual includes, the build recipe), embedded by
+ * visinger_amd/csrc/build.py.  The loader recomputes it over the tree it sits in and refuses a library built from other sources (a
+ * stale object that an mtime check would pass after a checkout).  (No reference counterpart: the reference has no native code.)  */
+VS_API const char *vs_source_hash(void);
 /* Dispatch switches (A/B comparisons and debugging; never needed for correct results).  The library reads the environment
  * variables of the same names ONCE, when it is loaded; afterwards only these calls change a switch, and no launch path touches
  * the environment.  Names and meanings: INTEGRATION.md "Switches".  Unknown name -> VS_EINVAL.  (No reference counterpart: the

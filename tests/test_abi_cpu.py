@@ -33,6 +33,43 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().vs_abi_version() == _lib.EXPECTED_ABI == 5
 
 
+def test_library_carries_the_hash_of_its_sources_and_a_foreign_build_is_refused(monkeypatch):
+    """binaries built in the container travel to the GPU box; an mtime check passes a stale object after a checkout.
+    The library answers with the sha256 of what it was compiled from and the loader compares it with the tree."""
+    from visinger_amd import _lib
+    from visinger_amd.csrc import build
+    L = _lib.lib()
+    assert L.vs_source_hash().decode() == build.source_hash() and len(build.source_hash()) == 64
+    assert not build.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 64)       # "the tree changed under the library"
+    with pytest.raises(_lib.VisingerHipError, match="built from other sources"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib().vs_abi_version() == _lib.EXPECTED_ABI
+
+
+def test_a_failed_scratch_guard_leaves_no_object_behind(tmp_path, monkeypatch):
+    """hipcc writes the object before the NO_SCRATCH guard can fail; the next incremental build must not find it.
+    A fake compiler that 'succeeds' with a spilling kernel in its remarks: the build raises and neither the .o nor its .tmp exists."""
+    import stat
+    from visinger_amd.csrc import build
+    src = tmp_path / "conv_split.hip"
+    src.write_text("// fake\n")
+    fake = tmp_path / "fakecc"
+    fake.write_text("#!/bin/sh\nwhile [ $# -gt 0 ]; do if [ \"$1\" = -o ]; then out=$2; fi; shift; done\necho obj > $out\n"
+                    "echo 'x.hip:1:1: remark: Function Name: _ZN2vs17conv_split_kernelILi1EEEvv [-Rpass-analysis=kernel-resource-usage]' 1>&2\n"
+                    "echo 'x.hip:1:1: remark:     ScratchSize [bytes/lane]: 112 [-Rpass-analysis=kernel-resource-usage]' 1>&2\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(build, "HERE", str(tmp_path))
+    monkeypatch.setattr(build, "LIB", str(tmp_path / "lib.so"))
+    monkeypatch.setattr(build, "STAMP", str(tmp_path / ".build_stamp.json"))
+    monkeypatch.setattr(build, "HIPCC", str(fake))
+    with pytest.raises(RuntimeError, match="must not use scratch"):
+        build.build(verbose=False)
+    assert not (tmp_path / "conv_split.o").exists() and not (tmp_path / "conv_split.o.tmp").exists() and not (tmp_path / "lib.so").exists()
+
+
 def test_arguments_are_validated_without_a_gpu():
     from visinger_amd import _lib
     L = _lib.lib()

@@ -89,6 +89,35 @@ def test_full_size_coupling_logdet_1e4_relative(oracle):
     assert maxerr(xr[:, 96:] , x[:, 96:] * mask) <= 5e-5            # decode(encode(x)) == x on valid frames
 
 
+@pytest.mark.parametrize("math", [0, 3, 6])
+def test_affine_coupling_logdet_is_run_to_run_bit_identical(oracle, math, vs_option):
+    """the log-det of the affine coupling (mean_only=False) is a wavefront-shuffle sum per tile stored in the tile's own
+    slot plus a fixed-order pass over the slots (logdet_reduce_kernel) -- no atomics: the same bits every run, on every engine, at a
+    length that spans many workgroups (T = 5000: 20+ column tiles x 3 channel pairs per item), ragged mask; and still within 1e-4
+    relative of the fp64 oracle."""
+    from visinger_amd.modules.visinger.flow import ResidualCouplingLayer
+    vs_option("VS_CONV_MATH", math)
+    B, T = 3, 5000
+    m = ResidualCouplingLayer(192, 192, 5, 1, 4, gin_channels=256, mean_only=False)
+    sd = _rand_sd(m, 5, scale=0.5)
+    m = m.cuda().eval()
+    r = np.random.default_rng(8)
+    x = r.standard_normal((B, 192, T)).astype(np.float32)
+    g = r.standard_normal((B, 256, 1)).astype(np.float32)
+    mask = np.ones((B, 1, T), np.float32)
+    mask[1, :, 3333:] = 0
+    mask[2, :, 17:] = 0
+    xs, ms, gs = cu(x), cu(mask), cu(g)
+    with torch.no_grad():
+        runs = [m(xs, ms, g=gs, reverse=False) for _ in range(6)]
+    for y, ld in runs[1:]:
+        assert torch.equal(ld, runs[0][1]) and torch.equal(y, runs[0][0])
+    _, ref_ld = oracle.coupling_layer(sd, x, mask, g, False, channels=192, hidden_channels=192, kernel_size=5, dilation_rate=1, n_layers=4,
+                                      mean_only=False)
+    rel = np.abs(runs[0][1].cpu().double().numpy() - ref_ld) / np.abs(ref_ld)
+    assert rel.max() <= 1e-4, rel
+
+
 def test_full_size_flow_inverse_and_generator_vs_oracle(oracle):
     """BASELINE config-2 path (flow inverse + HiFi-GAN, hop 256) at hidden 192 on a short clip vs the fp64 oracle."""
     from visinger_amd.modules.visinger.flow import ResidualCouplingBlock
@@ -278,7 +307,7 @@ def test_synthesis_step_is_graph_capturable(tiny):
 
 def test_synthesis_is_run_to_run_deterministic(tiny):
     """No atomics and no data-dependent scheduling on the synthesis path: the same inputs give the same bits, run after run
-    (the only float atomics of the library are the flow's forward log-det accumulation, one add per wave, training side)."""
+    (the flow's forward log-det has no atomics either: test_affine_coupling_logdet_is_run_to_run_bit_identical)."""
     model, a, _, _ = tiny
     args = [cu(a[k]) for k in ("text", "pitch", "dur", "mel2ph")]
     spk, noise = cu(a["spk_id"]), cu(a["noise"])

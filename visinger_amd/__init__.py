@@ -6,9 +6,6 @@ runs in ``csrc/libvisinger_hip.so`` through the C ABI of ``include/visinger_hip.
 makes the reference's own ``models/visinger.py`` import these classes unchanged.
 """
 import sys
-import warnings
-
-warnings.filterwarnings("ignore", message=".*weight_norm.*is deprecated.*", category=FutureWarning)
 
 __version__ = "0.1.0"
 

@@ -69,6 +69,17 @@ def lib():
     if got != EXPECTED_ABI:       # a stale or partially rebuilt .so would be called with the wrong argument layout (ConvIO, vs_relattn_fwd)
         raise VisingerHipError(f"{LIB_PATH} exports ABI version {got}, this package binds version {EXPECTED_ABI}: rebuild it "
                                f"(python -m visinger_amd.csrc.build --force)")
+    # ... and one built from other SOURCES (same ABI number, different kernels: an object file that survived a checkout) must not run
+    # either: the library carries the sha256 of what it was compiled from, recomputed here over the tree it sits in (skipped for a
+    # VS_LIB override -- an A/B build of another tree -- and for an installed library without its sources)
+    L.vs_source_hash.restype = ctypes.c_char_p
+    if not os.environ.get("VS_LIB") and not os.environ.get("VS_SKIP_SOURCE_HASH"):
+        from .csrc import build as _build
+        if _build.sources():
+            built, now = L.vs_source_hash().decode(), _build.source_hash()
+            if built != now:
+                raise VisingerHipError(f"{LIB_PATH} was built from other sources (library {built[:12]}, tree {now[:12]}): rebuild it "
+                                       f"(python -m visinger_amd.csrc.build)")
     L.vs_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.vs_set_option.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.vs_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]

@@ -40,12 +40,40 @@ def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip")))
 
 
+def all_inputs():
+    """every file the library is compiled from (kernels, shared headers / textual includes, the public header, this recipe)"""
+    return sorted(sources() + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.inc")) +
+                  glob.glob(os.path.join(HERE, "..", "..", "include", "*.h")) + [os.path.abspath(__file__)])
+
+
+def source_hash():
+    """sha256 over the names and contents of all_inputs(): compiled into the library (vs_source_hash()) and compared by
+    visinger_amd._lib.lib() at load -- a library built from other sources (a stale object that survived a checkout with a fresh mtime)
+    is refused instead of run.  Content-based: independent of mtimes and of where the tree sits."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in all_inputs():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+STAMP = os.path.join(HERE, ".build_stamp.json")      # {"source_hash": ..., "objects": {src basename: hash of its own inputs}}
+
+
+def _read_stamp():
+    import json
+    try:
+        with open(STAMP) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.inc")) + glob.glob(os.path.join(HERE, "..", "..", "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not os.path.exists(LIB) or _read_stamp().get("source_hash") != source_hash()
 
 
 def includes(path, seen=None):
@@ -64,43 +92,72 @@ def includes(path, seen=None):
     return seen
 
 
-def stale(src, obj):
-    if not os.path.exists(obj):
-        return True
-    t = os.path.getmtime(obj)
-    return any(os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__)] + sorted(includes(src)))
+def unit_hash(src):
+    """hash of one translation unit's inputs (its source, everything it includes, the compiler flags)"""
+    import hashlib
+    h = hashlib.sha256(" ".join([HIPCC] + FLAGS).encode())
+    for path in [src] + sorted(includes(src)):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
 
 
 def build(force=False, verbose=True):
+    import json
     if not force and not needs_build():
         return LIB
-    objs = []
-    procs = []
+    stamp = _read_stamp().get("objects", {}) if not force else {}
+    objs, procs, hashes = [], [], {}
     for src in sources():
         obj = src[:-4] + ".o"
         objs.append(obj)
-        if not force and not stale(src, obj):      # (objects are per translation unit: only the units whose sources changed)
-            continue
-        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        hashes[os.path.basename(src)] = unit_hash(src)
+        if os.path.exists(obj) and stamp.get(os.path.basename(src)) == hashes[os.path.basename(src)]:
+            continue      # (objects are per translation unit: only the units whose inputs changed, by content)
+        # compile to a temporary name: the object only takes its final name once hipcc AND the scratch guard have passed, so a failed
+        # build can never leave a fresh-looking object of a spilling kernel behind for the next incremental build to link (ADVICE r3)
+        tmp = obj + ".tmp"
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", tmp]
         guarded = os.path.basename(src) in NO_SCRATCH
         if guarded:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE if guarded else None, text=True), guarded))
-    for src, pr, guarded in procs:
+        procs.append((src, obj, tmp, subprocess.Popen(cmd, stderr=subprocess.PIPE if guarded else None, text=True), guarded))
+    failed = None
+    for src, obj, tmp, pr, guarded in procs:
         err = pr.communicate()[1] if guarded else None
-        if pr.wait() != 0:
-            if err:
-                sys.stderr.write(err)
-            raise RuntimeError(f"hipcc failed on {src}")
-        if guarded:
-            check_no_scratch(src, err)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        try:
+            if pr.wait() != 0:
+                if err:
+                    sys.stderr.write(err)
+                raise RuntimeError(f"hipcc failed on {src}")
+            if guarded:
+                check_no_scratch(src, err)
+            os.replace(tmp, obj)
+        except RuntimeError as e:
+            failed = failed or e
+            for stale_file in (tmp, obj):
+                if os.path.exists(stale_file):
+                    os.remove(stale_file)
+    if failed:
+        if os.path.exists(STAMP):
+            os.remove(STAMP)
+        raise failed
+    # the source hash the library answers with (vs_source_hash): a generated C file, compiled by the host compiler only
+    digest = source_hash()
+    stamp_c = os.path.join(HERE, "build_stamp.gen.c")
+    with open(stamp_c, "w") as f:
+        f.write('/* generated by build.py */\n__attribute__((visibility("default"))) const char *vs_source_hash(void) { return "%s"; }\n' % digest)
+    stamp_o = os.path.join(HERE, "build_stamp.gen.o")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-c", stamp_c, "-o", stamp_o])
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs + [stamp_o]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.utime(LIB, None)
+    os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as f:
+        json.dump({"source_hash": digest, "objects": hashes}, f, indent=1)
     return LIB
 
 

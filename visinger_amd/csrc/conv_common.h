@@ -30,6 +30,8 @@ struct ConvParams {
     long long bias_b_bs;
     const float *mask;    // [B, Tin]
     float *logdet;
+    float *ld_part;       // PAIRED coupling forward: per-(item, channel pair, 32-column tile) partial log-det sums [B][ld_slots], zeroed by the host;
+    int ld_nt, ld_slots;  // each wave stores its own slot (no atomics), logdet_reduce_kernel adds them up in a fixed order: bit-reproducible
     OutSpec out[2];
     int split_row;
     int kind, pair_mode, in_act;

@@ -1123,6 +1123,17 @@ __global__ void fold_weights_kernel(const float *__restrict__ w, const float *__
     if (i < rows * cols) out[i] = scale ? w[i] * scale[i / cols] : w[i];
 }
 
+// logdet[b] += sum of the item's per-tile partials, in a fixed order: lane l adds slots l, l + 64, ... sequentially, then a wavefront-shuffle
+// butterfly (commutative per step: every lane ends with the same bits).  One wave per item; a few hundred slots.
+__global__ void logdet_reduce_kernel(const float *__restrict__ part, int slots, float *__restrict__ logdet) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int i = lane; i < slots; i += 64) s += part[(long long)b * slots + i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) logdet[b] += s;
+}
+
 static inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 static inline int ceil_div_i(int a, int b) { return -floor_div(-a, b); }
 
@@ -1538,14 +1549,33 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     if (h->kind == VS_CONV1D_PAIRED) {
         p.row_lo = 0;
         p.row_hi = h->c_out;
+        const bool want_ld = (io->pair_mode == VS_PAIR_COUPLING_FWD) && io->logdet;
+        if (want_ld) {
+            // log-det = sum of logs over (channel, frame): every wave leaves the sum of its tile in its own slot, then one workgroup per item
+            // adds the slots in index order onto logdet[b] -- the same bits every run (an atomicAdd per tile summed in retirement order)
+            p.ld_nt = (int)ceil_div(p.N, 32) + 64;                      // (+64: first-tile indices of the trailing waves of the widest tile shape)
+            p.ld_slots = p.ld_nt * (int)ceil_div(h->MT, 2);
+            VS_TRY(h->ldpart.reserve((size_t)p.B * p.ld_slots * sizeof(float)));
+            p.ld_part = h->ldpart.as<float>();
+            VS_CHECK_HIP(hipMemsetAsync(p.ld_part, 0, (size_t)p.B * p.ld_slots * sizeof(float), s));
+        }
+        int rc;
         if (h->math) {
             p.wp = h->ws.as<float>();
             p.wscale = h->wsc.as<float>();
-            return launch_split(p, (h->MT >= 4) ? 4 : 5, h->math, h->span, s);
+            rc = launch_split(p, (h->MT >= 4) ? 4 : 5, h->math, h->span, s);
+        } else if (h->MT >= 4) {
+            p.W = 128 + h->span;
+            rc = launch_cfg<2, 2, 2, 2>(p, s);
+        } else {
+            p.W = 256 + h->span;
+            rc = launch_cfg<2, 2, 1, 4>(p, s);
         }
-        if (h->MT >= 4) { p.W = 128 + h->span; return launch_cfg<2, 2, 2, 2>(p, s); }
-        p.W = 256 + h->span;
-        return launch_cfg<2, 2, 1, 4>(p, s);
+        if (rc == VS_OK && want_ld) {
+            hipLaunchKernelGGL(logdet_reduce_kernel, dim3((unsigned)p.B), dim3(64), 0, s, p.ld_part, p.ld_slots, p.logdet);
+            VS_CHECK_HIP(hipGetLastError());
+        }
+        return rc;
     }
     {
         auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };

@@ -119,6 +119,7 @@ struct vs_conv {
     int pack_gen = 0;                          // weight versions packed in that arithmetic (selects the max slot)
     bool wsplit = false;                       // eligible for conv_wsplit_kernel (F(2,3) on the split-bf16 x6 arithmetic)
     bool wsplit_packed = false;                // wsw holds the transformed weights of the current version
+    vs::DevBuf ldpart;                         // PAIRED coupling forward: per-tile log-det partials (fixed-order reduction, no atomics)
     vs::DevBuf wsw;                            // Us[m_tile][chunk][group][xi][plane][64][8 bf16] (conv_wsplit.hip)
 };
 
