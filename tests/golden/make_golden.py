@@ -22,6 +22,8 @@ Reference symbols exercised (file:line under /root/reference):
   modules/commons/utils.py:86-110       slice_segments, rand_slice_segments, get_padding
   models/commons/align_ops.py:22-26     expand_states
   models/visinger.py:18-112             VISinger (state-dict manifest + tiny infer forward)
+  tasks/visinger.py:127-169, tasks/base.py:227-238   the training losses (called unbound)
+  utils/audio/align.py:58-104, utils/audio/io.py:8-12   get_note2dur, save_wav
 """
 import json
 import os
@@ -443,6 +445,136 @@ def gen_model_pitch():
         json.dump(hp_t, f, sort_keys=True)
 
 
+
+def _import_reference_task():
+    """tasks/visinger.py imports the whole preprocessing / dataset stack at module level (and opens ./preprocessor/text/dict/korean.json
+    relative to the working directory): stub what the image lacks and import it from the reference's root.  Nothing of it is instantiated:
+    the loss METHODS are called unbound on seeded tensors."""
+    for name in ("torchaudio.transforms", "tensorboard", "torch.utils.tensorboard", "textgrid", "miditoolkit", "g2pk", "jamo", "resemblyzer",
+                 "essentia", "essentia.standard", "pypinyin", "g2p_en", "praatio"):
+        sys.modules.setdefault(name, MagicMock())
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import tasks.visinger as tv
+        import tasks.base as tb
+    finally:
+        os.chdir(cwd)
+    return tv, tb
+
+
+def gen_losses():
+    """The loss functions of the GAN training step, from the reference's own task classes (tasks/visinger.py:100-107 KL weighting,
+    127-145 pitch, 140-145 CTC, 147-169 LSGAN + feature matching; tasks/base.py:227-238 masked mel L1 with the `mel_losses: l1:45.0`
+    table of config/models/visinger.yaml:55) called UNBOUND on seeded tensors with the reference's global `hparams` dict set to the YAML
+    values (config/models/visinger.yaml:51-64; lambda_uv / lambda_f0 exist in no YAML: SURVEY 3.5 -- set to lambda_pitch as
+    visinger_amd/train.py does).  Pins visinger_amd/train.py (VERDICT r3 missing #2).  The mel TRANSFORM (torchaudio) stays unpinned."""
+    import yaml
+    from types import SimpleNamespace
+    tv, tb = _import_reference_task()
+    from utils.commons.hparams import hparams
+    cfg = yaml.safe_load(open(os.path.join(REF, "config", "models", "visinger.yaml")))
+    keys = ("lambda_pitch", "lambda_ctc", "lambda_mel_adv", "lambda_kl", "lambda_fm", "kl_start_steps", "kl_min", "mel_losses")
+    hp = {k: cfg[k] for k in keys}
+    hp["lambda_uv"] = hp["lambda_f0"] = hp["lambda_pitch"]
+    hparams.clear()
+    hparams.update(hp)
+    g = torch.Generator().manual_seed(77)
+    B, T, M, Tph, D = 3, 40, 12, 9, 14
+    Task = tv.VISingerTask
+    # ---- masked mel L1 (tasks/base.py:227-238) through add_mel_loss with the parsed `mel_losses` table
+    mel_out = torch.randn(B, T, M, generator=g)
+    mel_tgt = torch.randn(B, T, M, generator=g)
+    mel_tgt[1, 30:] = 0.0                       # padded frames of the target: weight 0
+    mel_tgt[2, 17] = 0.0
+    me = SimpleNamespace(mel_losses={"l1": 45.0})
+    me.l1_loss = lambda a, b: tb.SpeechBaseTask.l1_loss(me, a, b)
+    losses = {}
+    tb.SpeechBaseTask.add_mel_loss(me, mel_out, mel_tgt, losses)
+    out = {"mel_out": mel_out, "mel_tgt": mel_tgt, "mel_l1": losses["mel_l1"], "mel_l1_unweighted": tb.SpeechBaseTask.l1_loss(me, mel_out, mel_tgt)}
+    # ---- pitch (tasks/visinger.py:127-139)
+    mel2ph = torch.randint(1, Tph + 1, (B, T), generator=g)
+    mel2ph[1, 33:] = 0
+    f0 = torch.rand(B, T, generator=g) * 2 + 4
+    uv = (torch.rand(B, T, generator=g) < 0.3).float()
+    f0_pred = torch.randn(B, T, 2, generator=g)
+    losses = {}
+    Task.add_pitch_loss(None, {"f0_pred": f0_pred}, {"f0": f0, "uv": uv, "mel2ph": mel2ph}, losses)
+    out.update(p_mel2ph=mel2ph, p_f0=f0, p_uv=uv, p_pred=f0_pred, uv_loss=losses["uv"], f0_loss=losses["f0"])
+    # ---- CTC (tasks/visinger.py:140-145)
+    ph_pred = torch.log_softmax(torch.randn(B, D, T, generator=g), dim=1)
+    text = torch.randint(1, D, (B, Tph), generator=g)
+    mel_len = torch.tensor([T, 33, T])
+    txt_len = torch.tensor([Tph, 6, 8])
+    losses = {}
+    Task.add_ctc_loss(None, {"ph_pred": ph_pred}, {"mel_lengths": mel_len, "text_tokens": text, "text_lengths": txt_len}, losses)
+    out.update(c_ph_pred=ph_pred, c_text=text, c_mel_len=mel_len, c_txt_len=txt_len, ctc_loss=losses["ctc"])
+    # ---- LSGAN + feature matching (tasks/visinger.py:147-169): 6 discriminators' logits, 6 x 3 feature maps
+    d_tgt = [torch.randn(B, 5 + i, generator=g) for i in range(6)]
+    d_gen = [torch.randn(B, 5 + i, generator=g) for i in range(6)]
+    f_tgt = [[torch.randn(B, 4, 7 + j, i + 1, generator=g) for j in range(3)] for i in range(6)]
+    f_gen = [[torch.randn(B, 4, 7 + j, i + 1, generator=g) for j in range(3)] for i in range(6)]
+    out.update(disc_loss=Task.add_discriminator_loss(None, d_tgt, d_gen), gen_loss=Task.add_generator_loss(None, d_gen),
+               fm_loss=Task.add_feature_matching_loss(None, f_tgt, f_gen))
+    for i in range(6):
+        out[f"d_tgt{i}"], out[f"d_gen{i}"] = d_tgt[i], d_gen[i]
+        for j in range(3):
+            out[f"f_tgt{i}_{j}"], out[f"f_gen{i}_{j}"] = f_tgt[i][j], f_gen[i][j]
+    # ---- KL weighting (tasks/visinger.py:103-107 inside run_model: restated arithmetic of those four lines is NOT callable in isolation;
+    # the fixture records the hparams it uses so the test can check the constants train.py carries)
+    out["hparams_json"] = np.frombuffer(json.dumps(hp, sort_keys=True).encode(), dtype=np.uint8)
+    save("losses", **out)
+
+
+def gen_align_io():
+    """utils/audio/align.py:58-104 get_note2dur (integer frame bookkeeping of a note list) and utils/audio/io.py:8-12 save_wav (int16
+    bytes), from the reference's own functions."""
+    import io as _io
+    import tempfile
+    from utils.audio.align import get_note2dur
+    from utils.audio.io import save_wav
+    from scipy.io import wavfile
+    # midi_info rows: (Bar, Pos, Pitch, Duration_midi, start_time, end_time, Tempo, syllable phones, lyric token) -- the function reads
+    # [4], [5], [7] and [8]
+    r = np.random.default_rng(5)
+    cases = {}
+    for name, hop, sr, min_sil in (("a", 300, 24000, 0.0), ("b", 256, 22050, 0.05), ("c", 300, 24000, 0.02)):
+        t, rows = 0.0, []
+        n = 14
+        for i in range(n):
+            # (the reference asserts that every frame belongs to a note: gaps must be closed by min_sil_duration, the first note starts at 0)
+            gap = 0.0 if (i == 0 or min_sil == 0.0) else float(r.choice([0.0, 0.0, 0.004, 0.012]))
+            dur = float(r.uniform(0.12, 0.6))
+            nph = int(r.choice([1, 2, 3]))
+            if i in (4, 5) and name != "a":
+                phones, tok = ["|"], "|"          # consecutive rests: merged (align.py:66-67)
+                nph = 1
+            else:
+                phones, tok = [f"p{i}_{j}" for j in range(nph)], f"s{i}"
+            start = t + gap
+            rows.append([1 + i // 4, i % 4, int(r.integers(40, 80)), int(r.integers(1, 8)), round(start, 4), round(start + dur, 4), 120, phones, tok])
+            t = start + dur
+        rows_in = json.loads(json.dumps(rows))
+        mel2phone, mel2note, duration, ph_list, midi_out = get_note2dur(rows, hop, sr, min_sil_duration=min_sil)
+        cases[name] = {"midi_info": rows_in, "hop_size": hop, "sample_rate": sr, "min_sil_duration": min_sil, "mel2phone": mel2phone,
+                       "mel2note": mel2note, "duration": duration, "ph_list": ph_list, "midi_info_out": midi_out}
+    with open(os.path.join(OUT, "note2dur.json"), "w") as f:
+        json.dump(cases, f)
+    print("note2dur.json")
+    wav32 = (r.standard_normal(4000) * 0.3).astype(np.float32)
+    wav32[10], wav32[11] = 0.99999, -1.0
+    wav64 = wav32.astype(np.float64) * 1.7
+    arrays = {"wav32": wav32, "wav64": wav64}
+    with tempfile.TemporaryDirectory() as d:
+        for key, wav, norm in (("f32", wav32, False), ("f32_norm", wav32, True), ("f64_norm", wav64, True)):
+            path = os.path.join(d, key + ".wav")
+            save_wav(wav.copy(), path, 22050, norm=norm)
+            sr, pcm = wavfile.read(path)
+            arrays["pcm_" + key] = pcm
+            arrays["bytes_" + key] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    save("save_wav", **arrays)
+
+
 if __name__ == "__main__":
     gen_wavenet()
     gen_posterior()
@@ -454,3 +586,5 @@ if __name__ == "__main__":
     gen_discriminators()
     gen_model()
     gen_model_pitch()
+    gen_losses()
+    gen_align_io()

@@ -22,6 +22,17 @@ from .ops import PROFILER, ConvOp, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_wei
 LRELU_SLOPE = 0.1
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Invalidate every packed-weight key at once (the epoch is part of each key).  (data_ptr, _version) follows optimizer steps,
+    load_state_dict and copy_ on the parameter, but NOT edits made through ``p.data`` (EMA swaps, ``p.data.clamp_``: `.data` carries
+    its own version counter).  VISingerTrainer.training_step bumps the epoch once per step, so such an edit between two steps costs one
+    re-pack instead of silently training on stale packed weights; inside a step the cache still serves the frozen network's second use."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 def param_key(holder):
     """Identity and in-place versions of the PARAMETERS the live weight / bias of a conv holder derive from: (weight_v, weight_g) under
     torch.nn.utils.weight_norm, else the plain weight parameter; None when the weight is not a function of parameters alone (spectral
@@ -42,7 +53,7 @@ def param_key(holder):
     else:
         return None
     bias = getattr(holder, "bias", None)
-    return tuple((t.data_ptr(), t._version) for t in ps) + (None if bias is None else (bias.data_ptr(), bias._version),)
+    return tuple((t.data_ptr(), t._version) for t in ps) + (None if bias is None else (bias.data_ptr(), bias._version), _WEIGHT_EPOCH[0])
 
 
 class HipConvFn(torch.autograd.Function):
@@ -57,6 +68,7 @@ class HipConvFn(torch.autograd.Function):
             op.set_weights_from(w, b, key)
         y = op.forward(x)
         ctx.module = module
+        ctx.wkey = key                  # the backward handles pack the adjoint of THIS weight: keyed by the forward's key, not by the parameters' state at backward time
         ctx.save_for_backward(x, w, b if b is not None else x.new_empty(0))
         ctx.has_bias = b is not None
         return y
@@ -66,7 +78,7 @@ class HipConvFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         need = ctx.needs_input_grad
         gy = gy.contiguous()
-        gx, gw = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]))
+        gx, gw = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]), key=ctx.wkey)
         gb = gy.sum((0, 2)) if (need[2] and ctx.has_bias) else None
         return gx, gw, gb, None
 
@@ -79,7 +91,7 @@ def _bwd_op(module, key, *args):
     return ops[key]
 
 
-def conv_backward(m, x, w, gy, need_x, need_w):
+def conv_backward(m, x, w, gy, need_x, need_w, key=False):
     """Gradients of y = conv(x, w) for a HipConv1d / HipConvTranspose1d `m` (stride-1 dilated conv, or stride-u transposed
     conv), MIOpen-free:
 
@@ -102,7 +114,7 @@ def conv_backward(m, x, w, gy, need_x, need_w):
             assert pb >= 0, "conv backward-data: padding larger than the receptive field is not supported"
             # (the handle packs the adjoint -- channel transpose + tap reversal -- of the forward weight by index arithmetic)
             op = _bwd_op(m, "dxa", L.CONV1D, Cout, Cin, K, d, pb, L.CONV_ADJOINT)
-            key = param_key(m)
+            key = param_key(m) if key is False else key
             if not op.has_weights_of(key):
                 op.set_weights_from(w, None, key)
             gx = op.forward(gy)
@@ -119,7 +131,7 @@ def conv_backward(m, x, w, gy, need_x, need_w):
         G = gyp.view(B, Cout, Mq, u).permute(0, 3, 1, 2).reshape(B, u * Cout, Mq)
         if need_x:
             op = _bwd_op(m, "dx", L.CONV1D, u * Cout, Cin, Q, 1, 0, 0)
-            key = param_key(m)
+            key = param_key(m) if key is False else key
             if not op.has_weights_of(key):
                 wq = F.pad(w.detach(), (0, Q * u - K)).view(Cin, Cout, Q, u).permute(0, 3, 1, 2).reshape(Cin, u * Cout, Q)
                 op.set_weights_from(wq, None, key)

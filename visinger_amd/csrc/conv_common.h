@@ -157,7 +157,8 @@ struct vs_split_pack {            // re-pack of the fp32 fragment-order weights 
     void *ws;                     // Ws[m_tile][tap][chunk][plane][64 lanes][8 bf16]
     int MT_alloc, KT, nchunks, terms;
     float *wscale;                // terms = 3 (two f16 planes): out, {s_w, 1 / s_w} with s_w = 2^(14 - floor(log2 max|w|))
-    const unsigned *maxbits;      // terms = 3: the largest |w| (bits) when the caller already has it, else NULL (found here)
+    const unsigned *maxbits;      // terms = 3: the largest |w| (bits) when the caller already has it, else NULL (found here, through `scratch`)
+    unsigned *scratch;            // terms = 3 without maxbits: one device word of the handle for the maximum (no allocation on the caller's stream)
 };
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);

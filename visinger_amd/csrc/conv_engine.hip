@@ -1331,8 +1331,8 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
 // {s_w, 1 / s_w, max |w| bits of the even packs, of the odd packs}
 static int reserve_wscale(vs_conv *h, hipStream_t s) {
     if (h->wsc.p) return VS_OK;
-    VS_TRY(h->wsc.reserve(16));
-    VS_CHECK_HIP(hipMemsetAsync(h->wsc.p, 0, 16, s));
+    VS_TRY(h->wsc.reserve(32));      // {s_w, 1 / s_w, max |w| bits of even / odd packs, scratch maximum of a vs_conv_set_math re-pack, 3 spare words}
+    VS_CHECK_HIP(hipMemsetAsync(h->wsc.p, 0, 32, s));
     return VS_OK;
 }
 
@@ -1345,10 +1345,12 @@ static int pack_split_planes(vs_conv *h, hipStream_t s, bool maxbits_ready = fal
     q.wp = h->wp.as<float>(); q.ws = h->ws.p; q.MT_alloc = h->MT_alloc; q.KT = h->KT; q.nchunks = h->nchunks; q.terms = h->math;
     q.wscale = nullptr;
     q.maxbits = nullptr;
+    q.scratch = nullptr;
     if (h->math == VS_MATH_SPLIT3) {
         VS_TRY(reserve_wscale(h, s));
         q.wscale = h->wsc.as<float>();
         q.maxbits = maxbits_ready ? reinterpret_cast<const unsigned *>(q.wscale + 2) + (h->pack_gen & 1) : nullptr;
+        q.scratch = reinterpret_cast<unsigned *>(q.wscale + 4);      // the handle's own word: no allocation on any pack path (stream capture)
     }
     return pack_split(q, s);
 }
@@ -1402,6 +1404,7 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         q.maxbits = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + (h->pack_gen & 1);
         q.maxbits_clear = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + ((h->pack_gen + 1) & 1);
         hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)std::min<long long>(ceil_div(total, 256), 1024)), dim3(256), 0, s, q);
+        VS_CHECK_HIP(hipGetLastError());
         VS_TRY(pack_split_planes(h, s, true));
     } else if (h->math) {
         // bf16-pipe arithmetic: fp32 fragments + bf16 planes in one launch

@@ -160,15 +160,12 @@ int pack_split(const vs_split_pack &q, hipStream_t s) {
         if (!q.wscale) { set_error("pack_split: the split-f16 arithmetic needs a scale buffer"); return VS_EINVAL; }
         const unsigned *maxbits = q.maxbits;
         if (!maxbits) {       // (vs_conv_set_math on a bound handle: a pass over the fp32 fragments; the slots of the regular packs stay untouched)
-            unsigned *mb;
-            VS_CHECK_HIP(hipMallocAsync((void **)&mb, sizeof(unsigned), s));      // (rare, off the steady-state path; freed in stream order below)
-            VS_CHECK_HIP(hipMemsetAsync(mb, 0, sizeof(unsigned), s));
+            if (!q.scratch) { set_error("pack_split: no scratch word for the weight maximum"); return VS_EINVAL; }
+            VS_CHECK_HIP(hipMemsetAsync(q.scratch, 0, sizeof(unsigned), s));
             const long long n = total * 8;                   // fp32 fragment elements (zero padding included)
-            hipLaunchKernelGGL(wabsmax_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256 * 8), 1024)), dim3(256), 0, s, q.wp, n, mb);
-            hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, (const unsigned *)mb);
+            hipLaunchKernelGGL(wabsmax_kernel, dim3((unsigned)std::min<long long>(ceil_div(n, 256 * 8), 1024)), dim3(256), 0, s, q.wp, n, q.scratch);
             VS_CHECK_HIP(hipGetLastError());
-            VS_CHECK_HIP(hipFreeAsync(mb, s));
-            return VS_OK;
+            maxbits = q.scratch;
         }
         hipLaunchKernelGGL(pack_split_f16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, q, maxbits);
         VS_CHECK_HIP(hipGetLastError());

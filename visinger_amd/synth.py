@@ -40,12 +40,16 @@ def collate(items, device):
 
 def to_int16(wav, norm=True):
     """utils/audio/io.py:8-15: optional peak normalisation, then * 32767 -> int16."""
-    wav = np.asarray(wav, dtype=np.float32)
+    wav = np.asarray(wav)
+    if not np.issubdtype(wav.dtype, np.floating):
+        wav = wav.astype(np.float32)
+    # (the arithmetic stays in the array's own float type, as in the reference: an fp64 waveform is scaled in fp64 -- the int16 truncation
+    #  of the two differs in the last bit; pinned byte for byte by tests/golden/save_wav.npz)
     if norm and wav.size:
         peak = np.abs(wav).max()
         if peak > 0:
             wav = wav / peak
-    return (wav * 32767.0).astype(np.int16)
+    return (wav * 32767).astype(np.int16)
 
 
 def save_wav(wav, path, sr, norm=False):

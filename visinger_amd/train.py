@@ -50,6 +50,26 @@ def feature_matching_loss(fmap_tgt, fmap_gen):
     return sum(torch.mean(torch.abs(t.float().detach() - g.float())) for ft, fg in zip(fmap_tgt, fmap_gen) for t, g in zip(ft, fg))
 
 
+def pitch_losses(f0_pred, f0, uv, mel2ph, lambda_uv, lambda_f0):
+    """tasks/visinger.py:127-139: voiced/unvoiced BCE over the valid frames, f0 L1 over the valid VOICED frames -> (uv loss, f0 loss).
+    (The reference divides by the voiced-frame count unguarded; a batch without any voiced frame gives 0 here instead of NaN.)"""
+    nonpad = (mel2ph != 0).float()
+    uv_loss = (F.binary_cross_entropy_with_logits(f0_pred[:, :, 1], uv, reduction="none") * nonpad).sum() / nonpad.sum() * lambda_uv
+    voiced = nonpad * (uv == 0).float()
+    f0_loss = (F.l1_loss(f0_pred[:, :, 0], f0, reduction="none") * voiced).sum() / voiced.sum().clamp(min=1) * lambda_f0
+    return uv_loss, f0_loss
+
+
+def ctc_loss(ph_pred, text_tokens, mel_lengths, text_lengths, lambda_ctc):
+    """tasks/visinger.py:140-145: CTC of the frame-level phoneme log-probabilities [B, dict, T] against the token sequence"""
+    return F.ctc_loss(ph_pred.float().permute(2, 0, 1), text_tokens, mel_lengths, text_lengths, zero_infinity=True) * lambda_ctc
+
+
+def kl_loss(kl, global_step, kl_start_steps, kl_min, lambda_kl):
+    """tasks/visinger.py:103-107: clamp, linear warm-up over kl_start_steps, weight"""
+    return min(global_step / kl_start_steps, 1) * torch.clamp(kl, min=kl_min) * lambda_kl
+
+
 class VISingerTrainer(nn.Module):
     """Owns the two networks (children named ``model`` and ``mel_disc`` like the reference task, so the checkpoint layout
     matches), the two AdamW optimizers and their ExponentialLR schedulers."""
@@ -109,19 +129,14 @@ class VISingerTrainer(nn.Module):
         out = self.model(batch["text_tokens"], batch["note_pitch"], batch["note_dur"], batch["mel2ph"], spk_id=batch.get("spk_ids"),
                          f0=batch.get("f0"), uv=batch.get("uv"), mel=batch["mels"], infer=False, noise_q=batch.get("noise_q"),
                          u_slice=batch.get("u_slice"))
-        losses = {"kl": min(self.global_step / h["kl_start_steps"], 1) * torch.clamp(out["kl"], min=h["kl_min"]) * h["lambda_kl"]}
+        losses = {"kl": kl_loss(out["kl"], self.global_step, h["kl_start_steps"], h["kl_min"], h["lambda_kl"])}
         tgt_mel = self.mel(batch["wavs"])                                                   # [B, T, M]
         tgt_slice = slice_segments(tgt_mel.transpose(1, 2).contiguous(), out["ids_slice"], self.segment_size).transpose(1, 2)
         losses["mel_l1"] = masked_l1(self.mel(out["wav_out"]), tgt_slice) * h["lambda_mel"]
         if "f0_pred" in out and batch.get("f0") is not None:
-            nonpad = (batch["mel2ph"] != 0).float()
-            uv, p = batch["uv"], out["f0_pred"]
-            losses["uv"] = (F.binary_cross_entropy_with_logits(p[:, :, 1], uv, reduction="none") * nonpad).sum() / nonpad.sum() * h["lambda_pitch"]
-            voiced = nonpad * (uv == 0).float()
-            losses["f0"] = (F.l1_loss(p[:, :, 0], batch["f0"], reduction="none") * voiced).sum() / voiced.sum().clamp(min=1) * h["lambda_pitch"]
+            losses["uv"], losses["f0"] = pitch_losses(out["f0_pred"], batch["f0"], batch["uv"], batch["mel2ph"], h["lambda_pitch"], h["lambda_pitch"])
         if "ph_pred" in out:
-            losses["ctc"] = F.ctc_loss(out["ph_pred"].float().permute(2, 0, 1), batch["text_tokens"], batch["mel_lengths"],
-                                       batch["text_lengths"], zero_infinity=True) * h["lambda_ctc"]
+            losses["ctc"] = ctc_loss(out["ph_pred"], batch["text_tokens"], batch["mel_lengths"], batch["text_lengths"], h["lambda_ctc"])
         self._cached = {k: v.detach() for k, v in out.items() if isinstance(v, torch.Tensor)}
         if self.global_step >= h["disc_start_steps"] and h["lambda_mel_adv"] > 0:
             real = slice_segments(batch["wavs"].unsqueeze(1), out["ids_slice"] * self.hop, self.segment_size * self.hop)
@@ -157,6 +172,8 @@ class VISingerTrainer(nn.Module):
     def training_step(self, batch, runner=None):
         """One iteration = generator pass + discriminator pass (trainer.py:306-384).  `runner` is the (optionally
         DDP-wrapped) module to call; gradients are clipped over ALL parameters of the task, as the reference does."""
+        from .autograd import bump_weight_epoch
+        bump_weight_epoch()      # edits made through p.data since the last step (EMA swaps) must not meet a stale packed weight
         logs = {}
         for opt_idx, opt in enumerate((self.opt_gen, self.opt_disc)):
             parts = self.backward_pass(batch, opt_idx, runner)
