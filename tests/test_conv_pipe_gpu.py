@@ -44,11 +44,11 @@ def test_pipe_kernel_is_bit_identical_to_the_tile_kernel(case, vs_option):
     res = torch.randn(B, cout, T, device="cuda", generator=g) if use_res else None
     acc = torch.randn(B, cout, T, device="cuda", generator=g) if use_acc else None
     in_act = L.IN_LRELU if lrelu else L.IN_NONE
-    vs_option("VS_NO_PIPE", 1)
+    vs_option("VS_PIPE", 0)
     y_ref, k_ref = _run(op, x, res, acc, scale, in_act, out_act)
-    vs_option("VS_NO_PIPE", 0)
+    vs_option("VS_PIPE", 1)
     y_pipe, k_pipe = _run(op, x, res, acc, scale, in_act, out_act)
-    assert k_ref == "conv_split_kernel<1, 8, 4, 1, 3>" and k_pipe == ("conv_pipe_kernel<true>" if use_acc else "conv_pipe_kernel<false>"), (k_ref, k_pipe)
+    assert k_ref == "conv_split_kernel<1, 8, 4, 1, 3>" and k_pipe == "conv_pipe_kernel<%d, %s>" % (k, "true" if use_acc else "false"), (k_ref, k_pipe)
     assert torch.equal(y_pipe, y_ref), float((y_pipe - y_ref).abs().max())
     y2, _ = _run(op, x, res, acc, scale, in_act, out_act)                # and run-to-run
     assert torch.equal(y2, y_pipe)
@@ -71,6 +71,7 @@ def test_pipe_kernel_is_not_taken_where_its_preconditions_fail(vs_option):
     from visinger_amd import _lib as L
     from visinger_amd.ops import ConvOp
     vs_option("VS_CONV_MATH", 3)
+    vs_option("VS_PIPE", 1)
     op = ConvOp(L.CONV1D, 128, 128, 7, 1, 3)
     op.set_weights(torch.randn(128, 128, 7, device="cuda") * 0.03, None, torch.zeros(128, device="cuda"))
     x = torch.randn(4, 128, 32768, device="cuda")
@@ -85,3 +86,6 @@ def test_pipe_kernel_is_not_taken_where_its_preconditions_fail(vs_option):
     assert op.kernel_instance() == "conv_split_kernel<1, 8, 4, 1, 3>"
     op.forward(torch.randn(1, 128, 65536, device="cuda"))                        # 256 tiles: fewer than two per workgroup
     assert not op.kernel_instance().startswith("conv_pipe_kernel")
+    vs_option("VS_PIPE", 0)                                                      # the default: opt-in only
+    op.forward(x)
+    assert op.kernel_instance() == "conv_split_kernel<1, 8, 4, 1, 3>"

@@ -37,7 +37,7 @@ for C, T in ((128, 65536), (256, 8192)):
             op.set_weights(torch.randn(C, C, k, device="cuda") * 0.03, None, torch.randn(C, device="cuda"))
             ms = {}
             for nopipe in (1, 0, 1, 0):
-                L.set_option("VS_NO_PIPE", nopipe)
+                L.set_option("VS_PIPE", 1 - nopipe)
                 t = one(op, x, y, res if use_res else None, acc if use_acc else None, L.IN_LRELU, 1.0 / 3 if use_acc else 1.0)
                 ms[nopipe] = min(ms.get(nopipe, 1e9), t)
                 name = op.kernel_instance()

@@ -17,7 +17,7 @@ res = torch.randn(B, C, T, device="cuda", generator=g) if RES else None
 acc = torch.randn(B, C, T, device="cuda", generator=g) if ACC else None
 ys = {}
 for nopipe in (1, 0):
-    L.set_option("VS_NO_PIPE", nopipe)
+    L.set_option("VS_PIPE", 1 - nopipe)
     y = torch.full((B, C, T), 7.0, device="cuda")
     op.forward(x, y=y, res=res, acc=acc, in_act=L.IN_LRELU if ACT else L.IN_NONE)
     torch.cuda.synchronize()

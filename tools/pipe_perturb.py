@@ -19,11 +19,11 @@ for C, T, k in ((128, 65536, 7), (128, 65536, 3), (256, 8192, 7)):
     op = ConvOp(L.CONV1D, C, C, k, 1, (k - 1) // 2)
     op.set_weights(torch.randn(C, C, k, device="cuda") * 0.03, None, torch.randn(C, device="cuda"))
     for use_res in (0, 1):
-        L.set_option("VS_NO_PIPE", 1); L.set_option("VS_SPLIT_DBG", 0)
+        L.set_option("VS_PIPE", 0); L.set_option("VS_SPLIT_DBG", 0)
         base = t(op, x, y, res if use_res else None)
-        L.set_option("VS_NO_PIPE", 0)
+        L.set_option("VS_PIPE", 1)
         row = []
-        for dbg in (0, 32, 64, 128, 96, 1, 33, 65, 3, 35, 67):
+        for dbg in (0, 1, 2, 3, 23, 279):
             L.set_option("VS_SPLIT_DBG", dbg)
             row.append((dbg, t(op, x, y, res if use_res else None)))
         L.set_option("VS_SPLIT_DBG", 0)

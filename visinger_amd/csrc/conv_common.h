@@ -168,7 +168,7 @@ int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t 
 
 // conv_pipe.hip: the 128 x 256 tile of the split-f16 x3 arithmetic as a persistent, software-pipelined kernel (epilogue of tile i inside the
 // main loop of tile i + 1); p as for launch_split(cfg 0); ncu = compute units of the device.  Preconditions: pipe_eligible().
-constexpr int PIPE_MIN_STEPS = 20;       // (chunk, tap) steps per tile the epilogue's 18 events need
+constexpr int PIPE_MIN_CHUNKS = 6;       // at most three of the epilogue's 18 events per 16-channel chunk: C_in >= 96
 int launch_pipe(ConvParams p, int span, int ncu, hipStream_t s);
 
 // conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)

@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 
 namespace vs {
 
@@ -95,7 +96,27 @@ constexpr int PIPE_CW = 128;             // columns of a wave's tile
 constexpr int PIPE_NTW = 4;              // 32-column accumulator tiles per wave
 constexpr int PIPE_EVENTS = 18;          // epilogue events per tile: 16 items + 2 events of load lead
 
-template <bool HAS_ACC>
+// wait until the `n` youngest vector-memory operations are the only ones outstanding; the common count of the main loop (2: the two
+// fragment loads just issued for the next tap) takes a compare and a fixed immediate instead of the computed jump
+__device__ __forceinline__ void wait_vm_fast2(int n) {
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else wait_vm(n);
+}
+
+// index k of the chunk's epilogue event that sits at tap T (event k at tap k * KT / 3 + shift, taken modulo KT), or -1
+constexpr int pipe_event_at(int T, int KT, int shift) {
+    for (int k = 0; k < 3; ++k)
+        if (((k * KT) / 3 + shift) % KT == T) return k;
+    return -1;
+}
+
+template <class F, int... Is>
+__device__ __forceinline__ void for_each_tap(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <int KT, bool HAS_ACC>
 __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
     constexpr int NPL = 2;
     constexpr int NT_W = PIPE_NTW, CW = PIPE_CW;
@@ -124,9 +145,9 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
     const int ncol = p.N >> 8;
     const int ntiles = ncol * p.B;
     const int ntl = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nchunks = p.nchunks, KT = p.KT;
-    const int S = nchunks * KT;                                  // steps per tile
-    const int istep = max(1, (S - 2) / PIPE_EVENTS);            // steps between two epilogue events
+    const int nchunks = p.nchunks;
+    const int G = ntl * nchunks;                                 // chunks this workgroup consumes
+    const int epc = (PIPE_EVENTS + nchunks - 1) / nchunks;       // epilogue events per chunk (<= 3: the host requires nchunks >= 6)
     auto coord = [&](int i, int &b, int &n0) __attribute__((always_inline)) {
         const int t = (int)blockIdx.x + i * (int)gridDim.x;
         b = __builtin_amdgcn_readfirstlane(t / ncol);
@@ -138,11 +159,11 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(wscale_inv) : : "memory");      // (hipcc must not sink this load into the loop: its wait there would be a vmcnt(0))
     const OutSpec &o = p.out[0];
     const bool has_res = o.res != nullptr;
+    constexpr bool has_acc = HAS_ACC;
     // values only needed at tile boundaries (tensor bases and item strides) are re-read from the kernel-argument segment there (scalar
-    // loads) instead of occupying 20 SGPRs through the loop, where spilled scalars cost VGPR lanes
+    // loads) instead of occupying SGPRs through the loop, where spilled scalars cost VGPR lanes
     typedef const __attribute__((address_space(4))) ConvParams *kargs_t;
     const kargs_t kargs = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr bool has_acc = HAS_ACC;
     const int in_act = p.in_act;
 
     f32x16 acc[NT_W], prev[NT_W];
@@ -154,7 +175,9 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
     // ---- the wave's VMEM scoreboard
     int vm_seq = 0;                 // vector-memory operations issued so far
     int seqX = 0;                   // number of the last staging load in flight
-    int seqR0 = 0, seqR1 = 0;       // ... of the last residual / accumulate load of ring slot 0 / 1
+    int seqR0 = 0, seqR1 = 0;       // ... of the last residual load of landing slot 0 / 1
+    int seqAcc = 0;                 // ... of the accumulate-input load
+    int seqA0 = 0, seqA1 = 0;       // ... of the fragment loads into set 0 / 1
 
     // ---- staging stream: loads (chunk l_chunk of tile l_i) two chunks ahead of consumption, stores (s_chunk of tile s_i) one ahead
     float st[4][3];
@@ -171,6 +194,8 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)uniform_ptr(q->x + (long long)b * q->x_bs), 0, (int)((long long)p.Cin * p.Tin * 4), 0x00020000);
     };
     __amdgpu_buffer_rsrc_t xsrc = x_rsrc(l_b);
+    // (every wave issues 12 loads: the third column iteration of the odd waves lies beyond the staged window and is never used -- a
+    //  constant count keeps the scoreboard arithmetic out of the loop)
     auto stage_load = [&]() __attribute__((always_inline)) {
         const int nb4 = (l_n0 + p.lo + lane) * 4 + spar * 256;
         int voff[4];
@@ -180,13 +205,9 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
         for (int j = 0; j < 4; ++j) {
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(st[j][0]) : "v"(voff[j]), "s"(xsrc) : "memory");
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:512" : "=v"(st[j][1]) : "v"(voff[j]), "s"(xsrc) : "memory");
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:1024" : "=v"(st[j][2]) : "v"(voff[j]), "s"(xsrc) : "memory");
         }
-        if (!spar) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:1024" : "=v"(st[j][2]) : "v"(voff[j]), "s"(xsrc) : "memory");
-        }
-        vm_seq += spar ? 8 : 12;
+        vm_seq += 12;
         seqX = vm_seq;
         if (++l_chunk == nchunks) {
             l_chunk = 0;
@@ -261,30 +282,38 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
         }
     };
 
-    // ---- weight fragments: [m_tile][tap][chunk][plane(2)][64 lanes][8 f16], one 16-byte load per plane and step, one step ahead
+    // ---- weight fragments: [m_tile][tap][chunk][plane(2)][64 lanes][8 f16], one 16-byte load per plane and tap, one tap ahead, into two
+    // NAMED register sets: tap t of a chunk computes from set t & 1.  With an odd KT the last tap of a chunk and the first tap of the next
+    // would want the same set: the fragments of a chunk's tap 0 are requested into set 1 and moved to set 0 once they have landed.
     const char *const wsb = uniform_ptr(reinterpret_cast<const char *>(p.wp) + (long long)mt0 * KT * nchunks * (NPL * 64 * 16));
     const int la = lane * 16;
     u32x4 a0[NPL], a1[NPL];
-    auto load_a = [&](u32x4 (&dst)[NPL], int chunk, int tap) __attribute__((always_inline)) {
+    constexpr int FIRST_SET = KT & 1;          // the set the fragments of a chunk's tap 0 are loaded into
+    auto load_a = [&](auto set_tag, int chunk, int tap) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
         const char *src = wsb + (long long)(tap * nchunks + chunk) * (NPL * 64 * 16);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0]) : "v"(la), "s"(src) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(dst[1]) : "v"(la), "s"(src) : "memory");
+        if constexpr (SET) {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(a1[0]) : "v"(la), "s"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(a1[1]) : "v"(la), "s"(src) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(a0[0]) : "v"(la), "s"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(a0[1]) : "v"(la), "s"(src) : "memory");
+        }
         vm_seq += 2;
+        if constexpr (SET) seqA1 = vm_seq; else seqA0 = vm_seq;
     };
 
-    // ---- epilogue of the PREVIOUS tile, in events
-    int ev = PIPE_EVENTS, ev_due = 0, ts = 0;      // (no finished tile yet)
+    // ---- epilogue of the PREVIOUS tile, in PIPE_EVENTS events: event ev finishes item ev - 2 (LDS transposition of the accumulators 8 rows
+    // at a time, + residual [+ accumulate input], one 16-byte store per lane) and requests the residual of item ev (LDS-DMA into one of two
+    // wave-private 1 KB slots; the accumulate input of item ev - 1 into a third).  Through registers those loads cost 12 VGPRs and were
+    // WRONG: hipcc copies a loop-carried asm destination at control-flow joins before the data has landed (cdna_hip_programming.md 5.7
+    // item 1); an LDS landing slot has no register for the compiler to move.
+    int ev = PIPE_EVENTS;                                            // (no finished tile yet)
     float acc_inv_prev = 1.f;
     const char *ypv = nullptr, *rpv = nullptr, *apv = nullptr;      // y / res / acc at (item pv_b, row mt0 * 32, column pv_n0 + wn * 128)
     const int lrow = lane >> 5;                                      // 32 lanes per 128-column row: two rows per instruction
     const int c4 = (lane & 31) * 4;
     const int lane_off = (lrow * p.Tout + c4) * 4;                   // bytes
-    // residual loads two events ahead of their item, accumulate-input loads one event ahead, as LDS-DMA into wave-private 1 KB slots
-    // (two for the residual ring, one for the accumulate input) and read back with ds_read_b128 when the item is finished.  Through
-    // registers they cost 12 VGPRs (scratch in the HAS_ACC instance) and were WRONG: hipcc copies a loop-carried asm destination at
-    // control-flow joins (v_mov before the data has landed -- the hazard of cdna_hip_programming.md 5.7 item 1); an LDS landing slot has no
-    // register for the compiler to move.
-    int seqAcc = 0;
     auto write_pass = [&](auto ps_tag) __attribute__((always_inline)) {
         constexpr int PS = decltype(ps_tag)::value;
         float *const Lw = Lw0 + (PS & 1) * 1024;
@@ -293,9 +322,8 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < NT_W; ++j) Lw[(q + 4 * lhalf) * CW + 32 * j + l31] = prev[j][4 * PS + q];
     };
-    auto epi_event = [&](auto slot_tag) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_tag)::value;
-        int seqR = SL ? seqR1 : seqR0;      // (scalars by value and written back: a reference chosen between two scalars keeps both in memory)
+    auto epi_event = [&]() __attribute__((always_inline)) {
+        const int sl = ev & 1;                                       // landing slot of this event's item and of the residual requested here
         const int e = ev - 2;
         if (e >= 0) {
             const int ps = e >> 2, it = e & 3;
@@ -306,9 +334,9 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
                 else write_pass(std::integral_constant<int, 3>{});
             }
             if constexpr (HAS_ACC) wait_vm(vm_seq - seqAcc);      // (the accumulate-input load of this item is younger than its residual load: one wait)
-            else if (has_res) wait_vm(vm_seq - seqR);
+            else if (has_res) wait_vm(vm_seq - (sl ? seqR1 : seqR0));
             f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f}, a4 = r4;
-            if (has_res) r4 = *reinterpret_cast<const f32x4 *>(rdma + SL * 256 + lane * 4);
+            if (has_res) r4 = *reinterpret_cast<const f32x4 *>(rdma + sl * 256 + lane * 4);
             if constexpr (HAS_ACC) a4 = *reinterpret_cast<const f32x4 *>(rdma + 512 + lane * 4);
             f32x4 v = *reinterpret_cast<const f32x4 *>(Lw0 + (ps & 1) * 1024 + (it * 2 + lrow) * CW + c4);
             const float bb = sbias[wm * 32 + 8 * ps + 2 * it + lrow];
@@ -329,9 +357,9 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
         const int l = ev;
         if (l < 16 && has_res) {
             const char *rp = rpv + (long long)(8 * (l >> 2) + 2 * (l & 3)) * p.Tout * 4;
-            glds16(lane_off, rp, rdma_lds + SL * 1024);
+            glds16(lane_off, rp, rdma_lds + sl * 1024);
             vm_seq += 1;
-            seqR = vm_seq;
+            if (sl) seqR1 = vm_seq; else seqR0 = vm_seq;
         }
         if constexpr (HAS_ACC) {
             const int la_ = ev - 1;               // item finished by the NEXT event
@@ -342,28 +370,15 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
                 seqAcc = vm_seq;
             }
         }
-        if constexpr (SL) seqR1 = seqR; else seqR0 = seqR;
         ++ev;
-        ev_due += istep;
-    };
-    auto epi_tick = [&]() __attribute__((always_inline)) {
-        if (ev < PIPE_EVENTS && ts >= ev_due && !PIPE_PERTURB(1)) {
-            if (ev & 1) epi_event(std::integral_constant<int, 1>{});
-            else epi_event(std::integral_constant<int, 0>{});
-        }
     };
 
     // ---- consumption stream
     int c_i = 0, c_b = l_b, c_n0 = l_n0;
-    int chunk = 0, tap = 0, gc = 0;                // chunk / tap of the current step, chunks consumed so far (LDS buffer parity)
-    const int nsteps = ntl * S;
-    int s = 0;
-    int pc = 0, pt = 0;                            // (chunk, tap) of the step after the current one
-    auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; if (++pc == nchunks) pc = 0; } };
-    int seqA0 = 0, seqA1 = 0;
+    int chunk = 0;                                 // chunk of the consumed tile
 
     auto tile_end = [&]() __attribute__((always_inline)) {
-        // (every event of the tile finished before has run: the host only takes this kernel for tiles of >= PIPE_EVENTS + 2 steps)
+        // (every event of the tile finished before has run: nchunks * epc >= PIPE_EVENTS)
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
             prev[j] = acc[j];
@@ -380,92 +395,106 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
         rpv = has_res ? uniform_ptr(q->out[0].res + (long long)c_b * q->out[0].res_bs + eoff) : ypv;
         apv = has_acc ? uniform_ptr(q->out[0].acc + (long long)c_b * q->out[0].acc_bs + eoff) : ypv;
         ev = 0;
-        ev_due = 1;
-        ts = 0;
         if (++c_i < ntl) coord(c_i, c_b, c_n0);
     };
 
-    // ---- prologue: chunk 0 of the first tile into LDS, chunk 1 in flight, the fragments of step 0 in flight
+    // ---- prologue: chunk 0 of the first tile into LDS, chunk 1 in flight, the fragments of tap 0 in flight
     __syncthreads();                                 // (sbias)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    load_a(a0, 0, 0);
-    seqA0 = vm_seq;
-    advance();
+    load_a(std::integral_constant<int, FIRST_SET>{}, 0, 0);
     stage_load();
     stage_store(lbuf0);
     stage_load();
     __syncthreads();
 
-    auto step = [&](auto par_tag) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;          // which of the two NAMED fragment sets this step consumes
-        u32x4 (&acur)[NPL] = *(PAR ? &a1 : &a0);
-        u32x4 (&apre)[NPL] = *(PAR ? &a0 : &a1);
-        const int seq_cur = PAR ? seqA1 : seqA0;
-        const unsigned *cur = (gc & 1) ? lbuf1 : lbuf0;
-        const bool first = (tap == 0);
-        PSTAMP(0);
-        if (first && s_i < ntl && !PIPE_PERTURB(2)) stage_store((gc & 1) ? lbuf0 : lbuf1);
-        if (s + 1 < nsteps && !(PIPE_PERTURB(8) && s > 2)) {
-            load_a(apre, pc, pt);
-            if constexpr (PAR) seqA0 = vm_seq; else seqA1 = vm_seq;
-            advance();
+    // one tap: fragments of the next tap requested, B fragments of the four 32-column tiles read one tile ahead, 12 MFMAs
+    auto tap_body = [&](auto t_tag, const unsigned *cur, int g) __attribute__((always_inline)) {
+        constexpr int T = decltype(t_tag)::value;
+        constexpr int SET = T & 1;
+        u32x4 (&acur)[NPL] = *(SET ? &a1 : &a0);
+        if constexpr (T == 0) {
+            if (s_i < ntl && !PIPE_PERTURB(2)) stage_store((g & 1) ? lbuf0 : lbuf1);
+            if constexpr (FIRST_SET == 1) {          // odd KT: tap 0's fragments arrived in set 1 (see load_a): move them, then set 1 is free for tap 1
+                wait_vm(vm_seq - seqA1);
+                asm volatile("" : "+v"(a1[0]), "+v"(a1[1]));
+                a0[0] = a1[0];
+                a0[1] = a1[1];
+                asm volatile("" : "+v"(a0[0]), "+v"(a0[1]));
+                seqA0 = seqA1;
+            }
         }
-        if (first && l_i < ntl && !PIPE_PERTURB(2)) stage_load();
-        const unsigned *xs = cur + (lhalf * W + wn * CW + l31 - p.lo + (p.off0 + tap * p.tstep)) * 4;
-        u32x4 bf[NPL], bn[NPL];
+        // the next tap's fragments (the last tap of the last chunk requests nothing)
+        if constexpr (T + 1 < KT) {
+            load_a(std::integral_constant<int, (T + 1) & 1>{}, chunk, T + 1);
+        } else {
+            if (g + 1 < G) load_a(std::integral_constant<int, FIRST_SET>{}, (chunk + 1 == nchunks) ? 0 : chunk + 1, 0);
+        }
+        if constexpr (T == 0) {
+            if (l_i < ntl && !PIPE_PERTURB(2)) stage_load();
+        }
+        const unsigned *xs = cur + (lhalf * W + wn * CW + l31 - p.lo + (p.off0 + T * p.tstep)) * 4;
+        // B fragments of the four 32-column tiles, two tiles (one PAIR) at a time, the next pair read under the MFMAs of the current one.
+        // The six MFMAs of a pair alternate between its two accumulator tiles: l x h (0), l x h (1), h x l (0), h x l (1), h x h (0), h x h (1)
+        // -- every accumulator still sees its three terms in the order of conv_split_body.inc (bit-identical sums), but two consecutive
+        // MFMAs are independent: a lone wave issuing three dependent MFMAs back to back reaches ~70 % of the matrix pipe
+        // (tools/pipe_perturb.py: one wave per SIMD), and its SIMD partner is not always in its own MFMA section to fill the gaps.
+        u32x4 bA[2][NPL], bB[2][NPL];
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ);
-        PSTAMP(1);
-        if (!PIPE_PERTURB(4)) wait_vm(vm_seq - seq_cur);
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) bA[jj][pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ + jj * 128);
+        if (!PIPE_PERTURB(4)) wait_vm_fast2(vm_seq - (SET ? seqA1 : seqA0));
         asm volatile("" : "+v"(acur[0]), "+v"(acur[1]));
-        PSTAMP(2);
+        auto pair_mfma = [&](int j0, u32x4 (&b)[2][NPL]) __attribute__((always_inline)) {
+            if (PIPE_PERTURB(256) && wn) return;
 #pragma unroll
-        for (int j = 0; j < NT_W; ++j) {
-            if (j + 1 < NT_W && !PIPE_PERTURB(16)) {
+            for (int jj = 0; jj < 2; ++jj)
+                acc[j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[1]), __builtin_bit_cast(f16x8, b[jj][0]), acc[j0 + jj], 0, 0, 0);
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) bn[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ + (j + 1) * 128);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // smallest terms first (conv_split_body.inc): l x h, h x l, h x h
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[1]), __builtin_bit_cast(f16x8, bf[0]), acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[0]), __builtin_bit_cast(f16x8, bf[1]), acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[0]), __builtin_bit_cast(f16x8, bf[0]), acc[j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == 1) { PSTAMP(3); epi_tick(); PSTAMP(4); }
+            for (int jj = 0; jj < 2; ++jj)
+                acc[j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[0]), __builtin_bit_cast(f16x8, b[jj][1]), acc[j0 + jj], 0, 0, 0);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) bf[pl] = bn[pl];
+            for (int jj = 0; jj < 2; ++jj)
+                acc[j0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[0]), __builtin_bit_cast(f16x8, b[jj][0]), acc[j0 + jj], 0, 0, 0);
+        };
+        if (!PIPE_PERTURB(16)) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) bB[jj][pl] = *reinterpret_cast<const u32x4 *>(xs + pl * PLSZ + (2 + jj) * 128);
         }
-        PSTAMP(5);
-        ++ts;
-        if (++tap == KT) {
-            __syncthreads();
-            PSTAMP(6);
-            // experiment: skew the two waves of a SIMD (column halves) against each other after the barrier that aligned them
-            if (PIPE_PERTURB(32) && wn) __builtin_amdgcn_s_sleep(3);
-            if (PIPE_PERTURB(64) && wn) __builtin_amdgcn_s_sleep(6);
-            if (PIPE_PERTURB(128) && wn) __builtin_amdgcn_s_sleep(12);
-            tap = 0;
-            ++gc;
-            if (++chunk == nchunks) {
-                chunk = 0;
-                tile_end();
-            } else if (pend != 1.f) {              // (wave-uniform, rare: the next chunk raised the tile's largest magnitude)
-#pragma unroll
-                for (int j = 0; j < NT_W; ++j) acc[j] *= pend;
+        __builtin_amdgcn_sched_barrier(0);
+        pair_mfma(0, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // the chunk's epilogue events sit at fixed taps: event k of the chunk at tap k * KT / 3 for the waves of column half 0 and one tap
+            // later for those of half 1
+            constexpr int K0 = pipe_event_at(T, KT, 0), K1 = pipe_event_at(T, KT, 1);
+            if constexpr (K0 >= 0 || K1 >= 0) {
+                const int kk = wn ? K1 : K0;
+                if (kk >= 0 && kk < epc && ev < PIPE_EVENTS && !PIPE_PERTURB(1)) epi_event();
             }
-            pend = 1.f;
         }
-        ++s;
+        __builtin_amdgcn_sched_barrier(0);
+        pair_mfma(2, bB);
+        __builtin_amdgcn_sched_barrier(0);
     };
-    while (s < nsteps) {
-        step(std::integral_constant<int, 0>{});
-        if (s < nsteps) step(std::integral_constant<int, 1>{});
+    for (int g = 0; g < G; ++g) {
+        const unsigned *cur = (g & 1) ? lbuf1 : lbuf0;
+        for_each_tap([&](auto t_tag) __attribute__((always_inline)) { tap_body(t_tag, cur, g); }, std::make_integer_sequence<int, KT>{});
+        __syncthreads();
+        // the accumulators follow the tile's running scale (pend = 1 unless the chunk stored during this one raised the largest magnitude):
+        // unconditional, so that the accumulators stay in place (a conditional multiply made hipcc copy all 64 at every chunk boundary)
+#pragma unroll
+        for (int j = 0; j < NT_W; ++j) acc[j] *= pend;
+        pend = 1.f;
+        if (++chunk == nchunks) {
+            chunk = 0;
+            tile_end();
+        }
     }
     // ---- the last tile's epilogue (nothing left to hide it under)
-    while (ev < PIPE_EVENTS && !PIPE_PERTURB(1)) {
-        if (ev & 1) epi_event(std::integral_constant<int, 1>{});
-        else epi_event(std::integral_constant<int, 0>{});
-    }
+    while (ev < PIPE_EVENTS && !PIPE_PERTURB(1)) epi_event();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -473,20 +502,33 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvParams p) {
 int launch_pipe(ConvParams p, int span, int ncu, hipStream_t s) {
     p.W = PIPE_BN + span;
     const size_t lds = (size_t)2 * 2 * 2 * p.W * 16 + 64 + 512 + (size_t)8 * 2 * 8 * PIPE_CW * sizeof(float) + (size_t)8 * 3 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VS_CHECK_HIP(hipFuncSetAttribute((const void *)conv_pipe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VS_CHECK_HIP(hipFuncSetAttribute((const void *)conv_pipe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+
     const int mb = p.MT / 4;
     const int ntiles = (p.N / PIPE_BN) * p.B;
     dim3 grid((unsigned)std::max(1, std::min(ntiles, ncu / mb)), (unsigned)mb, 1);
-    if (p.out[0].acc) hipLaunchKernelGGL(conv_pipe_kernel<true>, grid, dim3(512), lds, s, p);
-    else hipLaunchKernelGGL(conv_pipe_kernel<false>, grid, dim3(512), lds, s, p);
-    VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("conv_pipe_kernel<%s>", p.out[0].acc ? "true" : "false");
-    return VS_OK;
+    auto go = [&](auto kt_tag, auto acc_tag) -> int {
+        constexpr int KT = decltype(kt_tag)::value;
+        constexpr bool HA = decltype(acc_tag)::value;
+        auto kern = conv_pipe_kernel<KT, HA>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+        VS_CHECK_HIP(hipGetLastError());
+        set_last_kernel("conv_pipe_kernel<%d, %s>", KT, HA ? "true" : "false");
+        return VS_OK;
+    };
+    const bool ha = p.out[0].acc != nullptr;
+    switch (p.KT) {
+#define VS_PIPE_CASE(K) case K: return ha ? go(std::integral_constant<int, K>{}, std::true_type{}) : go(std::integral_constant<int, K>{}, std::false_type{});
+        VS_PIPE_CASE(3) VS_PIPE_CASE(5) VS_PIPE_CASE(7) VS_PIPE_CASE(9) VS_PIPE_CASE(11)
+#undef VS_PIPE_CASE
+        default: break;
+    }
+    set_error("launch_pipe: no instance for %d taps", p.KT);
+    return VS_EUNSUPPORTED;
 }
 
 }  // namespace vs
