@@ -97,6 +97,10 @@ VS_API void vs_conv_destroy(vs_conv_t *h);
 /* w: [c_out, c_in, k] ([c_in, c_out, k] for transpose).  g == NULL: w is the effective weight;
  * g != NULL: w is weight_v and g is weight_g ([dim0,1,1]) -> folded on the device.  bias may be NULL.          */
 VS_API int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const float *bias, void *stream);
+/* The same for TWO handles fed from one plain (already folded) weight `w` -- a conv and the VS_CONV_ADJOINT handle of its grad-input -- in
+ * one pair of launches instead of two: the training step packs every weight version for both (autograd.HipConvFn).  bias0: h0's bias or
+ * NULL; h1 gets none.  Falls back to two vs_conv_set_weights calls outside the split-f16 arithmetic.  (No reference counterpart.)       */
+VS_API int vs_conv_set_weights_pair(vs_conv_t *h0, vs_conv_t *h1, const float *w, const float *bias0, void *stream);
 
 /* Arithmetic of the matrix contraction of one conv handle (inputs, outputs and accumulation are fp32 in every mode):
  *   VS_MATH_F32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), Winograd F(2,3) instances where they measured faster
@@ -239,6 +243,9 @@ VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma
 VS_API int vs_gate_fwd(const float *x_in, const float *g, int64_t g_bs, float *acts, int64_t B, int64_t H, int64_t T, void *stream);
 VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const float *dacts, float *dx_in, float *dg, int64_t dg_bs,
                        int64_t B, int64_t H, int64_t T, void *stream);
+/* gb[c] = sum over (b, t) of gy[b, c, t]: the bias gradient of every conv of the training path (what autograd computes for the `bias`
+ * argument of torch.nn.functional.conv1d for the convs of modules/visinger under tasks/visinger.py:53-89), deterministic, one launch.     */
+VS_API int vs_bias_grad(const float *gy, float *gb, int64_t B, int64_t C, int64_t T, void *stream);
 VS_API int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const float *dy, float *dx, float *dgamma,
                               float *dbeta, int64_t B, int64_t C, int64_t T, float eps, void *stream);
 

@@ -90,6 +90,7 @@ def lib():
     L.vs_conv_destroy.argtypes = [ctypes.c_void_p]
     L.vs_conv_destroy.restype = None
     L.vs_conv_set_weights.argtypes = [ctypes.c_void_p, _f32p, _f32p, _f32p, ctypes.c_void_p]
+    L.vs_conv_set_weights_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _f32p, _f32p, ctypes.c_void_p]
     L.vs_conv_set_math.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.vs_conv_get_math.argtypes = [ctypes.c_void_p]
     L.vs_conv_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(ConvIO), ctypes.c_void_p]
@@ -106,6 +107,7 @@ def lib():
                                      ctypes.c_float, vp]
     L.vs_gate_fwd.argtypes = [_f32p, _f32p, i64, _f32p, i64, i64, i64, vp]
     L.vs_gate_bwd.argtypes = [_f32p, _f32p, i64, _f32p, _f32p, _f32p, i64, i64, i64, i64, vp]
+    L.vs_bias_grad.argtypes = [_f32p, _f32p, i64, i64, i64, vp]
     L.vs_layernorm_c_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, i64, i64, i64, ctypes.c_float, vp]
     u64, cf = ctypes.c_uint64, ctypes.c_float
     L.vs_relattn_train_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, _f32p, i64, ci, ci, i64, ci, ci, cf, u64, vp]
@@ -137,7 +139,7 @@ def lib():
 # (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
 PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
                for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
-                            "VS_WGRAD_GEMM", "VS_TRAIN_ATEN", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE")}
+                            "VS_WGRAD_GEMM", "VS_TRAIN_ATEN", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE")}
 
 
 def switch(name):

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from .ops import PROFILER, ConvOp, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_weight, gconv1d_fwd
+from .ops import PROFILER, ConvOp, bias_grad, conv_wgrad, gconv1d_bwd_data, gconv1d_bwd_weight, gconv1d_fwd
 
 LRELU_SLOPE = 0.1
 
@@ -65,7 +65,12 @@ class HipConvFn(torch.autograd.Function):
         op = module._op(bind=False)
         key = param_key(module)
         if not op.has_weights_of(key):
-            op.set_weights_from(w, b, key)
+            # the grad-input handle of a stride-1 conv (created by the first backward) takes the same weight: both packs in one pair of launches
+            adj = module.__dict__.get("_hip_bwd_ops", {}).get("dxa") if (key is not None and not L.switch("VS_NO_PAIR_PACK")) else None
+            if adj is not None and ctx.needs_input_grad[0]:
+                op.set_weights_pair(adj, w, b, key)
+            else:
+                op.set_weights_from(w, b, key)
         y = op.forward(x)
         ctx.module = module
         ctx.wkey = key                  # the backward handles pack the adjoint of THIS weight: keyed by the forward's key, not by the parameters' state at backward time
@@ -79,7 +84,7 @@ class HipConvFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         gy = gy.contiguous()
         gx, gw = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]), key=ctx.wkey)
-        gb = gy.sum((0, 2)) if (need[2] and ctx.has_bias) else None
+        gb = bias_grad(gy) if (need[2] and ctx.has_bias) else None
         return gx, gw, gb, None
 
 
@@ -193,7 +198,12 @@ class StridedConv1dFn(torch.autograd.Function):
         op = _cached_op(holder, ("fwd", C, Cout, K, stride), L.CONV1D, stride * C, Cout, Q, 1, 0, 0)
         key = param_key(holder)
         if not op.has_weights_of(key):
-            op.set_weights_from(_phase_weights(w.detach(), stride, Q) if stride > 1 else w, b, key)
+            wq = _phase_weights(w.detach(), stride, Q) if stride > 1 else w
+            adj = holder.__dict__.get("_hip_disc_ops", {}).get(("dxa", C, Cout, K, stride)) if (key is not None and not L.switch("VS_NO_PAIR_PACK")) else None
+            if adj is not None and ctx.needs_input_grad[0]:
+                op.set_weights_pair(adj, wq, b, key)
+            else:
+                op.set_weights_from(wq, b, key)
         yF = op.forward(XF)                                                                     # [1, Cout, N*Hq]
         ctx.save_for_backward(XF, w)
         ctx.cfg = (N, C, T, K, stride, pad, Q, Hq, Tout, b is not None, holder)
@@ -228,7 +238,7 @@ class StridedConv1dFn(torch.autograd.Function):
                 g2 = conv_wgrad(gyF, XF, Q, 1, 0)                                               # [Cout, s*C, Q]
             gw = g2.view(Cout, stride, C, Q).permute(0, 2, 3, 1).reshape(Cout, C, Q * stride)[:, :, :K].contiguous() if stride > 1 else g2
         if has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2))
+            gb = bias_grad(gy)
         return gx, gw, gb, None, None, None
 
 
@@ -249,7 +259,7 @@ class GroupedConv1dFn(torch.autograd.Function):
         gy = gy.contiguous().float()
         gx = gconv1d_bwd_data(gy, w, x.shape[2], stride, pad, groups) if ctx.needs_input_grad[0] else None
         gw = gconv1d_bwd_weight(gy, x, w.shape[2], stride, pad, groups) if ctx.needs_input_grad[1] else None
-        gb = gy.sum((0, 2)) if (has_bias and ctx.needs_input_grad[2]) else None
+        gb = bias_grad(gy) if (has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None
 
 

@@ -583,6 +583,7 @@ static int launch_bf16(const AttnParams &p, hipStream_t s) {
         dim3 pgrid((unsigned)ceil_div(p.T, AKT), (unsigned)p.nh, (unsigned)p.B);
         hipLaunchKernelGGL((attn_pack_kv_kernel<DT, AKT>), pgrid, dim3(256), 0, s, p);
         VS_CHECK_HIP(hipGetLastError());
+        if (AKT == 32 && attn_dma_supported(p)) return launch_attn_dma(p, s);      // (round 4: the LDS-DMA ring kernel, attention_dma.hip)
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -1,0 +1,374 @@
+// attention_dma.hip -- relattn_dma_kernel: MultiHeadAttention.attention (reference modules/rel_transformer.py:148-179 + 181-243) for the
+// long-form configuration (BASELINE config 5: T_mel 4096, hidden 512 -> 2 heads of 256 channels, plain-bf16 arithmetic), round 4.
+// Same algorithm, layouts and arithmetic as relattn_bf16_kernel<DT, 32, 1, true> (attention_bf16.hip: streaming softmax over 32-key
+// tiles, -1e4 mask fill, banded relative terms, K / V tiles pre-packed as LDS images by attn_pack_kv_kernel); what changes is how a tile
+// reaches LDS and how the matrix instructions are fed (263 TFLOP/s = 0.105 of the bf16 peak, one wave per SIMD,
+// 132 B of scratch, every load round trip exposed):
+//   * the image of a tile (K, V, key mask: 36 992 contiguous bytes) goes from global memory STRAIGHT into LDS by LDS-DMA
+//     (global_load_lds_dwordx4: no register destination) into a ring of three slots, TWO tiles ahead of the one being used: no staging
+//     registers (72 VGPRs in the old kernel, which then used all 512 registers and moved 1 186 values between the two register files),
+//     no LDS stores, and an L2 / HBM round trip has two whole tiles to complete.  One barrier per tile: the wave's own pieces are waited
+//     for by count (s_waitcnt vmcnt(n): the next tile's 9 or 10 pieces may stay in flight), the barrier makes every wave's pieces visible
+//     and retires every read of the slot that is refilled right after it;
+//   * S^T = K^T Q accumulates even and odd k-steps in TWO accumulator tiles (added once per tile): a chain of 16 dependent MFMAs on one
+//     tile issues at ~70 % of the pipe from a lone wave (round 4, tools/pipe_perturb.py); the P V MFMAs of a k-step already walk eight
+//     independent output tiles;
+//   * every LDS fragment is read one MFMA ahead of its use.
+// Results differ from relattn_bf16_kernel only by the summation order of S^T (even + odd k-steps): both are held to the same bounds
+// against the fp32 / fp64 restatements (tests/test_conv_split_gpu.py::test_bf16_attention_matches_fp32_kernel, test_attention_dma_gpu.py).
+#include "attn_common.h"
+#include "conv_common.h"
+
+namespace vs {
+
+// A/B knobs of the fragment pipeline (defaults = what measured fastest on the box)
+#ifndef ATT_KD
+#define ATT_KD 4        // K fragments in flight ahead of their MFMA
+#endif
+#ifndef ATT_VD
+#define ATT_VD 3        // V fragments in flight
+#endif
+#ifndef ATT_PIN
+#define ATT_PIN 0       // 1: query fragments pinned in the accumulator file
+#endif
+#ifndef ATT_SB
+#define ATT_SB 1        // 1: sched_barrier between (MFMA, next read) steps
+#endif
+
+template <int DT>
+__global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p) {
+    constexpr int AKT = 32;
+    constexpr int DKR = DT * 32;                     // padded head dim
+    constexpr int NKS = DKR / 16;                    // k-steps of S^T = K^T Q
+    constexpr int AVP = AKT / 2 + 4;                 // V row pitch in dwords
+    constexpr int KPL = (DKR / 8) * AKT * 4;         // dwords of the K image
+    constexpr int VPL = DKR * AVP;                   // dwords of the V image
+    constexpr int IMG = KPL + VPL + AKT;             // dwords of a tile image: K, V, key mask
+    constexpr int NU4 = IMG / 4;                     // 16-byte units of an image
+    constexpr int NFULL = NU4 / 256;                 // pieces every wave issues (one 16-byte unit per lane each)
+    constexpr int NTAIL = NU4 - NFULL * 256;         // units of the last, partial piece (lanes of wave 0)
+    static_assert(IMG % 4 == 0 && NTAIL >= 0 && NTAIL < 256 && NKS % 2 == 0, "image geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    // XCD-aware placement (1-D grid): workgroup L runs on XCD L % 8 and workgroups are dispatched in order, so the query blocks of ONE
+    // (batch, head) pair are given ids of one residue class -- they then run on one XCD at about the same time and stream the pair's
+    // K / V images through THAT XCD's L2 once (76 MB of images per launch against 8 x 4 MB of L2: with the plain (query block, head,
+    // batch) grid the 32 query blocks of a pair sat on all eight XCDs and every tile came from beyond L2 several times).
+    const int nqb = (p.T + 127) / 128, npair = p.nh * p.B;
+    int qblk, pair;
+    if ((npair & 7) == 0) {
+        const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+        qblk = idx % nqb;
+        pair = (idx / nqb) * 8 + xcd;
+    } else {
+        qblk = blockIdx.x % nqb;
+        pair = blockIdx.x / nqb;
+    }
+    const int b = pair / p.nh, h = pair - b * p.nh;
+    const int i0 = (qblk * 4 + wave) * 32;
+    const int dk = p.dk, T = p.T;
+    const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
+
+    unsigned *const ring = reinterpret_cast<unsigned *>(smem);           // [3][IMG]
+    float *const QRs = smem + 3 * IMG;                                    // [4][32][ATT_QRS] rel-key logits
+    float *const Sws = QRs + 4 * 32 * ATT_QRS;                            // [4][32][ATT_QRS] in-window raw scores
+    float *const RVs = smem;                                              // [nrel][dk] relative value embeddings: over the ring, after the loop
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)ring);
+
+    const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
+    const float *maskb = p.mask ? p.mask + (long long)b * T : nullptr;
+    const float *relk = nrel ? p.rel_k + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+    const float *relv = nrel ? p.rel_v + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
+
+    // ---- query fragments: B operand of S^T = K^T Q, element j of k-step ks = Q[d = 16 ks + 8 half + j][query l31], RNE to bf16 ----
+    const int qi = i0 + l31;
+    const int qic = min(qi, T - 1);
+    auto planes8 = [&](const float (&v)[8]) __attribute__((always_inline)) -> u32x4 {
+        u32x4 o;
+        o.x = pack_hi(rne_bf16(v[0]), rne_bf16(v[1])); o.y = pack_hi(rne_bf16(v[2]), rne_bf16(v[3]));
+        o.z = pack_hi(rne_bf16(v[4]), rne_bf16(v[5])); o.w = pack_hi(rne_bf16(v[6]), rne_bf16(v[7]));
+        return o;
+    };
+    u32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        float qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = 16 * ks + 8 * half + j;
+            const float v = qb[(long long)min(d, dk - 1) * T + qic];
+            qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
+        }
+        qf[ks] = planes8(qv);
+        // the query fragments live in the ACCUMULATOR file for the whole kernel (an MFMA takes its A / B operands from either file): 64
+        // arch VGPRs freed for LDS fragments in flight -- an LDS round trip is ~200 cycles here and a lone wave has only its own loads
+        // to cover it with, so the K / V fragments are requested eight / six MFMAs ahead
+        if (ATT_PIN) asm volatile("" : "+a"(qf[ks]));
+    }
+    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] from the fp32 query (rolled loops: prologue code off the main loop's registers)
+    float qr[ATT_MAXREL];
+#pragma unroll
+    for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
+    if (nrel) {
+#pragma unroll 1
+        for (int d8 = half; d8 < (dk + 7) / 8; d8 += 2) {
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * d8 + j;
+                if (d < dk && qi < T) {
+                    const float qs = qb[(long long)d * T + qic] * p.scale;
+#pragma unroll
+                    for (int r = 0; r < ATT_MAXREL; ++r)
+                        if (r < nrel) qr[r] += qs * relk[r * dk + d];
+                }
+            }
+        }
+    }
+    float *QRw = QRs + wave * 32 * ATT_QRS;
+    float *Sww = Sws + wave * 32 * ATT_QRS;
+    for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
+    if (nrel) {
+#pragma unroll
+        for (int r = 0; r < ATT_MAXREL; ++r) {
+            const float tot = qr[r] + __shfl_xor(qr[r], 32);      // the two lane halves hold complementary d's
+            if (half == 0) QRw[l31 * ATT_QRS + r] = tot;
+        }
+    }
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_half = 0.f;
+    const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
+
+    // ---- the tile ring ----
+    const int ntiles = (T + AKT - 1) / AKT;
+    const char *const imgb = reinterpret_cast<const char *>(p.kvimg + ((long long)(b * p.nh + h) * ntiles) * IMG);
+    const int lane16 = tid * 16;                                    // byte offset of this lane's unit inside a piece of 256 units
+    // NFULL pieces of 256 units each (one 16-byte unit per lane: lane i of wave w moves unit 256 p + 64 w + i of the image to the same
+    // unit of the slot), issued from ONE statement that saves M0 once: per piece an s_mov of the LDS address, the DMA, two scalar adds
+    auto dma_tile = [&](int jt, int slot) __attribute__((always_inline)) {
+        const char *src = imgb + (long long)jt * (IMG * 4);
+        unsigned dst = ring_lds + slot * (IMG * 4) + wave * 1024;
+        unsigned keep;
+        // (two offset registers used alternately, each advanced only after the OTHER one's load has been issued: the add never follows
+        //  the load that reads the register)
+        int va = lane16, vb = lane16 + 0x1000;
+#define VS_LD(v) "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " v ", %4\n\ts_add_u32 %1, %1, 0x1000\n\t"
+#define VS_PAIR VS_LD("%2") VS_LD("%3") "v_add_u32 %2, 0x2000, %2\n\tv_add_u32 %3, 0x2000, %3\n\t"
+        static_assert(NFULL == 6 || NFULL == 9, "pieces per tile image (192- / 256-channel heads)");
+        if constexpr (NFULL == 9)
+            asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR VS_PAIR VS_PAIR VS_LD("%2") "s_nop 1\n\tv_add_u32 %2, 0x1000, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep), "+s"(dst), "+v"(va), "+v"(vb) : "s"(src) : "memory", "scc");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR VS_PAIR "s_mov_b32 m0, %0"
+                         : "=&s"(keep), "+s"(dst), "+v"(va), "+v"(vb) : "s"(src) : "memory", "scc");
+#undef VS_PAIR
+#undef VS_LD
+        const int voff = va;          // = lane16 + NFULL * 4096 in both cases
+        if (NTAIL && tid < NTAIL) glds16(voff, src, dst);      // (the last, partial piece: the first waves only)
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (nothing of the prologue's loads may be counted against the ring)
+    dma_tile(0, 0);
+    if (ntiles > 1) dma_tile(1, 1);
+
+#define ASTAMP(k)                                                                                                    \
+    do {                                                                                                             \
+        if (p.stamps && blockIdx.x == 0 && wave == 0 && jt < 120) {            \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+            if (lane == 0) p.stamps[jt * 8 + (k)] = t_;                                                              \
+        }                                                                                                            \
+    } while (0)
+    for (int jt = 0; jt < ntiles; ++jt) {
+        const int j0 = jt * AKT;
+        ASTAMP(0);
+        // this wave's pieces of tile jt have landed (those of tile jt + 1 -- NFULL, + 1 for the waves of the partial piece -- may stay in flight) ...
+        if (jt + 1 < ntiles) {
+            if (NTAIL && wave * 64 < NTAIL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFULL + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFULL) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // ... everybody's have, and everybody is done with tile jt - 1, whose slot takes tile jt + 2
+        __syncthreads();
+        ASTAMP(1);
+        if (jt + 2 < ntiles) dma_tile(jt + 2, (jt + 2) % 3);
+        ASTAMP(2);
+        const unsigned *Kb = ring + (jt % 3) * IMG, *Vb = Kb + KPL;
+        const float *Mb = reinterpret_cast<const float *>(Vb + VPL);
+
+        // ---- S^T tile: rows = keys acc_row(r), columns (lanes) = queries; even / odd k-steps in two accumulators ----
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        {
+            auto readK = [&](int ks) __attribute__((always_inline)) {
+                return *reinterpret_cast<const u32x4 *>(Kb + ((2 * ks + half) * AKT + l31) * 4);
+            };
+            // (fragments eight k-steps ahead of their MFMA: one wave per SIMD has nothing else to cover an LDS round trip with)
+            constexpr int KD = ATT_KD;
+            u32x4 kf[KD];
+#pragma unroll
+            for (int i = 0; i < KD; ++i) kf[i] = readK(i);
+            if (ATT_SB) __builtin_amdgcn_sched_barrier(0);          // (the scheduler may sink every read to its use to save registers: pin the order)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ATT_SB) __builtin_amdgcn_sched_barrier(0);
+                const u32x4 kc = kf[ks % KD];
+                if (ks + KD < NKS) kf[ks % KD] = readK(ks + KD);
+                if (ks & 1) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kc), __builtin_bit_cast(bf16x8, qf[ks]), s1, 0, 0, 0);
+                else s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kc), __builtin_bit_cast(bf16x8, qf[ks]), s0, 0, 0, 0);
+            }
+        }
+        ASTAMP(3);
+        const bool near_diag = nrel && (j0 + AKT - 1 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
+        // the common tile: wholly inside the sequence, no padded key, no padded query in this wave, off the relative window -- the scores
+        // are the MFMA results as they are (wave-uniform test: one LDS read of the tile's key mask per lane and two ballots)
+        const bool plain = !near_diag && (j0 + AKT <= T) && __all(Mb[l31] != 0.f) && __all(mi != 0.f);
+        float tmax = -INFINITY;
+        float sv_[16];
+        if (plain) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sv_[r] = s0[r] + s1[r];
+                tmax = fmaxf(tmax, sv_[r]);
+            }
+        } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int j = j0 + jj;
+            float sv = s0[r] + s1[r];
+            if (near_diag) {
+                const int rel = j - qi;
+                if (rel >= -p.ws && rel <= p.ws) sv += QRw[l31 * ATT_QRS + rel + p.ws];
+            }
+            if (mi * Mb[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
+            if (j >= T) sv = -INFINITY;                  // beyond the sequence: not part of the softmax
+            if (near_diag) {
+                const int rel = j - qi;
+                if (rel >= -p.ws && rel <= p.ws && j < T) Sww[l31 * ATT_QRS + rel + p.ws] = sv;
+            }
+            sv_[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float psum = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = __expf(sv_[r] - m_new);              // exp(-inf) = 0 for excluded keys; the result is rounded to 8 bits anyway: the fast exp
+            psum += pv[r];
+        }
+        u32x4 pf[2];                                      // P^T fragments of the two 16-key k-steps
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = pv[8 * sh + e];
+            pf[sh] = planes8(v8);
+        }
+        l_half = l_half * alpha + psum;
+        m_run = m_new;
+        // the running maximum of a row settles after a few tiles: skip the rescale of the output accumulators whenever no query of the
+        // wave moved its maximum
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                __builtin_amdgcn_sched_barrier(0);      // (one output tile at a time through the VGPRs: batching all eight costs 128 live registers)
+            }
+        }
+
+        ASTAMP(4);
+        // ---- O^T += V P^T: k-step s4 sums over the keys 16 s4 + 8 (j >> 2) + 4 half + (j & 3), the order of the V rows ----
+        {
+            auto readV = [&](int s4, int t) __attribute__((always_inline)) {
+                return *reinterpret_cast<const u32x4 *>(Vb + (t * 32 + l31) * AVP + s4 * 8 + half * 4);
+            };
+            constexpr int VD = ATT_VD;
+            u32x4 vf[VD];
+#pragma unroll
+            for (int i = 0; i < VD; ++i) vf[i] = readV(i / DT, i % DT);
+            if (ATT_SB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 2 * DT; ++n) {
+                if (ATT_SB) __builtin_amdgcn_sched_barrier(0);
+                const u32x4 vc = vf[n % VD];
+                if (n + VD < 2 * DT) vf[n % VD] = readV((n + VD) / DT, (n + VD) % DT);
+                o[n % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), __builtin_bit_cast(bf16x8, pf[n / DT]), o[n % DT], 0, 0, 0);
+            }
+        }
+        ASTAMP(5);
+    }
+#undef ASTAMP
+
+    // ---- finish: normalise, add the relative-value term (fp32), store ----
+    __syncthreads();                                     // every read of the ring has retired: its first bytes take the relative value table
+    for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
+    __syncthreads();
+    const float l_tot = l_half + __shfl_xor(l_half, 32);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= inv;
+    // sum_r p[i, i + r - ws] * rel_v[r]: the window index is the (rolled) outer loop so that every access to the output accumulators
+    // has a compile-time index
+#pragma unroll 1
+    for (int rr = 0; rr < nrel; ++rr) {
+        const float w = expf(Sww[l31 * ATT_QRS + rr] - m_run) * inv;
+        const float *rv = RVs + rr * dk;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
+    }
+    float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (d < dk && qi < T) ob[(long long)d * T + qi] = o[t][r];
+        }
+    }
+}
+
+template <int DT>
+static int launch_dma_dt(const AttnParams &p, hipStream_t s) {
+    constexpr int DKR = DT * 32, IMG = (DKR / 8) * 32 * 4 + DKR * 20 + 32;
+    const size_t lds = 4 * ((size_t)3 * IMG + 2 * 4 * 32 * ATT_QRS);
+    auto kern = relattn_dma_kernel<DT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(ceil_div(p.T, 128) * p.nh * p.B), 1, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    VS_CHECK_HIP(hipGetLastError());
+    set_last_kernel("relattn_dma_kernel<%d>", DT);
+    return VS_OK;
+}
+
+// p.kvimg holds the images attn_pack_kv_kernel<DT, 32> wrote for this launch (32-key tiles: heads of 129 .. 256 channels); no key split
+bool attn_dma_supported(const AttnParams &p) {
+    const int DT = (int)ceil_div(p.dk, 32);
+    return p.kvimg && DT > 4 && DT <= 8 && !(p.part && p.ksplit > 1) && !opt(OPT_NO_ATTN_DMA);
+}
+
+int launch_attn_dma(const AttnParams &p, hipStream_t s) {
+    const int DT = (int)ceil_div(p.dk, 32);
+    return DT <= 6 ? launch_dma_dt<6>(p, s) : launch_dma_dt<8>(p, s);
+}
+
+}  // namespace vs

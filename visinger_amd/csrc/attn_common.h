@@ -25,6 +25,7 @@ struct AttnParams {
     // -- K as [d/8][key][8 bf16], V as [d][permuted keys] + row padding, the tile's key mask -- built ONCE per launch by
     // attn_pack_kv_kernel instead of once per query block (T / 128 times) inside the attention kernel; null: convert in the kernel
     unsigned *kvimg;              // [B][nh][key tiles][attn_kv_image_dwords(dk)] or null
+    unsigned long long *stamps;   // debug (vs_debug_set_stamp_buffer): shader-clock stamps of workgroup (0, 0, 0), wave 0; null in production
 };
 
 // bytes of the pre-packed K / V images for a launch of the plain-bf16 kernel, 0 where the kernel converts in place (short sequences,
@@ -37,5 +38,9 @@ size_t attn_kv_work_bytes(long long B, int nh, int dk, long long T);
 bool attn_bf16_supported(const AttnParams &p, int terms);
 int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s);
 int launch_attn_combine(const AttnParams &p, hipStream_t s);
+// attention_dma.hip (round 4): the pre-packed plain-bf16 kernel for heads of 129 .. 256 channels with the tile images brought into an LDS
+// ring by LDS-DMA; p.kvimg as written by attn_pack_kv_kernel<DT, 32> (launch_attn_bf16 runs the pack, then asks here)
+bool attn_dma_supported(const AttnParams &p);
+int launch_attn_dma(const AttnParams &p, hipStream_t s);
 
 }  // namespace vs

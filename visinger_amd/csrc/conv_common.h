@@ -151,6 +151,15 @@ __device__ __forceinline__ int wave_max_u8(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// 16 bytes per lane from global memory straight into LDS (no register destination: nothing for hipcc to copy before the data lands):
+// lane i's bytes go to lds_dst + 16 * i (tools/ubench/glds_layout.hip); counted in vmcnt like any load.  M0 is written in the statement
+// that reads it (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(int lane_byte_off, const char *base, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+
 // conv_split.hip
 struct vs_split_pack {            // re-pack of the fp32 fragment-order weights into bf16 planes
     const float *wp;              // Wp[m_tile][tap][chunk][quad(2)][64][4] (pack_conv_kernel)
@@ -162,6 +171,7 @@ struct vs_split_pack {            // re-pack of the fp32 fragment-order weights 
 };
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);
+int pack_split_pair(const vs_split_pack &q0, const vs_split_pack &q1, hipStream_t s);   // terms = 3, both maxima ready: one launch
 // cfg: tile shape as chosen by vs_conv_forward for the direct engine (0: 128 rows, 1/3: 64, 2: 32 x 256, 6: 32 x 128; 4/5: paired); span = receptive span
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);   // (p.x_bf16 / p.y_bf16: terms = 1, cfg 0 / 2 / 3 / 6)
 

@@ -46,7 +46,7 @@ static OptEntry g_opts[OPT_COUNT] = {
     {"VS_NO_WINO_K7", 0, 0}, {"VS_WINO_DBG", 0, 0}, {"VS_NO_WSPLIT", 0, 0}, {"VS_WSPLIT_FORCE", 0, 0}, {"VS_WSPLIT_STAGGER", 0, 0},
     {"VS_NO_SMALL_GRID", 0, 0}, {"VS_SMALL_GRID_T6", 512, 512}, {"VS_CONV_CFG", -1, -1}, {"VS_SPLIT_DBG", 0, 0}, {"VS_TRACE", 0, 0},
     {"VS_NO_BF16_ATTN", 0, 0}, {"VS_NO_SPLIT_ATTN", 0, 0}, {"VS_NO_WGRAD_SPLIT", 0, 0}, {"VS_RB_TILE256", 0, 0},
-    {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_PIPE", 0, 0},
+    {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_PIPE", 0, 0}, {"VS_NO_ATTN_DMA", 0, 0},
 };
 static const bool g_opts_loaded = [] {
     for (OptEntry &e : g_opts) {
@@ -872,7 +872,7 @@ __device__ __forceinline__ float packed_weight(const PackParams &q, int mt, int 
     return val;
 }
 
-__global__ void pack_conv_kernel(const PackParams q) {
+__device__ __forceinline__ void pack_conv_body(const PackParams &q) {
     const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
     const long long work = max(total, (long long)q.MT_alloc * 32);
     if (blockIdx.x == 0 && threadIdx.x == 0 && q.maxbits_clear) *q.maxbits_clear = 0u;
@@ -904,6 +904,13 @@ __global__ void pack_conv_kernel(const PackParams q) {
         __syncthreads();
         if (threadIdx.x == 0) atomicMax(q.maxbits, max(max(red[0], red[1]), max(red[2], red[3])));
     }
+}
+__global__ void pack_conv_kernel(const PackParams q) { pack_conv_body(q); }
+// two handles fed from the same weight (a conv and the ADJOINT handle of its grad-input: vs_conv_set_weights_pair) in ONE launch:
+// blockIdx.y selects the handle.  A training step packs every weight for both; two launches per handle were 1 068 of its 6 175.
+__global__ void pack_conv_pair_kernel(const PackParams q0, const PackParams q1) {
+    if (blockIdx.y == 0) pack_conv_body(q0);
+    else pack_conv_body(q1);
 }
 
 // The same pack for the bf16-pipe engine in ONE launch: thread (cell = (m_tile, tap, chunk), lane) produces the eight values of its bf16
@@ -1432,6 +1439,55 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
     h->wsplit_packed = false;      // (the F(2,3) transform of the split engine is rebuilt from Wp by the first launch that uses it)
     h->weights_set = true;
     return VS_OK;
+}
+
+// fp32 fragments + bias of handle h from (w, bias): the PackParams of vs_conv_set_weights for a plain (already folded) weight
+static void fill_pack_params(vs_conv *h, const float *w, const float *bias, PackParams &q) {
+    q.w = w; q.scale = nullptr; q.bias = bias; q.wp = h->wp.as<float>(); q.biasp = h->biasp.as<float>();
+    q.kind = h->kind; q.c_in = h->c_in; q.c_out = h->c_out; q.k = h->k; q.up = h->dil; q.pad = h->pad; q.dmin = h->dmin;
+    q.KT = h->KT; q.CP = h->CP; q.MT_alloc = h->MT_alloc; q.Hh = h->Hh; q.flags = h->flags; q.wino_tail1 = 0;
+    ++h->pack_gen;
+    q.maxbits = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + (h->pack_gen & 1);
+    q.maxbits_clear = reinterpret_cast<unsigned *>(h->wsc.as<float>() + 2) + ((h->pack_gen + 1) & 1);
+}
+
+int vs_conv_set_weights_pair(vs_conv_t *h0, vs_conv_t *h1, const float *w, const float *bias0, void *stream) {
+    VS_REQUIRE(h0 && h1 && w, "vs_conv_set_weights_pair: NULL handle or weight");
+    // the fused form serves the training step's common case; everything else is the two plain calls
+    const bool fused = h0->math == VS_MATH_SPLIT3 && h1->math == VS_MATH_SPLIT3 && !(h0->kind == VS_CONV1D && h0->c_out <= 4) &&
+                       !(h1->kind == VS_CONV1D && h1->c_out <= 4 && !(h1->flags & VS_CONV_ADJOINT));
+    if (!fused) {
+        VS_TRY(vs_conv_set_weights(h0, w, nullptr, bias0, stream));
+        return vs_conv_set_weights(h1, w, nullptr, nullptr, stream);
+    }
+    hipStream_t s = as_stream(stream);
+    PackParams q[2];
+    vs_conv *hs[2] = {h0, h1};
+    long long work = 0;
+    for (int i = 0; i < 2; ++i) {
+        vs_conv *h = hs[i];
+        const size_t n = (size_t)h->MT_alloc * h->KT * h->CP * 64;
+        VS_TRY(h->wp.reserve(n * sizeof(float)));
+        VS_TRY(h->biasp.reserve((size_t)h->MT_alloc * 32 * sizeof(float)));
+        VS_TRY(reserve_wscale(h, s));
+        VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * 2 * 64 * 16));
+        fill_pack_params(h, w, i == 0 ? bias0 : nullptr, q[i]);
+        work = std::max<long long>(work, std::max<long long>((long long)n, (long long)h->MT_alloc * 32));
+    }
+    hipLaunchKernelGGL(pack_conv_pair_kernel, dim3((unsigned)std::min<long long>(ceil_div(work, 256), 1024), 2), dim3(256), 0, s, q[0], q[1]);
+    VS_CHECK_HIP(hipGetLastError());
+    vs_split_pack sp[2];
+    for (int i = 0; i < 2; ++i) {
+        vs_conv *h = hs[i];
+        sp[i].wp = h->wp.as<float>(); sp[i].ws = h->ws.p; sp[i].MT_alloc = h->MT_alloc; sp[i].KT = h->KT; sp[i].nchunks = h->nchunks; sp[i].terms = 3;
+        sp[i].wscale = h->wsc.as<float>();
+        sp[i].maxbits = reinterpret_cast<const unsigned *>(sp[i].wscale + 2) + (h->pack_gen & 1);
+        sp[i].scratch = nullptr;
+        h->wino_packed = false;
+        h->wsplit_packed = false;
+        h->weights_set = true;
+    }
+    return pack_split_pair(sp[0], sp[1], s);
 }
 
 int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {

@@ -64,15 +64,6 @@ __device__ __forceinline__ const char *uniform_ptr(const void *q) {
     return reinterpret_cast<const char *>(((unsigned long long)hi << 32) | lo);
 }
 
-// 16 bytes per lane from global memory straight into LDS (no register destination: nothing for hipcc to copy before the data lands):
-// lane i's bytes go to lds_dst + 16 * i (tools/ubench/glds_layout.hip); counted in vmcnt like any load.  M0 is written in the statement
-// that reads it (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16(int lane_byte_off, const char *base, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_byte_off), "s"(base), "s"(lds_dst) : "memory");
-}
-
 // Timing-only perturbations (results are garbage): build with -DVS_PIPE_PERTURB and set VS_SPLIT_DBG to a sum of 1 = no epilogue events,
 // 2 = no staging (no activation loads, no split + LDS writes, no exponent exchange), 4 = no wait for the weight fragments, 8 = no
 // weight-fragment loads after the first, 16 = no B-fragment reads.  Compiled out by default.

@@ -124,7 +124,7 @@ __global__ void wabsmax_kernel(const float *wp, long long n, unsigned *maxbits) 
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
 }
-__global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *maxbits) {
+__device__ __forceinline__ void pack_split_f16_body(const vs_split_pack &q, const unsigned *maxbits) {
     const long long total = (long long)q.MT_alloc * q.KT * q.nchunks * 64;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int eb = max(f16_key_exponent(*maxbits), F16_EB_MIN);      // (*maxbits: the largest f16_maxkey; all-zero weights: any scale does)
@@ -152,6 +152,21 @@ __global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *max
         u32x4 o; o.x = d[0][pl]; o.y = d[1][pl]; o.z = d[2][pl]; o.w = d[3][pl];
         dst[pl * 64] = o;
     }
+}
+
+__global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *maxbits) { pack_split_f16_body(q, maxbits); }
+__global__ void pack_split_f16_pair_kernel(const vs_split_pack q0, const vs_split_pack q1) {
+    if (blockIdx.y == 0) pack_split_f16_body(q0, q0.maxbits);
+    else pack_split_f16_body(q1, q1.maxbits);
+}
+
+// the f16 planes of two handles (vs_conv_set_weights_pair) in one launch; both carry their ready weight maximum
+int pack_split_pair(const vs_split_pack &q0, const vs_split_pack &q1, hipStream_t s) {
+    if (!q0.wscale || !q1.wscale || !q0.maxbits || !q1.maxbits) { set_error("pack_split_pair: scale buffers / maxima missing"); return VS_EINVAL; }
+    const long long t0 = (long long)q0.MT_alloc * q0.KT * q0.nchunks * 64, t1 = (long long)q1.MT_alloc * q1.KT * q1.nchunks * 64;
+    hipLaunchKernelGGL(pack_split_f16_pair_kernel, dim3((unsigned)ceil_div(std::max(t0, t1), 256), 2), dim3(256), 0, s, q0, q1);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
 }
 
 int pack_split(const vs_split_pack &q, hipStream_t s) {

@@ -184,7 +184,45 @@ __global__ void __launch_bounds__(256) phase_unstack_kernel(const float *__restr
 
 using namespace vs;
 
+// bias gradient of a conv: gb[c] = sum over (b, t) of gy[b, c, t] -- one workgroup per channel, every thread a fixed strided subset in
+// a fixed order, then a fixed LDS tree: the same bits every run (no atomics), one launch where `gy.sum((0, 2))` took two
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float *__restrict__ gy, float *__restrict__ gb, int B, int C, int T) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(gy) & 15u) == 0) {
+        const int T4 = T >> 2;
+        for (int b = 0; b < B; ++b) {
+            const float4 *row = reinterpret_cast<const float4 *>(gy + ((long long)b * C + c) * T);
+            for (int i = tid; i < T4; i += 256) {
+                const float4 v = row[i];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        }
+    } else {
+        for (int b = 0; b < B; ++b) {
+            const float *row = gy + ((long long)b * C + c) * T;
+            for (int i = tid; i < T; i += 256) s += row[i];
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) gb[c] = red[0];
+}
+
 extern "C" {
+
+int vs_bias_grad(const float *gy, float *gb, int64_t B, int64_t C, int64_t T, void *stream) {
+    VS_REQUIRE(gy && gb && B > 0 && C > 0 && T > 0 && C <= 65535 * 32, "vs_bias_grad: bad arguments");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), gy, gb, (int)B, (int)C, (int)T);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
 
 int vs_gate_fwd(const float *x_in, const float *g, int64_t g_bs, float *acts, int64_t B, int64_t H, int64_t T, void *stream) {
     VS_REQUIRE(x_in && acts && B > 0 && B <= 65535 && H > 0 && H <= 65535 && T > 0, "vs_gate_fwd: bad arguments");

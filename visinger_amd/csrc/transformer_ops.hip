@@ -17,6 +17,8 @@
 
 #include <cstdlib>
 
+extern unsigned long long *g_stamp_buf;   // conv_engine.hip (vs_debug_set_stamp_buffer)
+
 namespace vs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -379,7 +381,7 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     p.out_bs = out_batch_stride ? out_batch_stride : (long long)n_heads * k_channels * T;
     p.B = (int)B; p.nh = n_heads; p.dk = k_channels; p.T = (int)T; p.ws = window_size; p.nh_rel = n_heads_rel;
     p.scale = 1.0f / sqrtf((float)k_channels);
-    p.part = nullptr; p.ksplit = 0; p.kvimg = nullptr;
+    p.part = nullptr; p.ksplit = 0; p.kvimg = nullptr; p.stamps = g_stamp_buf;
     hipStream_t s = as_stream(stream);
     VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6 || math == VS_MATH_SPLIT3, "vs_relattn_fwd: unknown arithmetic %d", math);
     if (math == VS_MATH_SPLIT3) math = VS_MATH_SPLIT6;      // (the attention core has no split-f16 instance: the fp32-class split-bf16 x6 kernel serves both)

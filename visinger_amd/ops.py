@@ -190,6 +190,14 @@ class ConvOp:
                                              L.ptr(None if bias is None else bias.detach().contiguous()), L.stream_ptr()))
         self._wkey = key
 
+    def set_weights_pair(self, adjoint_op, w, bias, key):
+        """Training path: pack `w` for this handle AND for the VS_CONV_ADJOINT handle of its grad-input in one pair of launches
+        (vs_conv_set_weights_pair); both carry `key` afterwards, so the backward finds its weights in place."""
+        L.check(self.lib.vs_conv_set_weights_pair(self.h, adjoint_op.h, L.ptr(w.detach().contiguous()),
+                                                  L.ptr(None if bias is None else bias.detach().contiguous()), L.stream_ptr()))
+        self._wkey = key
+        adjoint_op._wkey = key
+
     def forward(self, x, *, B=None, T=None, x_bs=0, in_act=L.IN_NONE, mask=None, bias_b=None, bias_b_bs=0,
                 y=None, y_bs=0, res=None, res_bs=0, acc=None, acc_bs=0, scale=1.0, out_act=L.OUT_NONE, out_mask=False,
                 mode=L.MODE_LINEAR, split_row=0, out1=None, pair_mode=L.PAIR_GATE, logdet=None,
@@ -377,6 +385,16 @@ def mel2token_to_dur(mel2token, T_txt, max_dur=None):
     L.check(lib.vs_mel2token_to_dur(_i64ptr(m), _i64ptr(dur), B, T, int(T_txt), -1 if max_dur is None else int(max_dur),
                                     L.stream_ptr()))
     return dur
+
+
+def bias_grad(gy):
+    """8f-1: gb[c] = sum_{b,t} gy[b, c, t] (one deterministic launch: vs_bias_grad); gy contiguous fp32 [B, C, T]"""
+    lib = L.require_gpu()
+    gy = gy.contiguous().float()
+    B, C, T = gy.shape
+    gb = torch.empty((C,), device=gy.device, dtype=torch.float32)
+    L.check(lib.vs_bias_grad(L.ptr(gy), L.ptr(gb), B, C, T, L.stream_ptr()))
+    return gb
 
 
 def conv_wgrad(gy, x, k, dil=1, pad=0):
