@@ -38,7 +38,7 @@ VS_API const char *vs_last_error(void);
  * this library, so a caller that attributes per-launch timings to kernel instances (bench.py's roofline line) reads it back
  * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
 VS_API const char *vs_last_kernel_name(void);
-VS_API int vs_abi_version(void);          /* 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
+VS_API int vs_abi_version(void);          /* 6: vs_source_hash, vs_bias_grad, vs_conv_set_weights_pair; 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
 /* sha256 (hex) over the sources this library was compiled from (kernels, headers, textual includes, the build recipe), embedded by
  * visinger_amd/csrc/build.py.  The loader recomputes it over the tree it sits in and refuses a library built from other sources (a
  * stale object that an mtime check would pass after a checkout).  (No reference counterpart: the reference has no native code.)  */

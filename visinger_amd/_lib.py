@@ -22,7 +22,7 @@ FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 MATH_F32, MATH_BF16, MATH_SPLIT3, MATH_SPLIT6 = 0, 1, 3, 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
-EXPECTED_ABI = 5          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
+EXPECTED_ABI = 6          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
 
 _f32p = ctypes.c_void_p
 

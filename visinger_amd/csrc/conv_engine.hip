@@ -1217,7 +1217,7 @@ extern "C" {
 
 const char *vs_last_error(void) { return g_err; }
 const char *vs_last_kernel_name(void) { return g_last_kernel; }
-int vs_abi_version(void) { return 5; }
+int vs_abi_version(void) { return 6; }
 
 int vs_set_option(const char *name, long long value) {
     VS_REQUIRE(name, "vs_set_option: NULL name");
