@@ -35,12 +35,14 @@ print("kernel:", op.kernel_instance())
 for name, v in (("prologue", pro), ("main", main), ("epilogue", epi), ("epi-issue", issued), ("total", st[:, 3] - st[:, 0])):
     print(f"{name:9s} mean {v.mean():8.2f}  p10 {np.percentile(v,10):8.2f}  p50 {np.percentile(v,50):8.2f}  p90 {np.percentile(v,90):8.2f}  max {v.max():8.2f} us")
 if (full[:, 8] != 0).all():
-    names = {8: "xform+bias issued", 9: "res loads issued", 10: "pass0 LDS written", 11: "pass0 stored", 12: "pass1 stored", 13: "pass2 stored", 6: "pass3 stored"}
+    # (-DVS_EPI_STAMPS builds, tools/build_variant.py: wave 0's time stamps inside the vector epilogue; every stamp also waits for the LDS queue)
+    names = {8: "first residual loads issued", 16: "pass0 LDS written (+r1 issued)", 17: "pass0 stored", 18: "pass1 LDS written", 19: "pass1 stored",
+             20: "pass2 LDS written", 21: "pass2 stored", 22: "pass3 LDS written", 23: "pass3 stored", 6: "loop end", 3: "all stores acknowledged"}
     prev = full[:, 2]
-    for slot in (8, 9, 10, 11, 12, 13, 6):
+    for slot in (8, 16, 17, 18, 19, 20, 21, 22, 23, 6, 3):
         if (full[:, slot] != 0).all():
             dlt = (full[:, slot] - prev) / 100.0
-            print(f"   epilogue +{names[slot]:20s} mean {dlt.mean():6.2f}  p50 {np.percentile(dlt,50):6.2f}  p90 {np.percentile(dlt,90):6.2f} us")
+            print(f"   epilogue +{names[slot]:32s} mean {dlt.mean():6.2f}  p50 {np.percentile(dlt,50):6.2f}  p90 {np.percentile(dlt,90):6.2f} us")
             prev = full[:, slot]
 cyc = (s[:, 5] - s[:, 4]).astype(np.float64)
 print("main-loop shader cycles: mean %.0f ; implied clock %.3f GHz" % (cyc.mean(), (cyc / (main * 1e3)).mean()))
@@ -67,11 +69,12 @@ for lo, hi in ((0.0, 0.1), (0.3, 0.4), (0.6, 0.7), (0.85, 0.95)):
 starts = np.sort(st[:, 0])
 print("start-time quantiles:", np.percentile(starts, [0, 5, 6.3, 12.5, 25, 50, 75, 100]).round(1))
 
-steps = full[:, 8:]
-nst = int((steps[0] != 0).sum())
-d = np.diff(steps[:, :nst].astype(np.float64), axis=1)
-print("per-step shader cycles (median over workgroups):", np.median(d, axis=0).round(0).astype(int).tolist())
-print("last step -> main end:", np.median(full[:, 5] - steps[:, nst - 1]))
+if os.environ.get("STEPS") == "1":        # (-DVS_SPLIT_PERTURB builds: per-step ticks of the main loop in slots 8..)
+    steps = full[:, 8:]
+    nst = int((steps[0] != 0).sum())
+    d = np.diff(steps[:, :nst].astype(np.float64), axis=1)
+    print("per-step shader cycles (median over workgroups):", np.median(d, axis=0).round(0).astype(int).tolist())
+    print("last step -> main end:", np.median(full[:, 5] - steps[:, nst - 1]))
 
 # which workgroups share a CU in the first dispatch round?
 first = np.where(st[:, 0] < 5.0)[0]

@@ -41,7 +41,13 @@ template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 __global__ void __launch_bounds__(256, 2) conv_split_kernel(const ConvParams p) {
     constexpr bool XB = false;
 #define VS_EPILOGUE_INC "conv_epilogue.inc"
+#ifdef VS_EPI_OLD_BIAS_ROW             // (debug builds: the round-3 epilogue that loads a row's bias inside the row loop -- the A/B of conv_split_body.inc's note)
+#define VS_EPI_BIAS_IN_LOOP 1
+#else
+#define VS_EPI_BIAS_IN_LOOP 0
+#endif
 #include "conv_split_body.inc"
+#undef VS_EPI_BIAS_IN_LOOP
 #undef VS_EPILOGUE_INC
 }
 
@@ -51,7 +57,9 @@ template <int MT_W, int NT_W, int WAVES_M, int WAVES_N, int TERMS>
 __global__ void __launch_bounds__(256, 2) conv_split_tr_kernel(const ConvParams p) {
     constexpr bool XB = false;
 #define VS_EPILOGUE_INC "conv_epilogue_tr.inc"
+#define VS_EPI_BIAS_IN_LOOP 1      // (the vector epilogue behind the polyphase stores is the rare path here: no bias register held for it)
 #include "conv_split_body.inc"
+#undef VS_EPI_BIAS_IN_LOOP
 #undef VS_EPILOGUE_INC
 }
 
