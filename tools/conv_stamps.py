@@ -8,9 +8,13 @@ from visinger_amd import _lib as L
 from visinger_amd.ops import ConvOp
 
 C, k, d, T, B = int(os.environ.get("C", 128)), int(os.environ.get("K", 3)), int(os.environ.get("D", 1)), int(os.environ.get("T", 65536)), int(os.environ.get("B", 32))
+if os.environ.get("MATH"):
+    L.set_option("VS_CONV_MATH", int(os.environ["MATH"]))
 op = ConvOp(L.CONV1D, C, C, k, d, (k * d - d) // 2)
 op.set_weights(torch.randn(C, C, k, device="cuda") * 0.05, None, torch.randn(C, device="cuda"))
 x = torch.randn(B, C, T, device="cuda"); y = torch.empty_like(x); res = torch.randn_like(x)
+if os.environ.get("DT") == "bf16":      # bf16-resident tensors (MATH=1): conv_split_kernel_bf16io
+    x, y, res = x.bfloat16(), y.bfloat16(), res.bfloat16()
 use_res = os.environ.get("RES", "1") == "1"
 for _ in range(2):
     op.forward(x, y=y, res=res if use_res else None, in_act=L.IN_LRELU)
