@@ -208,7 +208,10 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         load_a(a0, pc, pt); advance();
         __syncthreads();
         auto step = [&](u32x4 (&acur)[PLANES], u32x4 (&apre)[PLANES]) __attribute__((always_inline)) {
-            if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
+            // (UNCONDITIONAL, on a clamped chunk index: behind `if (s + 1 < nsteps)` hipcc's wait in front of this step's first MFMA was vmcnt(0) -- the
+            //  scoreboard merge of the two paths -- which also waited for the fragments requested on the line above: one exposed L2 round trip per
+            //  step pair in every conv of every fused block.  Round 4, found in the ISA; the last step's extra load is never used.)
+            load_a(apre, min(pc, p.nchunks - 1), pt); advance();
             mma_step(acur, Tb + ((chunk * 2 + lh) * WT + MP + wn * (NT_W * 32) + l5 + tap * d - pad) * 4);
             if (++tap == KT) { tap = 0; ++chunk; }
             ++s;

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     int chunk = 0, tap = 0, s = 0;
     auto step1 = [&](u32x4 (&acur)[NPL], u32x4 (&apre)[NPL]) __attribute__((always_inline)) {
         const unsigned *cur = (chunk & 1) ? lbuf1 : lbuf0;
-        if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
+        load_a(apre, min(pc, p.nchunks - 1), pt); advance();      // (unconditional, clamped: see resblock_f16.hip -- behind a branch hipcc waits vmcnt(0) for it)
         if (tap == 0) {
             if (chunk + 1 < p.nchunks) stage_store((chunk & 1) ? lbuf0 : lbuf1);
             if (chunk + 2 < p.nchunks) stage_load(chunk + 2);
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256, 2) respair_split_kernel(const PairSplitPa
     pc = 0; pt = 0; chunk = 0; tap = 0; s = 0;
     load_a(a0, pc, pt); advance();
     auto step2 = [&](u32x4 (&acur)[NPL], u32x4 (&apre)[NPL]) __attribute__((always_inline)) {
-        if (s + 1 < nsteps) { load_a(apre, pc, pt); advance(); }
+        load_a(apre, min(pc, p.nchunks - 1), pt); advance();      // (unconditional, clamped: see resblock_f16.hip -- behind a branch hipcc waits vmcnt(0) for it)
         mma_step(acur, Tb + ((chunk * 2 + lhalf) * WT + wn * (NT_W * 32) + l31 + tap) * 4, TPL);
         if (++tap == KT) { tap = 0; ++chunk; }
         ++s;
