@@ -155,26 +155,31 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    for (int u = blockIdx.z; u < p.units; u += gridDim.z) {
+    // A unit's global loads -- the gy tile (CO_T rows x 16 float4; T_out % 4 == 0, rows 16-byte aligned: host-checked) and the x tile (32 rows x 68
+    // position pairs) -- are ALL unconditional on clamped addresses (what lies outside is zeroed when the registers go to LDS) and are issued for unit
+    // u + 1 right behind the barrier that publishes unit u's tiles, so that they fly under unit u's MFMAs.  (Round 4, found in the ISA: each of the
+    // predicated float4 loads of the gy tile had its own `s_waitcnt vmcnt(0)` -- four to eight SERIAL round trips per unit in front of the x loads'
+    // one, none of them overlapped with matrix work: 5-15 us of latency per unit against ~2 us of MFMAs.)
+    constexpr int GIT = 8 / TS;
+    constexpr int XPAIRS = 32 * (WS_XW / 2), XIT = (XPAIRS + 255) / 256;
+    float4 gv[GIT];
+    float xv[XIT][2];
+    auto load_g = [&](int u, int i0, int i1) __attribute__((always_inline)) {
         const int b = u / p.units_per_item;
         const int t0 = (u - b * p.units_per_item) * WS_TU;
         const float *gyb = p.gy + (long long)b * p.Cout * p.Tout;
-        const float *xb = p.x + (long long)b * p.Cin * p.Tin;
-        __syncthreads();                               // previous unit's fragments are consumed
-        // gy tile: CO_T rows x 16 float4 (T_out % 4 == 0, rows 16-byte aligned: host-checked)
 #pragma unroll
-        for (int i = 0; i < 8 / TS; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const int e = tid + 256 * i;
             const int row = e >> 4, c4 = (e & 15) * 4;
-            const int co = co0 + row, t = t0 + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (co < p.Cout && t < p.Tout) v = *reinterpret_cast<const float4 *>(gyb + (long long)co * p.Tout + t);
-            *reinterpret_cast<float4 *>(Gs + row * WS_GP + c4) = v;
+            const int co = min(co0 + row, p.Cout - 1), t = min(t0 + c4, p.Tout - 4);
+            gv[i] = *reinterpret_cast<const float4 *>(gyb + (long long)co * p.Tout + t);
         }
-        // x tile: 32 rows x 68 position pairs, split exactly into three bf16 planes (one dword per pair and plane); all loads of a
-        // thread are issued before the first split (a rolled loop waited for each pair's loads in turn: 9 exposed round trips per unit)
-        constexpr int XPAIRS = 32 * (WS_XW / 2), XIT = (XPAIRS + 255) / 256;
-        float xv[XIT][2];
+    };
+    auto load_x = [&](int u) __attribute__((always_inline)) {
+        const int b = u / p.units_per_item;
+        const int t0 = (u - b * p.units_per_item) * WS_TU;
+        const float *xb = p.x + (long long)b * p.Cin * p.Tin;
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             const int e = min(tid + 256 * i, XPAIRS - 1);
@@ -184,6 +189,31 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
             xv[i][0] = xr[min(max(n, 0), p.Tin - 1)];
             xv[i][1] = xr[min(max(n + 1, 0), p.Tin - 1)];
         }
+    };
+    auto load_unit = [&](int u) __attribute__((always_inline)) { load_g(u, 0, GIT); load_x(u); };
+    // (the prefetch registers -- 32 + 18 at TS = 1 -- fit next to at most 4 (TS = 1) / 5 (TS = 2) accumulator tiles; the other instances issue the unit's
+    //  loads together at the top of the unit: one exposed round trip instead of five to nine; seven tiles: the gy tile in two halves, then the x tile -- three)
+    constexpr bool PRE = (TS == 1) ? (KT <= 4) : (KT <= 5);
+    constexpr bool TWO = (TS == 1 && KT >= 7);
+    if constexpr (PRE) { if ((int)blockIdx.z < p.units) load_unit(blockIdx.z); }
+    for (int u = blockIdx.z; u < p.units; u += gridDim.z) {
+        const int b = u / p.units_per_item;
+        const int t0 = (u - b * p.units_per_item) * WS_TU;
+        if constexpr (!PRE) { if constexpr (TWO) load_g(u, 0, GIT / 2); else load_unit(u); }
+        __syncthreads();                               // previous unit's fragments are consumed
+        auto store_g = [&](int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                const int e = tid + 256 * i;
+                const int row = e >> 4, c4 = (e & 15) * 4;
+                const bool ok = (co0 + row < p.Cout) && (t0 + c4 < p.Tout);
+                *reinterpret_cast<float4 *>(Gs + row * WS_GP + c4) = ok ? gv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if constexpr (TWO) { store_g(0, GIT / 2); load_g(u, GIT / 2, GIT); store_g(GIT / 2, GIT); }
+        else store_g(0, GIT);
+        // x tile: split exactly into three bf16 planes (one dword per pair and plane)
+        if constexpr (TWO) load_x(u);
 #pragma unroll
         for (int i = 0; i < XIT; ++i) {
             const int e = tid + 256 * i;
@@ -200,6 +230,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
             }
         }
         __syncthreads();
+        if constexpr (PRE) { if (u + (int)gridDim.z < p.units) load_unit(u + gridDim.z); }
         const float *ga = Gs + (cot * 32 + l31) * WS_GP + 8 * lhalf;
 #pragma unroll
         for (int ks = 0; ks < WS_TU / 16; ++ks) {
