@@ -248,6 +248,26 @@ def test_wgrad_split_kernel_matches_aten(Cin, Cout, K, d, T, B):
     assert e_got[0] <= 3e-6 * scale + 2.5 * e_got[1], (e_got, scale)        # fp32 class: within the library's own error of the fp64 result
 
 
+@pytest.mark.parametrize("B,C,T", [(16, 192, 512), (32, 32, 8192), (3, 7, 260), (2, 5, 1001), (1, 1, 12), (16, 1536, 1), (5, 64, 4)])
+def test_bias_grad_and_single_position_wgrad(B, C, T):
+    """vs_bias_grad (gb[c] = sum over (b, t) of gy: one launch, fixed order) against an fp64 sum -- float4 path with full and ragged batches of
+    eight loads, the scalar path for T % 4 != 0 -- run-to-run bit-identical; and the T = 1 weight gradient (a library GEMM: ops.conv_wgrad)."""
+    from visinger_amd.ops import bias_grad, conv_wgrad
+    torch.manual_seed(B * 1000 + C + T)
+    gy = torch.randn(B, C, T, device="cuda")
+    got = bias_grad(gy)
+    ref = gy.double().sum((0, 2))
+    assert got.shape == (C,)
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * (1.0 + float(gy.abs().double().sum((0, 2)).max()) * 0.05)
+    assert torch.equal(got, bias_grad(gy))
+    if T == 1:
+        x = torch.randn(B, 24, 1, device="cuda")
+        gw = conv_wgrad(gy, x, 1, 1, 0)
+        want = torch.einsum("bot,bit->oi", gy.double(), x.double()).unsqueeze(2)
+        assert gw.shape == (C, 24, 1)
+        assert float((gw.double() - want).abs().max()) <= 1e-5 * (1.0 + float(want.abs().max()))
+
+
 def _attn_core_torch(q, k, v, rel_k, rel_v, mask, nh, w, keep=None):
     """rel_transformer.py:148-179 + 181-243 with plain torch ops on [B, nh, T, T] (fp64): the definition the streaming kernels are
     checked against.  keep: dropout factor per (b, h, query, key) (0 or 1 / (1 - p)), or None."""

@@ -409,6 +409,11 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
         # split-bf16 weight-gradient kernel (csrc/conv_backward.hip conv_wgrad_split_kernel<1, 1>) like every other tap count
         PROFILER.note("wgrad 1x1 (library GEMM)", 2.0 * B * Cout * Cin * Tout)
         return torch.einsum("bot,bit->oi", gy, x).unsqueeze(2)
+    if Tout == 1 and Tin == 1 and k == 1 and pad == 0:
+        # a conv over ONE position (the speaker / conditioning projections of a training step): gw = gy^T x, a [Cout x B] . [B x Cin] product with nothing
+        # to tile along t -- vs_conv_wgrad's fp32 fallback spent 100-400 us per call on it (tools/wgrad_breakdown.py, round 4); the fp32 library GEMM
+        PROFILER.note("wgrad T = 1 (library GEMM)", 2.0 * B * Cout * Cin)
+        return (gy[:, :, 0].t() @ x[:, :, 0]).unsqueeze(2)
     if gy.data_ptr() % 16:       # (an offset view that is contiguous: the split kernel loads float4 rows of gy)
         gy = gy.clone()
     planes = lib.vs_conv_wgrad_planes(B, Cout, Cin, Tout, int(k))
