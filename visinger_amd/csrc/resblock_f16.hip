@@ -198,22 +198,30 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         const int pad = d * (KT - 1) / 2;
         const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (PLANES * 64) + lane_c;
         u32x4 a0[PLANES], a1[PLANES];
-        auto load_a = [&](u32x4 (&dst)[PLANES], int chunk, int tap) __attribute__((always_inline)) {
-            const u32x4 *src = wbase + ((long long)tap * p.nchunks + chunk) * (PLANES * 64);
+        // (fragment and tile positions as RUNNING offsets -- one scalar add per step each where (tap * nchunks + chunk) * (PLANES * 64) was a 64-bit multiply
+        //  and the tile address a v_mul_lo: the scalar stream of a step is what it costs next to its 4-12 MFMAs)
+        const int a_dtap = p.nchunks * (PLANES * 64), a_dwrap = (PLANES * 64) - (KT - 1) * a_dtap;
+        const int a_last = ((KT - 1) * p.nchunks + (p.nchunks - 1)) * (PLANES * 64);
+        int aoff = 0;
+        auto load_a = [&](u32x4 (&dst)[PLANES]) __attribute__((always_inline)) {
+            const u32x4 *src = wbase + min(aoff, a_last);          // (clamped: the last step's extra request, never used, stays inside this conv's fragments)
 #pragma unroll
             for (int pl = 0; pl < PLANES; ++pl) dst[pl] = src[pl * 64];
         };
-        int pc = 0, pt = 0, chunk = 0, tap = 0, s = 0;
-        auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; ++pc; } };
-        load_a(a0, pc, pt); advance();
+        int pt = 0, tap = 0, s = 0;
+        auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; aoff += a_dwrap; } else aoff += a_dtap; };
+        load_a(a0); advance();
         __syncthreads();
+        const unsigned *const xlane = Tb + (lh * WT + MP + wn * (NT_W * 32) + l5 - pad) * 4;
+        const int x_dtap = d * 4, x_dwrap = 2 * WT * 4 - (KT - 1) * d * 4;
+        int xoff = 0;
         auto step = [&](u32x4 (&acur)[PLANES], u32x4 (&apre)[PLANES]) __attribute__((always_inline)) {
-            // (UNCONDITIONAL, on a clamped chunk index: behind `if (s + 1 < nsteps)` hipcc's wait in front of this step's first MFMA was vmcnt(0) -- the
-            //  scoreboard merge of the two paths -- which also waited for the fragments requested on the line above: one exposed L2 round trip per
-            //  step pair in every conv of every fused block.  Round 4, found in the ISA; the last step's extra load is never used.)
-            load_a(apre, min(pc, p.nchunks - 1), pt); advance();
-            mma_step(acur, Tb + ((chunk * 2 + lh) * WT + MP + wn * (NT_W * 32) + l5 + tap * d - pad) * 4);
-            if (++tap == KT) { tap = 0; ++chunk; }
+            // (UNCONDITIONAL: behind `if (s + 1 < nsteps)` hipcc's wait in front of this step's first MFMA was vmcnt(0) -- the scoreboard merge of the two
+            //  paths -- which also waited for the fragments requested on the line above: one exposed L2 round trip per step pair in every conv of
+            //  every fused block.  Round 4, found in the ISA.)
+            load_a(apre); advance();
+            mma_step(acur, xlane + xoff);
+            if (++tap == KT) { tap = 0; xoff += x_dwrap; } else xoff += x_dtap;
             ++s;
         };
         while (s < nsteps) {
