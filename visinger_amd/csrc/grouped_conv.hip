@@ -80,14 +80,22 @@ __global__ void __launch_bounds__(256) gconv_bwd_data_kernel(const GConvParams p
     const int g = c / p.cig, ci = c - g * p.cig;
     const float *gyb = p.gy + ((long long)b * p.Cout + (long long)g * p.cog) * p.Tout;
     const int tp = t + p.pad;
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // (four output channels at a time on four accumulators: eight loads in flight where one fmaf chain had two)
     for (int k = tp % p.stride; k < p.K; k += p.stride) {      // taps with (t + p - k) divisible by the stride
         const int n = (tp - k) / p.stride;
         if (tp - k < 0 || n >= p.Tout) continue;
         const float *wk = p.w + ((long long)g * p.cog * p.cig + ci) * p.K + k;
-        for (int co = 0; co < p.cog; ++co) acc = fmaf(wk[(long long)co * p.cig * p.K], gyb[(long long)co * p.Tout + n], acc);
+        const long long ws = (long long)p.cig * p.K;
+        int co = 0;
+        for (; co + 3 < p.cog; co += 4) {
+            const float w0 = wk[(co + 0) * ws], w1 = wk[(co + 1) * ws], w2 = wk[(co + 2) * ws], w3 = wk[(co + 3) * ws];
+            const float g0 = gyb[(long long)(co + 0) * p.Tout + n], g1 = gyb[(long long)(co + 1) * p.Tout + n];
+            const float g2 = gyb[(long long)(co + 2) * p.Tout + n], g3 = gyb[(long long)(co + 3) * p.Tout + n];
+            a0 = fmaf(w0, g0, a0); a1 = fmaf(w1, g1, a1); a2 = fmaf(w2, g2, a2); a3 = fmaf(w3, g3, a3);
+        }
+        for (; co < p.cog; ++co) a0 = fmaf(wk[co * ws], gyb[(long long)co * p.Tout + n], a0);
     }
-    p.gx[e] = acc;
+    p.gx[e] = (a0 + a1) + (a2 + a3);
 }
 
 // one workgroup per (co, batch item): thread j < cig*K owns gw[co, ci, k]; gy[b, co, n] is a broadcast, the x reads of a
