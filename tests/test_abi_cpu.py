@@ -240,3 +240,28 @@ def test_dispatch_switches_are_read_once_and_set_through_the_abi():
     for path in glob.glob(os.path.join(ROOT, "visinger_amd", "**", "*.py"), recursive=True):
         if not path.endswith(("_lib.py", os.path.join("csrc", "build.py"))):
             assert "os.environ" not in open(path).read(), path
+
+
+def test_isa_lint_finds_full_waits_inside_loops(tmp_path):
+    """tools/isa_lint.py: the scan behind DESIGN.md 4.4 -- `s_waitcnt vmcnt(0)` counts per kernel, only inside blocks hipcc marks as loop bodies."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    asm = tmp_path / "k.s"
+    asm.write_text("\n".join([
+        "_Z6kernelv:                             ; @_Z6kernelv",
+        "\ts_waitcnt vmcnt(0)",                                        # straight-line code: not reported
+        ".LBB0_1:                                ; =>This Inner Loop Header: Depth=1",
+        "\tglobal_load_dword v1, v[2:3], off",
+        "\ts_waitcnt vmcnt(0)",
+        "\ts_waitcnt vmcnt(2) lgkmcnt(0)",
+        ".LBB0_2:                                ;   in Loop: Header=BB0_1 Depth=1",
+        "\ts_waitcnt vmcnt(0) lgkmcnt(1)",
+        ".LBB0_3:",
+        "\ts_waitcnt vmcnt(0)",
+        "_Z5otherv:",
+        ".LBB1_1:                                ;   in Loop: Header=BB1_1 Depth=1",
+        "\ts_waitcnt lgkmcnt(0)",
+    ]) + "\n")
+    assert mod.scan(str(asm)) == {"_Z6kernelv": [5, 8]}
