@@ -88,11 +88,17 @@ class VISingerTrainer(nn.Module):
 
     def configure(self):
         h = self.hp
+        # torch's FUSED AdamW where every parameter lives on the GPU (the same update rule, step counters on the device): the default (foreach)
+        # implementation keeps one CPU step counter per parameter -- ~860 `.item()` / `add_` host round trips and ~470 small launches per optimizer
+        # step (tools/train_launch_count.py, round 4).  VS_NO_FUSED_ADAMW=1: the A/B switch.
+        from ._lib import switch
+        fused = (not switch("VS_NO_FUSED_ADAMW")) and all(p.is_cuda for p in self.parameters())
+        kw = dict(fused=True) if fused else {}
         self.opt_gen = torch.optim.AdamW(self.model.parameters(), lr=h["lr"], betas=(h["optimizer_adam_beta1"], h["optimizer_adam_beta2"]),
-                                         weight_decay=h["weight_decay"], eps=h["eps"])
+                                         weight_decay=h["weight_decay"], eps=h["eps"], **kw)
         self.opt_disc = torch.optim.AdamW(self.mel_disc.parameters(), lr=h["lr"],
                                           betas=(h["optimizer_adam_beta1"], h["optimizer_adam_beta2"]),
-                                          **h["discriminator_optimizer_params"])
+                                          **h["discriminator_optimizer_params"], **kw)
         self.sched = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=h["scheduler_gamma"]) for o in (self.opt_gen, self.opt_disc)]
         return self
 
