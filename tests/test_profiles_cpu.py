@@ -106,7 +106,7 @@ def test_round3_profile_split_f16_engine_and_whole_resblock_launches(tag):
     y + the halo columns of the tile under the doubled FETCH_SIZE, an upper bound) where the per-pair launches of round 2 moved 2.3 passes
     PER PAIR (three pairs per block)."""
     dom = "conv_split_kernel<1, 8, 4, 1, 3>"
-    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r04_e_")          # the newest committed summary of this workload is the one bench.py cites
+    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r04_f_")          # the newest committed summary of this workload is the one bench.py cites
     line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line_profiled.json")))
     r = line["roofline"]
     assert r["kernel"] == dom and r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 3.0) < 1e-6
@@ -144,7 +144,7 @@ def bench_pmc(kind, name):
     return bench.pmc_traffic(name) if kind == "traffic" else bench.pmc_mfma_executed(name)
 
 
-@pytest.mark.parametrize("tag,ms_max,c5_max,c3_max", [("r04_c", 82.0, 64.0, 115.0), ("r04_d", 78.0, 61.5, 109.0), ("r04_e", 77.0, 60.5, 108.0)])
+@pytest.mark.parametrize("tag,ms_max,c5_max,c3_max", [("r04_c", 82.0, 64.0, 115.0), ("r04_d", 78.0, 61.5, 109.0), ("r04_e", 77.0, 60.5, 108.0), ("r04_f", 77.0, 60.5, 105.0)])
 def test_round4_profiles_parse_and_agree(tag, ms_max, c5_max, c3_max):
     """profiles/r04_c_* (middle of round 4) and r04_d_* / r04_e_* (its end; `tools/profile_round.sh <tag>`, `<tag>_config5 --config 5`, `<tag>_config3 --config 3`): the driver-visible
     stdout is small and ends with the headline line; rocprofv3's average launch of the dominant instance equals the
@@ -179,6 +179,6 @@ def test_round4_profiles_parse_and_agree(tag, ms_max, c5_max, c3_max):
     t5 = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_config5_pmc_traffic.json")))["kernels"]
     assert "relattn_dma_kernel<8>" in t5 and t5["relattn_dma_kernel<8>"]["hbm_bytes_per_launch_corrected"] < 0.5e9
     assert bench.pmc_traffic("conv_split_kernel_bf16io<1, 8, 4, 1, 1, 3>", bench.HEADLINE_WORKLOAD) is None
-    assert "r04_e_config5" in bench.pmc_traffic("conv_split_kernel_bf16io<1, 8, 4, 1, 1, 3>", "B8_T4096_h512_hop256_bf16")["source"]
+    assert "r04_f_config5" in bench.pmc_traffic("conv_split_kernel_bf16io<1, 8, 4, 1, 1, 3>", "B8_T4096_h512_hop256_bf16")["source"]
     k3 = open(os.path.join(ROOT, "profiles", f"{tag}_config3_bench_kernel_stats.csv")).read()
     assert "conv_split_kernel<1, 1, 1, 4, 3>" in k3 and "pack_conv_pair_kernel" in k3 and "bias_grad_kernel" in k3
