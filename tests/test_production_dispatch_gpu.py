@@ -176,10 +176,12 @@ def test_config5_whole_model_bf16_resident_vs_oracle(oracle, capsys):
         assert must in names, (must, sorted(names))            # whole MRF blocks on bf16-resident tensors
     oracle.set_threads(bench.usable_cores())
     voiced_dev = (f0_pred[:, :, 1] <= 0).cpu().numpy()
-    # (the voicing decision is a threshold on a bf16-computed value: every frame takes the device's decision; agreement is asserted
-    #  where the oracle's value is clear of the threshold by more than the arithmetic's error)
+    # (the voicing decision is a threshold on a bf16-computed value: frames whose ORACLE value lies within hint_tol of the threshold -- the size
+    #  of the bf16 arithmetic's error on that value -- take the device's decision; everywhere else the oracle decides by itself, and agreement
+    #  is asserted on the frames clear of the threshold.  Round 5: a finite tolerance, where every frame used to take the device's decision.)
+    hint_tol = 0.05
     ref = oracle.visinger_infer(sd, hp, *[t.numpy() for t in (text, pitch, dur, mel2ph, spk, noise)], return_all=True, dtype=np.float32,
-                                voiced_hint=voiced_dev, hint_tol=np.inf)
+                                voiced_hint=voiced_dev, hint_tol=hint_tol)
     p1 = ref["f0_pred"][:, :, 1]
     clear = np.abs(p1) > 0.1 * float(np.sqrt((p1 ** 2).mean()))
     agree = float((voiced_dev[clear] == (p1 <= 0)[clear]).mean())
@@ -188,7 +190,50 @@ def test_config5_whole_model_bf16_resident_vs_oracle(oracle, capsys):
     ew = err(wav, ref["wav_out"])[1] / rms(ref["wav_out"])
     with capsys.disabled():
         print(f"\n   config 5 whole model (hidden 512, T_mel 4096, bf16 + bf16-resident): f0_pred rms err / rms {ef:.2e}, waveform rms err / "
-              f"signal rms {ew:.2e}, voicing agreement on clear frames {agree:.4f}; instances: " + ", ".join(sorted(names)))
+              f"signal rms {ew:.2e}, voicing agreement on clear frames {agree:.4f}, rms of the voicing value {rms(p1):.3f}, frames within "
+              f"hint_tol {hint_tol} of the threshold {int((np.abs(p1) <= hint_tol).sum())} of {p1.size}; instances: " + ", ".join(sorted(names)))
     assert agree >= 0.99
     assert ef <= 3e-2
     assert ew <= 5e-2
+
+
+def test_config5_rel_encoder_on_the_benched_attention_kernel_vs_oracle(oracle, capsys):
+    """BASELINE configs[4] at a batch where the BENCHED attention dispatch runs: `bench.py --config 5` (B=8) puts the
+    attention core of the hidden-512 prior transformers on relattn_dma_kernel<8> (no key split: B * heads * T / 128 >= 128 workgroups), which
+    the B=1 whole-model test above never reaches (key split -> relattn_bf16_kernel<8, 32, 1>).  Here a RelativeEncoder of that width (2 heads
+    of 256 channels, FFN 2048, k = 9; reference modules/rel_transformer.py:148-179, 290-320) runs B=2 x T=4096 in the plain-bf16 arithmetic,
+    ragged (item 1 ends at frame 3000), the instance is asserted by name, and the output is held against oracle.rel_encoder (fp32 CPU
+    restatement, pinned to the reference's golden rel_encoder_* vectors in tests/test_oracle_golden.py).  Stated bf16 bound: rms error
+    <= 3e-2 of the output rms and worst element <= 0.25 of it (two post-LN layers: outputs are unit-variance per frame)."""
+    from visinger_amd.modules.hipconv import set_conv_math
+    from visinger_amd.modules.rel_transformer import RelativeEncoder
+    torch.manual_seed(5)
+    C, F, nh, nl, ks, B, T = 512, 2048, 2, 2, 9, 2, 4096
+    m = RelativeEncoder(C, F, nh, nl, kernel_size=ks, p_dropout=0.0).eval()
+    sd = sd_numpy(m)
+    x = torch.randn(B, C, T)
+    lens = torch.tensor([T, 3000])
+    mask = (torch.arange(T)[None] < lens[:, None]).float()[:, None]
+    m = m.cuda()
+    set_conv_math(m, L.MATH_BF16)
+    try:
+        y, names = dispatched(lambda: m(x.cuda(), mask.cuda()))
+    finally:
+        set_conv_math(m, None)
+    assert names.get("relattn_dma_kernel<8>") == nl, sorted(names)           # the kernel config 5 is benched on, once per layer
+    assert not any(n.startswith("relattn_bf16_kernel") or n.startswith("relattn_kernel") for n in names), sorted(names)
+    oracle.set_threads(usable())
+    ref = oracle.rel_encoder(sd, x.numpy(), mask.numpy(), None, n_heads=nh, n_layers=nl, kernel_size=ks, dtype=np.float32)
+    emax, erms = err(y, ref)
+    scale = float(np.sqrt((np.asarray(ref, np.float64) ** 2).mean()))
+    with capsys.disabled():
+        print(f"\n   config 5 RelativeEncoder (hidden 512, T 4096, B 2, bf16) on relattn_dma_kernel<8>: rms err / rms {erms / scale:.2e}, "
+              f"max err / rms {emax / scale:.2e}; instances: " + ", ".join(sorted(names)))
+    assert bool(torch.isfinite(y).all())
+    assert float(y[1, :, 3000:].abs().max()) == 0.0                            # padded frames of the ragged item are exactly zero
+    assert erms <= 3e-2 * scale and emax <= 0.25 * scale
+
+
+def usable():
+    from conftest import usable_cores
+    return usable_cores()

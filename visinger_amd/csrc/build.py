@@ -18,8 +18,9 @@ NO_SCRATCH = {"conv_split.hip": "conv_split_kernel", "conv_wsplit.hip": "conv_ws
               # (no hand-counted waits here, but a spill in this kernel is paid once per conv of a fused chain: round 3 found 112 B / lane
               #  = 0.5 GB of scratch stores per launch behind a run-time LDS pitch)
               "resblock_f16.hip": "resblock_",                # resblock_f16_kernel and resblock_bf16_kernel
-              # every vector-memory instruction of its loop is counted by hand (conv_pipe.hip: vm_seq): a scratch access would be one more
-              "conv_pipe.hip": "conv_pipe_kernel"}
+              # (a spill inside the chunk body would sit between MFMAs that leave it no issue slot; ADVICE r4: the LDS-DMA ring of the attention
+              #  kernel counts its vector-memory operations by hand as well)
+              "conv_ktap.hip": "conv_ktap_kernel", "attention_dma.hip": "relattn_dma_kernel"}
 
 
 def check_no_scratch(src, remarks):

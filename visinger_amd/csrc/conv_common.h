@@ -176,10 +176,10 @@ int pack_split_pair(const vs_split_pack &q0, const vs_split_pack &q1, hipStream_
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);   // (p.x_bf16 / p.y_bf16: terms = 1, cfg 0 / 2 / 3 / 6)
 
 
-// conv_pipe.hip: the 128 x 256 tile of the split-f16 x3 arithmetic as a persistent, software-pipelined kernel (epilogue of tile i inside the
-// main loop of tile i + 1); p as for launch_split(cfg 0); ncu = compute units of the device.  Preconditions: pipe_eligible().
-constexpr int PIPE_MIN_CHUNKS = 6;       // at most three of the epilogue's 18 events per 16-channel chunk: C_in >= 96
-int launch_pipe(ConvParams p, int span, int ncu, hipStream_t s);
+// conv_ktap.hip: the 128 x 256 tile of the split-f16 x3 arithmetic with the taps unrolled and the staging of the next chunk in the MFMA shadows
+// (bit-identical to conv_split_kernel<1, 8, 4, 1, 3>); p as for launch_split(cfg 0).  Preconditions: plain stride-1 conv, C_in % 16 == 0, ktap_taps(KT).
+bool ktap_taps(int kt);
+int launch_ktap(const ConvParams &p, hipStream_t s);
 
 // conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)
 bool wsplit_instance(int dil, int G);

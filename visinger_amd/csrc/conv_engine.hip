@@ -46,7 +46,7 @@ static OptEntry g_opts[OPT_COUNT] = {
     {"VS_NO_WINO_K7", 0, 0}, {"VS_WINO_DBG", 0, 0}, {"VS_NO_WSPLIT", 0, 0}, {"VS_WSPLIT_FORCE", 0, 0}, {"VS_WSPLIT_STAGGER", 0, 0},
     {"VS_NO_SMALL_GRID", 0, 0}, {"VS_SMALL_GRID_T6", 512, 512}, {"VS_CONV_CFG", -1, -1}, {"VS_SPLIT_DBG", 0, 0}, {"VS_TRACE", 0, 0},
     {"VS_NO_BF16_ATTN", 0, 0}, {"VS_NO_SPLIT_ATTN", 0, 0}, {"VS_NO_WGRAD_SPLIT", 0, 0}, {"VS_RB_TILE256", 0, 0},
-    {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_PIPE", 0, 0}, {"VS_NO_ATTN_DMA", 0, 0},
+    {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_NO_KTAP", 0, 0}, {"VS_NO_ATTN_DMA", 0, 0},
 };
 static const bool g_opts_loaded = [] {
     for (OptEntry &e : g_opts) {
@@ -1724,24 +1724,13 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     if (h->math) p.wp = h->ws.as<float>();
     if (h->math) p.dbg = (int)opt(OPT_SPLIT_DBG);
     p.wscale = h->wsc.as<float>();
-    // (opt-in: VS_PIPE) the persistent software-pipelined instance of the 128 x 256 tile (conv_pipe.hip): plain stride-1 convs of the split-f16 arithmetic whose
-    // every tile takes the vector epilogue (whole 256-column tiles, whole 128-row blocks, no masks / per-item bias / row split), with enough
-    // (chunk, tap) steps per tile to carry the previous tile's epilogue and at least two tiles per workgroup to pipeline
-    if (h->math == VS_MATH_SPLIT3 && cfg == 0 && h->kind == VS_CONV1D && !p.x_bf16 && !p.y_bf16 && p.fast_epi && !p.split_row && opt(OPT_PIPE) &&
-        (p.N % 256) == 0 && (h->MT % 4) == 0 && p.M == h->MT * 32 && p.in_act < VS_IN_MASK && !p.out[0].out_mask && p.out[0].mode == VS_OUT_LINEAR &&
-        !p.bias_b && h->nchunks >= PIPE_MIN_CHUNKS && p.Cin % CK == 0 && (h->KT == 3 || h->KT == 5 || h->KT == 7 || h->KT == 9 || h->KT == 11)) {
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            VS_CHECK_HIP(hipGetDevice(&dev));
-            VS_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
-        const long long ntiles = (long long)(p.N / 256) * p.B;
-        if (ntiles * (h->MT / 4) >= 2ll * ncu && ncu >= h->MT / 4) {
-            p.row_lo = 0;
-            p.row_hi = h->c_out;
-            return launch_pipe(p, h->span, ncu, s);
-        }
+    // the wide stride-1 convs of the split-f16 arithmetic (generator resblocks at 128 / 256 channels, conv_pre, FFN conv_1): taps unrolled, the staging of
+    // the next chunk dealt out over the MFMA gaps of the current one (conv_ktap.hip; bit-identical to the tile kernel, VS_NO_KTAP=1: A/B)
+    if (h->math == VS_MATH_SPLIT3 && cfg == 0 && h->kind == VS_CONV1D && !p.x_bf16 && !p.y_bf16 && !opt(OPT_NO_KTAP) && ktap_taps(h->KT) &&
+        p.Cin % CK == 0 && !(p.split_row && (p.split_row % 32) != 0)) {
+        p.row_lo = 0;
+        p.row_hi = h->c_out;
+        return launch_ktap(p, s);
     }
     auto launch = [&](const ConvParams &q) -> int {
         if (h->math) return launch_split(q, cfg, h->math, h->span, s);

@@ -40,7 +40,7 @@ enum Opt {
     OPT_RB_TILE256,       // VS_RB_TILE256: whole-resblock launch at 32 channels on 256-column tiles (default 512: half the weight-fragment traffic and halo per output)
     OPT_NO_ATTN_KVPACK,   // VS_NO_ATTN_KVPACK: the plain-bf16 attention kernel converts K / V tiles in place (no pre-packed images)
     OPT_NO_TR_EPI,        // VS_NO_TR_EPI: transposed convs on the generic instances (element-wise polyphase stores)
-    OPT_PIPE,             // VS_PIPE: the wide split-f16 convs on the persistent software-pipelined conv_pipe_kernel (bit-identical to, and so far 5-15 % slower than, conv_split_kernel<1, 8, 4, 1, 3>: off by default)
+    OPT_NO_KTAP,          // VS_NO_KTAP: the wide stride-1 split-f16 convs on the tile kernel conv_split_kernel<1, 8, 4, 1, 3> instead of conv_ktap_kernel (taps unrolled, staging in the MFMA shadows; bit-identical: A/B switch)
     OPT_NO_ATTN_DMA,      // VS_NO_ATTN_DMA: wide-head plain-bf16 attention on relattn_bf16_kernel<.., true> (register-staged tiles) instead of relattn_dma_kernel
     OPT_COUNT
 };
