@@ -405,13 +405,15 @@ def roofline_from_profile(prof, dt, steps, workload=None):
     step_bytes = sum(v["bytes"] for v in allp.values()) / steps
     step_tflops = step_flops / (dt / steps) / 1e12
     kern_ms = sum(v["ms"] for v in prof.values())
-    if name.startswith(("conv_split_kernel", "respair_split_kernel", "resblock_f16_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
+    if name.startswith(("conv_split_kernel", "conv_ktap_kernel", "respair_split_kernel", "resblock_f16_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
         targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
         ints = [int(a) for a in targs if a.isdigit()]
         if name.startswith("conv_split_kernel"):
             terms = ints[4]                                  # cross products per fp32 product (5th template argument)
         elif name.startswith("conv_wsplit_kernel"):
             terms = 6
+        elif name.startswith("conv_ktap_kernel"):
+            terms = 3 if ints[2] == 2 else 1                 # conv_ktap_kernel<taps, input transform, planes, tensors, tile...>: two f16 planes = three cross products
         elif name.startswith("resblock_f16_kernel"):
             terms = 3
         else:

@@ -84,6 +84,19 @@ def test_arguments_are_validated_without_a_gpu():
     assert L.vs_conv_create(ctypes.byref(h), 1, 16, 8, 16, 8, 4, 0) == 0
     assert L.vs_conv_out_len(h, 10) == 80
     L.vs_conv_destroy(h)
+    # vs_conv_set_weights_pair: the second handle must be the VS_CONV_ADJOINT counterpart of the first (a mismatched pair made the
+    # pack read the weight out of bounds) -- rejected before anything is reserved or launched
+    h0, h1, h2 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.vs_conv_create(ctypes.byref(h0), 0, 32, 64, 3, 1, 1, 0) == 0
+    assert L.vs_conv_create(ctypes.byref(h1), 0, 64, 32, 3, 1, 1, 0) == 0            # swapped channels, but not an ADJOINT handle
+    assert L.vs_conv_create(ctypes.byref(h2), 0, 64, 48, 3, 1, 1, 4) == 0            # ADJOINT (flag 4), wrong c_out
+    w = (ctypes.c_float * (64 * 32 * 3))()
+    fp = ctypes.cast(w, ctypes.POINTER(ctypes.c_float))
+    L.vs_conv_set_weights_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
+    assert L.vs_conv_set_weights_pair(h0, h1, fp, None, None) == 1 and b"ADJOINT" in L.vs_last_error()
+    assert L.vs_conv_set_weights_pair(h0, h2, fp, None, None) == 1
+    for hh in (h0, h1, h2):
+        L.vs_conv_destroy(hh)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -56,6 +56,48 @@ def test_strided_shard_and_max_time_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _shard8_worker(rank, world, port, q):
+    """BASELINE configs[3]: 256 utterances over 8 ranks = 8 x 32, the reference's strided shard batch[rank::8] (tasks/base.py:130-133)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visinger_amd.dp import shard_batch, max_over_ranks
+    g = torch.Generator().manual_seed(1234)                  # every rank builds the same global batch (ids, lengths, tokens)
+    ids = torch.arange(256)
+    lens = torch.randint(512, 1025, (256,), generator=g)
+    tokens = torch.randint(4, 64, (256, 128), generator=g)
+    my_ids, my_lens, my_tok = shard_batch([ids, lens, tokens], rank, world)
+    ok = my_ids.shape[0] == 32 and torch.equal(my_ids, torch.arange(rank, 256, world)) and torch.equal(my_tok, tokens[rank::world])
+    got = [torch.empty_like(my_ids) for _ in range(world)]
+    dist.all_gather(got, my_ids)                             # (a test-side gather: the data path itself has no collective)
+    ok = ok and torch.equal(torch.sort(torch.cat(got)).values, ids)            # a partition: every utterance on exactly one rank
+    frames = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(frames, my_lens.sum().view(1))
+    ok = ok and int(torch.stack(frames).sum()) == int(lens.sum())
+    ok = ok and max_over_ranks(10.0 + rank) == 10.0 + world - 1               # the step time is the slowest rank's
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_strided_shard_world8():
+    """B = 256 -> 8 x 32 over gloo, world_size 8 (VERDICT r4 next #9): the partition bench.py --gpus 8 uses, on CPU"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
 def _ddp_worker(rank, world, port, q):
     """Training-path collective (SURVEY.md 8e): the discriminator loss of visinger_amd.train under stock DDP over gloo.
     Each rank sees its strided shard; the all-reduced gradient must equal the single-process gradient on the global

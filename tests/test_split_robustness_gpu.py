@@ -119,3 +119,36 @@ def test_nonfinite_inputs_stay_local_and_nonfinite(oracle):
         bad = ~np.isfinite(y)
         assert (bad == hit[:, None, :]).all(), math                 # non-finite exactly in the receptive fields, for every row
         assert np.abs(y[~bad] - np.broadcast_to(clean, y.shape)[~bad]).max() <= 2e-5, math
+
+
+@pytest.mark.parametrize("C,k,T", [(128, 7, 2048), (64, 3, 4096)])
+def test_outlier_channel_inside_a_chunk_costs_the_small_values_their_low_bits(oracle, vs_option, C, k, T):
+    """ONE channel of a 16-channel chunk carries values ~1e7 (2^23) times its neighbours', and the outputs under test
+    take (almost) nothing from it -- the outlier's weights are zero for the first half of the output rows, so those rows are sums over the
+    SMALL channels only.  The split-f16 arithmetic scales a staged 16-channel tile by ONE power of two that puts the outlier below 2^15:
+    the small values then sit near 2^-8 of the scaled range, where their two f16 planes keep an ABSOLUTE precision of 2^-25 of the scaled
+    unit (f16 subnormal spacing of the low plane) = about 2^-16 .. 2^-17 RELATIVE to the small values themselves.  The S-normalised bounds
+    of the tests above cannot see this (S is dominated by the outlier); here the error is measured relative to the SMALL values' own
+    S_small = sum |x_small| |w|.  Stated behaviour: the split-f16 engine is fp32-class (<= 2^-21) wherever a tile's dynamic range stays
+    below 2^17 and degrades gracefully to <= 2^-14 of S_small at a 2^23 range inside one chunk (measured ~2^-16); the exact-fp32 MFMA engine
+    and the split-bf16 x6 engine (8-bit exponents per plane, no tile scale) keep <= 2^-21 on the same data.  The rows that DO take the
+    outlier stay fp32-class relative to their S."""
+    vs_option("VS_NO_WINO", 1)
+    r = np.random.default_rng(31 * C + k)
+    x = r.standard_normal((2, C, T)).astype(np.float32)
+    out_ch = 5                                                   # inside the first 16-channel chunk
+    x[:, out_ch] *= np.float32(1.0e7)
+    w = (r.standard_normal((C, C, k)) * (C * k) ** -0.5).astype(np.float32)
+    w[: C // 2, out_ch, :] = 0.0                                 # the first half of the rows never sees the outlier channel
+    ref, S, out = run(oracle, x, w, None, k, 1)
+    half = C // 2
+    for math, name, bar in ((L.MATH_F32, "fp32-mfma", 2.0 ** -21), (L.MATH_SPLIT6, "split6", 2.0 ** -21), (L.MATH_SPLIT3, "split3", 2.0 ** -14)):
+        y = out[math][0]
+        e_small = float(np.max(np.abs(y[:, :half] - ref[:, :half]) / S[:, :half]))          # S of these rows = S_small (outlier weights are 0)
+        e_big = float(np.max(np.abs(y[:, half:] - ref[:, half:]) / S[:, half:]))
+        print(f"outlier channel C={C} k={k}: {name:9s} rows without the outlier max|err|/S_small {e_small:.3e} (2^{np.log2(max(e_small, 1e-30)):.1f}); "
+              f"rows with it max|err|/S {e_big:.3e}")
+        assert e_small <= bar, (name, e_small)
+        assert e_big <= 2.0 ** -21, (name, e_big)
+    # and the loss is what the arithmetic's description says, not more: the small values keep at least 14 bits next to a 2^23 outlier
+    assert float(np.max(np.abs(out[L.MATH_SPLIT3][0][:, :half] - ref[:, :half]) / S[:, :half])) > 2.0 ** -24      # (it IS visible: this test can see it)

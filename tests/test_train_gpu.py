@@ -432,7 +432,7 @@ def test_training_step_packs_each_weight_version_once(vs_option):
 def test_config3_training_step_at_full_size(vs_option):
     """BASELINE config 3 at ITS OWN size (B = 16, T_mel = 512, segment 32, hop 256, the reference-width generator and
     MPD / MSD, dropout 0): the gradients of every parameter of both passes from the HIP path against PyTorch-ROCm autograd of the SAME module
-    graph with stock aten ops in place of every HIP kernel (autograd.aten_reference: F.conv1d / F.conv_transpose1d, torch gate / LayerNorm /
+    graph with stock aten ops in place of every HIP kernel (tests/aten_backend.py: F.conv1d / F.conv_transpose1d, torch gate / LayerNorm /
     [T, T] attention).  At this size the dispatch takes other instances than at the fixture size of test_gradients_match_reference_autograd
     (which pins the graph itself to the reference's autograd): they are asserted by name.  The mel transform stays on the engine in both runs
     (parity unpinned: SURVEY 8c).  Tolerance: 2e-3 of each gradient's largest magnitude."""
@@ -456,7 +456,12 @@ def test_config3_training_step_at_full_size(vs_option):
             post.bias.copy_(0.05 * torch.randn(post.bias.shape, generator=g))
 
     def grads(aten):
-        vs_option("VS_TRAIN_ATEN", 1 if aten else 0)
+        import contextlib
+        from aten_backend import aten_backend
+        with (aten_backend() if aten else contextlib.nullcontext()):
+            return grads_(aten)
+
+    def grads_(aten):
         out = {}
         for opt_idx in (0, 1):
             tr.zero_grad(set_to_none=True)
@@ -477,7 +482,6 @@ def test_config3_training_step_at_full_size(vs_option):
     hip = grads(False)
     instances = set(PROFILER.counts())
     ref = grads(True)
-    vs_option("VS_TRAIN_ATEN", 0)
     # the instances this size dispatches to (the fixture-size test never reaches the first three)
     for name in ("conv_split_kernel<1, 1, 1, 4, 3>", "conv_split_kernel<1, 4, 2, 2, 3>", "conv_wgrad (vs_conv_wgrad)", "relattn_train_bwd"):
         assert any(k.startswith(name) for k in instances), (name, sorted(instances))

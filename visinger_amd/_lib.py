@@ -139,7 +139,7 @@ def lib():
 # (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
 PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
                for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
-                            "VS_WGRAD_GEMM", "VS_TRAIN_ATEN", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE", "VS_NO_FUSED_ADAMW")}
+                            "VS_WGRAD_GEMM", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE", "VS_NO_FUSED_ADAMW")}
 
 
 def switch(name):

@@ -207,6 +207,7 @@ class StridedConv1dFn(torch.autograd.Function):
         yF = op.forward(XF)                                                                     # [1, Cout, N*Hq]
         ctx.save_for_backward(XF, w)
         ctx.cfg = (N, C, T, K, stride, pad, Q, Hq, Tout, b is not None, holder)
+        ctx.wkey = key          # (the saved `w` is THIS version: the grad-input handle is labelled with it, as HipConvFn does -- ADVICE r4)
         return yF.view(Cout, N, Hq)[:, :, :Tout].permute(1, 0, 2)
 
     @staticmethod
@@ -222,7 +223,7 @@ class StridedConv1dFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             op = _cached_op(holder, ("dxa", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, L.CONV_ADJOINT)
-            key = param_key(holder)
+            key = ctx.wkey      # (not param_key(holder) now: parameters stepped between forward and backward would label the OLD weight with the new key)
             if not op.has_weights_of(key):      # (the handle packs the adjoint of the phase-stacked forward weight)
                 op.set_weights_from(_phase_weights(w.detach(), stride, Q) if stride > 1 else w, None, key)
             gXF = op.forward(gyF)                                                               # [1, s*C, N*Hq + Q - 1]
@@ -265,8 +266,6 @@ class GroupedConv1dFn(torch.autograd.Function):
 
 def disc_conv1d(holder, x, w, b, stride, pad, groups=1):
     """conv1d of the discriminators: dense -> MFMA engine, grouped -> VALU kernels; differentiable in x, w, b"""
-    if aten_reference():
-        return F.conv1d(x.float(), w, b, stride=stride, padding=pad, groups=groups)
     if groups == 1:
         return StridedConv1dFn.apply(x, w, b, stride, pad, holder)
     return GroupedConv1dFn.apply(x, w, b, stride, pad, groups)
@@ -279,21 +278,8 @@ def effective_weight(m):
     return m.weight
 
 
-def aten_reference():
-    """TEST-ONLY switch (VS_TRAIN_ATEN, set through _lib.set_option by tests/test_train_gpu.py): every conv, gate, LayerNorm and attention
-    core of the training path as stock PyTorch-ROCm ops -- the SAME module graph with aten kernels in place of the HIP kernels, so that
-    torch autograd gives a reference gradient for every parameter at sizes where the reference itself cannot run on the GPU box.
-    Never set by the product path, the trainer or bench.py."""
-    return bool(L.switch("VS_TRAIN_ATEN"))
-
-
 def conv(m, x):
     """differentiable conv through HipConv1d / HipConvTranspose1d `m`"""
-    if aten_reference():
-        w = effective_weight(m)
-        if m._kind == L.CONV_TRANSPOSE1D:
-            return F.conv_transpose1d(x, w, m.bias, stride=m.stride[0], padding=m.padding[0])
-        return F.conv1d(x, w, m.bias, padding=m.padding[0], dilation=m.dilation[0])
     return HipConvFn.apply(x, effective_weight(m), m.bias, m)
 
 
@@ -374,7 +360,7 @@ def wavenet(m, x, x_mask, g=None):
         g = conv(m.cond_layer, g)
     # (the gate kernel reads the conditioning as ONE column per item, g[b, c, 0]: a time-varying [B, gin, T] condition -- which the
     # reference's WN broadcasts as well -- or a non-fp32 one takes the PyTorch formulation)
-    fused = (x.is_cuda and not L.switch("VS_NO_TRAIN_FUSED") and not aten_reference() and (m.p_dropout == 0 or not m.training) and
+    fused = (x.is_cuda and not L.switch("VS_NO_TRAIN_FUSED") and (m.p_dropout == 0 or not m.training) and
              (g is None or (g.shape[2] == 1 and g.dtype == torch.float32)))
     for i in range(m.n_layers):
         x_in = conv(m.in_layers[i], x)
@@ -470,7 +456,7 @@ def generator(m, x, g=None):
 
 def layer_norm(m, x, r=None):
     """rel_transformer.py:33-42 on x (+ r: the residual add of the encoder layers folded in)"""
-    if x.is_cuda and x.dim() == 3 and x.shape[1] <= 1024 and not L.switch("VS_NO_TRAIN_FUSED") and not aten_reference():
+    if x.is_cuda and x.dim() == 3 and x.shape[1] <= 1024 and not L.switch("VS_NO_TRAIN_FUSED"):
         return LayerNormFn.apply(x, r, m.gamma, m.beta, m.eps)
     if r is not None:
         x = x + r
@@ -581,7 +567,7 @@ def attention(m, x, frame_mask):
     relative terms laid onto the band through strided views (what the reference's pad / reshape skew implements)."""
     B, C, T = x.shape
     nh, dk, w = m.n_heads, m.k_channels, m.window_size
-    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not L.switch("VS_NO_TRAIN_ATTN") and not aten_reference():
+    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not L.switch("VS_NO_TRAIN_ATTN"):
         rel_k, rel_v = (m.emb_rel_k, m.emb_rel_v) if w is not None else (None, None)
         pd = m.drop.p if m.training else 0.0
         plain = all(not hasattr(c, "weight_g") and c.bias is not None and c.kernel_size[0] == 1 for c in (m.conv_q, m.conv_k, m.conv_v))

@@ -20,7 +20,7 @@ NO_SCRATCH = {"conv_split.hip": "conv_split_kernel", "conv_wsplit.hip": "conv_ws
               "resblock_f16.hip": "resblock_",                # resblock_f16_kernel and resblock_bf16_kernel
               # (a spill inside the chunk body would sit between MFMAs that leave it no issue slot; ADVICE r4: the LDS-DMA ring of the attention
               #  kernel counts its vector-memory operations by hand as well)
-              "conv_ktap.hip": "conv_ktap_kernel", "attention_dma.hip": "relattn_dma_kernel"}
+              "conv_ktap.hip": "conv_ktap_kernel", "conv_ktap_bf16.hip": "conv_ktap_kernel", "conv_ktap_small.hip": "conv_ktap_kernel", "attention_dma.hip": "relattn_dma_kernel"}
 
 
 def check_no_scratch(src, remarks):

@@ -176,10 +176,13 @@ int pack_split_pair(const vs_split_pack &q0, const vs_split_pack &q1, hipStream_
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);   // (p.x_bf16 / p.y_bf16: terms = 1, cfg 0 / 2 / 3 / 6)
 
 
-// conv_ktap.hip: the 128 x 256 tile of the split-f16 x3 arithmetic with the taps unrolled and the staging of the next chunk in the MFMA shadows
-// (bit-identical to conv_split_kernel<1, 8, 4, 1, 3>); p as for launch_split(cfg 0).  Preconditions: plain stride-1 conv, C_in % 16 == 0, ktap_taps(KT).
-bool ktap_taps(int kt);
-int launch_ktap(const ConvParams &p, hipStream_t s);
+// conv_ktap.hip / conv_ktap_bf16.hip (conv_ktap.inc): the 128 x 256 tile with the taps unrolled and the staging of the next chunk in the MFMA shadows, in the
+// split-f16 x3 arithmetic (terms 3; bit-identical to conv_split_kernel<1, 8, 4, 1, 3>) and in plain bf16 (terms 1; conv_split_kernel<1, 8, 4, 1, 1> and its
+// bf16-resident variants); p as for launch_split(cfg 0).  Preconditions: plain stride-1 conv, C_in % 16 == 0, ktap_instance(terms, KT, io, in_act).
+bool ktap_instance(int terms, int cfg, int kt, int io, int in_act);     // cfg: launch_split's tile shape (0, 1 / 3, 6); io: bit 0 -- x, bit 1 -- y / res / acc hold bf16 elements
+int launch_ktap(const ConvParams &p, int cfg, hipStream_t s);
+int launch_ktap_small(const ConvParams &p, int cfg, hipStream_t s);      // (conv_ktap_small.hip: the 64 x 256 and 32 x 128 tiles of the split-f16 arithmetic)
+int launch_ktap_bf16(const ConvParams &p, int cfg, hipStream_t s);
 
 // conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)
 bool wsplit_instance(int dil, int G);

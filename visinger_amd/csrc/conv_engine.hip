@@ -1453,6 +1453,10 @@ static void fill_pack_params(vs_conv *h, const float *w, const float *bias, Pack
 
 int vs_conv_set_weights_pair(vs_conv_t *h0, vs_conv_t *h1, const float *w, const float *bias0, void *stream) {
     VS_REQUIRE(h0 && h1 && w, "vs_conv_set_weights_pair: NULL handle or weight");
+    // h1 reads the SAME weight tensor as the grad-input conv of h0: anything else would index `w` out of bounds in the pack
+    VS_REQUIRE((h1->flags & VS_CONV_ADJOINT) && !(h0->flags & VS_CONV_ADJOINT) && h1->c_in == h0->c_out && h1->c_out == h0->c_in && h1->k == h0->k &&
+                   (h0->kind == VS_CONV_TRANSPOSE1D || h1->dil == h0->dil),
+               "vs_conv_set_weights_pair: the second handle is not the VS_CONV_ADJOINT counterpart of the first (c_in / c_out swapped, same k and dilation)");
     // the fused form serves the training step's common case; everything else is the two plain calls
     const bool fused = h0->math == VS_MATH_SPLIT3 && h1->math == VS_MATH_SPLIT3 && !(h0->kind == VS_CONV1D && h0->c_out <= 4) &&
                        !(h1->kind == VS_CONV1D && h1->c_out <= 4 && !(h1->flags & VS_CONV_ADJOINT));
@@ -1725,12 +1729,14 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     if (h->math) p.dbg = (int)opt(OPT_SPLIT_DBG);
     p.wscale = h->wsc.as<float>();
     // the wide stride-1 convs of the split-f16 arithmetic (generator resblocks at 128 / 256 channels, conv_pre, FFN conv_1): taps unrolled, the staging of
-    // the next chunk dealt out over the MFMA gaps of the current one (conv_ktap.hip; bit-identical to the tile kernel, VS_NO_KTAP=1: A/B)
-    if (h->math == VS_MATH_SPLIT3 && cfg == 0 && h->kind == VS_CONV1D && !p.x_bf16 && !p.y_bf16 && !opt(OPT_NO_KTAP) && ktap_taps(h->KT) &&
-        p.Cin % CK == 0 && !(p.split_row && (p.split_row % 32) != 0)) {
+    // the next chunk dealt out over the MFMA gaps of the current one (conv_ktap.inc; bit-identical to the tile kernels, VS_NO_KTAP=1: A/B); likewise the
+    // plain-bf16 arithmetic (BASELINE configs[4]: the hidden-512 transformer convs on fp32 tensors, the generator's wide convs on bf16-resident tensors)
+    // ... and the 64 x 256 / 32 x 128 tiles of short launches (T_mel-sized tensors, the training step): conv_ktap_small.hip
+    if ((h->math == VS_MATH_SPLIT3 || h->math == VS_MATH_BF16) && h->kind == VS_CONV1D && !opt(OPT_NO_KTAP) && p.Cin % CK == 0 &&
+        ktap_instance(h->math, cfg, h->KT, (p.x_bf16 ? 1 : 0) | (p.y_bf16 ? 2 : 0), p.in_act) && !(p.split_row && (p.split_row % 32) != 0)) {
         p.row_lo = 0;
         p.row_hi = h->c_out;
-        return launch_ktap(p, s);
+        return h->math == VS_MATH_SPLIT3 ? launch_ktap(p, cfg, s) : launch_ktap_bf16(p, cfg, s);
     }
     auto launch = [&](const ConvParams &q) -> int {
         if (h->math) return launch_split(q, cfg, h->math, h->span, s);

@@ -46,7 +46,18 @@ struct ResblockParams {
     int MP;                              // the largest pad of the chain (the kernel instance's margin is the next of 8 / 16 / 28)
     int fast_epi;
     int bf16;                            // VS_MATH_BF16 on bf16-resident tensors (x, y, acc point at bf16 elements; strides in elements)
+    unsigned long long *stamps;          // debug: per-workgroup phase stamps (vs_debug_set_stamp_buffer; NULL in production), tools/resblock_stamps.py
 };
+
+// [0] start, [1] x loaded, then per conv c: [2 + 4c] input transformed + exponent barrier, [3 + 4c] tile written + barrier, [4 + 4c] MFMA loop done,
+// [5 + 4c] scaled out; [2 + 4 nconv] end.  s_memrealtime (100 MHz) in the slots, the shader clock (s_memtime) at [32 + slot].
+__device__ __forceinline__ void rb_stamp(const ResblockParams &p, int slot) {
+    if (p.stamps && threadIdx.x == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+        p.stamps[(size_t)lin * 64 + slot] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[(size_t)lin * 64 + 32 + slot] = __builtin_amdgcn_s_memtime();
+    }
+}
 
 // MP: margin columns of the tile on each side (>= the largest pad of the chain: 8 / 16 / 28 for k = 3 / 7 / 11).  A template constant: with
 // a run-time pitch the sixteen (column tile, channel group) cell addresses of the tile writes were hoisted out of the conv loop as
@@ -80,6 +91,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
     const int nsteps = p.nchunks * KT;
     auto acc_row = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * lhalf; };
 
+    rb_stamp(p, 0);
     // margins of the tile: zeros, once (the waves only ever write their own BN columns)
     for (int e = tid; e < PLANES * KG * 2 * MP; e += 64 * NW) {
         const int rowi = e / (2 * MP), c = e % (2 * MP);
@@ -112,6 +124,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
             for (int r = 0; r < 16; ++r) xr[j][r] = inside[j] ? xr[j][r] : 0.f;
     }
 
+    rb_stamp(p, 1);
     // one (chunk, tap) step: NT_W column tiles x 3 cross products; the planes of tile j+1 are read under the MFMAs of tile j
     auto mma_step = [&](const u32x4 (&acur)[PLANES], const unsigned *xs) __attribute__((always_inline)) {
         u32x4 bf[PLANES], bn[PLANES];
@@ -170,6 +183,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         } else {
             __syncthreads();
         }
+        rb_stamp(p, 2 + 4 * c);
         // ---- split and write the tile
 #pragma unroll
         for (int j = 0; j < NT_W; ++j) {
@@ -212,6 +226,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         auto advance = [&]() __attribute__((always_inline)) { if (++pt == KT) { pt = 0; aoff += a_dwrap; } else aoff += a_dtap; };
         load_a(a0); advance();
         __syncthreads();
+        rb_stamp(p, 3 + 4 * c);
         const unsigned *const xlane = Tb + (lh * WT + MP + wn * (NT_W * 32) + l5 - pad) * 4;
         const int x_dtap = d * 4, x_dwrap = 2 * WT * 4 - (KT - 1) * d * 4;
         int xoff = 0;
@@ -228,6 +243,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
             step(a0, a1);
             if (s < nsteps) step(a1, a0);
         }
+        rb_stamp(p, 4 + 4 * c);
         // ---- scale out, bias in; the second conv of a pair adds the residual stream
         const float inv = (PLANES == 2) ? f16_inv_scale(eb) * p.wscale[c][1] : 1.f;
         const float *const bias = p.bias[c] + wm * 32;
@@ -241,6 +257,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
                 else acc[j][r] = v;
             }
         }
+        rb_stamp(p, 5 + 4 * c);
     }
     __syncthreads();                         // the tile is consumed: its space becomes the epilogue's
 
@@ -310,6 +327,10 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
             }
         }
     }
+    if (p.stamps) {
+        __builtin_amdgcn_s_waitcnt(0);
+        rb_stamp(p, 2 + 4 * p.nconv);
+    }
 }
 
 template <int NT_W, int WAVES_M, int WAVES_N, int MP>
@@ -365,6 +386,8 @@ static int launch_resblock_cfg(const ResblockParams &p, hipStream_t s) {
 }  // namespace vs
 
 using namespace vs;
+
+extern unsigned long long *g_stamp_buf;   // conv_engine.hip (vs_debug_set_stamp_buffer)
 
 extern "C" {
 
@@ -423,6 +446,7 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
     p.y_bs = o.y_bs ? o.y_bs : dflt; p.acc_bs = o.acc_bs ? o.acc_bs : dflt;
     p.scale = (o.scale == 0.f) ? 1.f : o.scale;
     p.B = (int)io->B; p.C = C; p.T = (int)io->T; p.K = c0->k; p.nconv = nconv; p.nchunks = c0->nchunks;
+    p.stamps = g_stamp_buf;
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     auto al8 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 7u) == 0; };
     p.fast_epi = (io->T % 4 == 0) && (p.y_bs % 4 == 0) && (!p.acc || p.acc_bs % 4 == 0) &&
