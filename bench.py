@@ -144,6 +144,33 @@ def cpu_baseline(model, hp, batch, backend="c", wav_dev=None, f0_dev=None, T_cap
     return res
 
 
+def oracle_check_config5(model, hp, batch, f0_dev):
+    """BASELINE configs[4]: an oracle error figure in the config-5 line.  The whole item at T_mel = 4096 / hidden 512 costs the CPU port
+    minutes (the generator); the bounded piece is the text encoder + positional table + pitch predictor of ITEM 0 of the timed batch -- six encoder layers at
+    T_ph and six at T_mel = 4096 with 2 x 256-channel heads, i.e. the benched attention / FFN dispatch -- against the device's f0_pred of the same item
+    (reference: models/visinger.py:71-90, 122-135; modules/rel_transformer.py:148-179, 290-345).  rms relative error; the stated bf16 bound is 3e-2."""
+    from oracle import visinger_oracle as orc
+    orc.build()
+    orc.set_threads(usable_cores())
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    text, pitch, dur, mel2ph, spk, noise = [t[:1].cpu().numpy() for t in batch]
+    H = hp["hidden_size"]
+    dt_ = np.float32
+    t0 = time.perf_counter()
+    kw = dict(n_heads=hp["num_heads"], kernel_size=hp["ffn_kernel_size"], dtype=dt_)
+    nonpad = (np.asarray(mel2ph) > 0).astype(dt_)[:, None, :]
+    prior = orc.text_encoder(orc._sub(sd, "text_encoder"), text, pitch, dur, mel2ph, hidden_channels=H, n_layers=hp["enc_layers"], **kw) * nonpad
+    pos = orc.sinusoidal_positional_embedding(prior.transpose(0, 2, 1)[..., 0], H, 0, init_size=2000).astype(dt_)
+    prior = prior + pos.transpose(0, 2, 1)
+    spk_e = orc._c(sd["spk_id_proj.weight"], dt_)[spk][:, :, None]
+    _, f0_ref, _ = orc.forward_pitch(sd, hp, prior, nonpad, spk_e, dtype=dt_)
+    sec = time.perf_counter() - t0
+    d = f0_dev[:1].double().cpu().numpy() - f0_ref
+    rms = float(np.sqrt((np.asarray(f0_ref, np.float64) ** 2).mean()))
+    return {"f0_pred_rms_rel_err": float(np.sqrt((d ** 2).mean())) / rms, "f0_pred_max_abs_err": float(np.abs(d).max()), "f0_pred_rms": rms, "tolerance_rms_rel": 3e-2,
+            "seconds": sec, "what": "item 0 of the timed batch: text encoder + pitch predictor (T_mel 4096, hidden 512) on the fp32 CPU oracle vs the device's f0_pred"}
+
+
 def cpu_baseline_config2(model, hp, batch, items=2):
     """BASELINE.md 4 asks for the config-2 shape next to the GPU number: flow inverse + HiFi-GAN decode at T_mel=512, a bounded sample of
     `items` of the 8 utterances, on the fp32 C/OpenMP port."""
@@ -200,7 +227,7 @@ def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
     return res
 
 
-PROFILE_TAGS = ("r04_f", "r04_e", "r04_d", "r04_c", "r04_b", "r04_a", "r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e",
+PROFILE_TAGS = ("r05_c", "r05_b", "r05_a", "r04_f", "r04_e", "r04_d", "r04_c", "r04_b", "r04_a", "r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e",
                 "r01_c")      # newest first: profiles/<tag>[_<suffix>]_pmc_*.json
 HEADLINE_WORKLOAD = "B32_T1024_h192_hop256_f32"      # what a profiles/*_pmc_*.json without a "workload" field was recorded on (rounds 1-3)
 
@@ -236,6 +263,16 @@ def pmc_traffic(kernel, workload=HEADLINE_WORKLOAD):
         if _norm(kernel) in ks:
             return {"bytes_per_launch": ks[_norm(kernel)]["hbm_bytes_per_launch_corrected"],
                     "source": f"recorded: {path} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"}
+    return None
+
+
+def pmc_step_traffic(workload):
+    """HBM bytes per STEP over every kernel of the recorded PMC passes of `workload` (whole-step lines: BASELINE config 3)"""
+    for path, d in _pmc_files("traffic", workload):
+        t = d.get("pass_total") or {}
+        if t.get("hbm_bytes_corrected_per_step"):
+            return {"bytes_per_step": t["hbm_bytes_corrected_per_step"],
+                    "source": f"recorded: {path} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over every kernel of the pass / its {t['steps_in_pass']} steps)"}
     return None
 
 
@@ -524,6 +561,8 @@ def compact_line(full, math=None, details=None):
     for k in ("fp32_mfma_engine", "split_bf16x6_engine"):
         if k in full:
             out[k] = _pick(full[k], ("value", "ms_per_step", "max_abs_waveform_diff_vs_value_run"))
+    if "oracle_check" in full:
+        out["oracle_check"] = _pick(full["oracle_check"], ("f0_pred_rms_rel_err", "f0_pred_max_abs_err", "tolerance_rms_rel", "seconds"))
     if "cpu_baseline_torch" in full:
         out["cpu_baseline_torch"] = _pick(full["cpu_baseline_torch"], ("value", "cores", "items", "seconds"))
     if "losses_last_step" in full:
@@ -646,6 +685,8 @@ def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
             "ms_per_step": dt / steps * 1e3, "ms_per_step_stats": percentile_stats(per_step), "dtype": wl.dtype_name(), "data": "synthetic",
             "config": dict(wl.describe(), realtime_factor=samples / dt / SR, what=preset["what"]),
             "roofline": roofline_from_profile(PROFILER.summary(), dt, steps, wl.workload_key())}
+    if config == 5 and with_cpu and out.get("f0_pred") is not None:
+        line["oracle_check"] = oracle_check_config5(wl.model, wl.hp, wl.batch, out["f0_pred"])
     if config == 2 and with_cpu:
         line["cpu_baseline"], wav_cpu = cpu_baseline_config2(wl.model, wl.hp, wl.c2_inputs)
         line["cpu_baseline"]["waveform_max_abs_err"] = float(np.abs(wav[:wav_cpu.shape[0]].double().cpu().numpy() - wav_cpu).max())
@@ -812,6 +853,8 @@ def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barri
                    "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)"},
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": step_tflops, "peak": peak, "frac": step_tflops / peak,
                      "frac_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": (pmc_step_traffic(workload_key(3, B, T, 192, 256, "f32")) or {}).get("bytes_per_step"),
+                     "traffic_source": (pmc_step_traffic(workload_key(3, B, T, 192, 256, "f32")) or {}).get("source"),
                      "step": {"algorithmic_tflop_per_step": step_flops / 1e12,
                               "by_kind_tflop": {k: v["flops"] / 1e12 for k, v in sorted(counts.items(), key=lambda kv: -kv[1]["flops"])[:12]},
                               "launches_counted": sum(v["launches"] for v in counts.values())},

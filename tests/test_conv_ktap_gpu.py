@@ -61,7 +61,7 @@ def test_ktap_kernel_is_bit_identical_to_the_tile_kernel(case, vs_option):
     y_ref, k_ref = _run(op, x, res, acc, scale, ia, out_act, mask, out_mask, bias_b)
     vs_option("VS_NO_KTAP", 0)
     y_new, k_new = _run(op, x, res, acc, scale, ia, out_act, mask, out_mask, bias_b)
-    assert k_ref == "conv_split_kernel<1, 8, 4, 1, 3>" and k_new == "conv_ktap_kernel<%d, %d, 2, 0, 4, 1, 8>" % (k, in_act), (k_ref, k_new)
+    assert k_ref == "conv_split_kernel<1, 8, 4, 1, 3>" and k_new == "conv_ktap_kernel<%d, %d, 2, 0, 4, 1, 8, 1>" % (k, in_act), (k_ref, k_new)
     assert torch.equal(y_new, y_ref), float((y_new - y_ref).abs().max())
     y2, _ = _run(op, x, res, acc, scale, ia, out_act, mask, out_mask, bias_b)                # and run-to-run
     assert torch.equal(y2, y_new)
@@ -143,7 +143,7 @@ def test_ktap_bf16_instances_are_bit_identical_to_the_tile_kernels(case, vs_opti
     y_new, k_new = run()
     io = (1 if xb else 0) | (2 if yb else 0)
     assert k_ref == ("conv_split_kernel_bf16io<1, 8, 4, 1, 1, %d>" % io if io else "conv_split_kernel<1, 8, 4, 1, 1>"), k_ref
-    assert k_new == "conv_ktap_kernel<%d, %d, 1, %d, 4, 1, 8>" % (k, in_act, io), k_new
+    assert k_new == "conv_ktap_kernel<%d, %d, 1, %d, 4, 1, 8, 1>" % (k, in_act, io), k_new
     if in_act < 2:
         assert torch.equal(y_new, y_ref), float((y_new.float() - y_ref.float()).abs().max())
     else:           # item 0's mask is all ones: masking it is the identity
@@ -229,9 +229,10 @@ def test_ktap_small_tiles_are_bit_identical_to_the_tile_kernels(case, vs_option)
     y_ref, k_ref = run()
     vs_option("VS_NO_KTAP", 0)
     y_new, k_new = run()
-    tile = {"conv_split_kernel<1, 4, 2, 2, %d>" % (3 if s3 else 1): "2, 2, 4", "conv_split_kernel<1, 1, 1, 4, %d>" % (3 if s3 else 1): "1, 4, 1"}
+    tile = {"conv_split_kernel<1, 4, 2, 2, %d>" % (3 if s3 else 1): "2, 2, 4", "conv_split_kernel<1, 2, 1, 4, %d>" % (3 if s3 else 1): "1, 4, 2",
+            "conv_split_kernel<1, 1, 1, 4, %d>" % (3 if s3 else 1): "1, 4, 1"}
     assert k_ref in tile, k_ref
-    assert k_new == "conv_ktap_kernel<%d, %d, %d, 0, %s>" % (k, in_act, 2 if s3 else 1, tile[k_ref]), (k_ref, k_new)
+    assert k_new == "conv_ktap_kernel<%d, %d, %d, 0, %s, 1>" % (k, in_act, 2 if s3 else 1, tile[k_ref]), (k_ref, k_new)
     if s3 or in_act < 2:       # (plain bf16 with a masked input: the tile kernel races -- tests/test_conv_mask_race_gpu.py)
         assert torch.equal(y_new, y_ref), float((y_new - y_ref).abs().max())
     y2, _ = run()
@@ -251,6 +252,56 @@ def test_ktap_small_tiles_are_bit_identical_to_the_tile_kernels(case, vs_option)
     assert float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) <= (2e-6 if s3 else 1e-2), float(err.abs().max())
 
 
+@pytest.mark.parametrize("math,H,gin,B,T,mode", [(3, 192, 256, 32, 1024, "gate"), (3, 192, 0, 3, 700, "gate"), (1, 512, 256, 8, 4096, "gate"), (3, 96, 0, 4, 1024, "coupling_inv")])
+def test_ktap_paired_instances_are_bit_identical_to_the_tile_kernel(math, H, gin, B, T, mode, vs_option):
+    """VS_CONV1D_PAIRED (csrc/conv_ktap_pair.hip): the WaveNet's k = 5 in_layers with the gate in the epilogue (reference modules/visinger/encoder.py:158-161, 206-213:
+    tanh(a + g_a) * sigmoid(b + g_b) over the row pair (c, H + c), the conditioning as a per-item bias) -- and the coupling update of the flow's `post` conv shape
+    (flow.py:66-85) -- against conv_split_kernel<2, 2, 2, 2, T>, bit for bit, and against fp64"""
+    from visinger_amd import _lib as L
+    from visinger_amd.ops import ConvOp
+    vs_option("VS_CONV_MATH", math)
+    g = torch.Generator(device="cuda").manual_seed(4000 + H + T)
+    op = ConvOp(L.CONV1D_PAIRED, H, 2 * H, 5, 1, 2)
+    w = torch.randn(2 * H, H, 5, device="cuda", generator=g) * (H * 5) ** -0.5
+    bias = torch.randn(2 * H, device="cuda", generator=g) * 0.1
+    op.set_weights(w, None, bias)
+    x = torch.randn(B, H, T, device="cuda", generator=g)
+    x[:, : H // 2] *= torch.exp2(torch.randint(-5, 6, (B, H // 2, 1), device="cuda", generator=g).float())
+    bias_b = torch.randn(B, 2 * H, device="cuda", generator=g) if gin else None
+    lens = torch.randint(T // 2, T + 1, (B,), device="cuda", generator=g)
+    lens[0] = T
+    mask = (torch.arange(T, device="cuda")[None] < lens[:, None]).float()
+    x1 = torch.randn(B, H, T, device="cuda", generator=g) if mode != "gate" else None
+
+    def run():
+        if mode == "gate":
+            y = op.forward(x, bias_b=bias_b, pair_mode=L.PAIR_GATE)
+        else:
+            y = op.forward(x, res=x1, mask=mask, pair_mode=L.PAIR_COUPLING_INV)
+        return y, op.kernel_instance()
+
+    vs_option("VS_NO_KTAP", 1)
+    y_ref, k_ref = run()
+    vs_option("VS_NO_KTAP", 0)
+    y_new, k_new = run()
+    assert k_ref == "conv_split_kernel<2, 2, 2, 2, %d>" % math, k_ref
+    assert k_new == "conv_ktap_kernel<5, 0, %d, 0, 2, 2, 2, 2>" % (2 if math == 3 else 1), k_new
+    assert torch.equal(y_new, y_ref), float((y_new - y_ref).abs().max())
+    y2, _ = run()
+    assert torch.equal(y2, y_new)
+    z = torch.nn.functional.conv1d(x[:1].double(), w.double(), bias.double(), padding=2)
+    if bias_b is not None:
+        z = z + bias_b[:1, :, None].double()
+    a, b_ = z[:, :H], z[:, H:]
+    if mode == "gate":
+        ref = torch.tanh(a) * torch.sigmoid(b_)
+    else:
+        m = mask[:1, None].double()
+        ref = (x1[:1].double() - a * m) * torch.exp(-b_ * m) * m
+    err = y_new[:1].double() - ref
+    assert float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()) <= (3e-6 if math == 3 else 1e-2), float(err.abs().max())
+
+
 def test_ktap_kernel_dispatch_and_fallbacks(vs_option):
     """taken for plain stride-1 convs of 3 / 7 / 11 taps on whole 16-channel chunks; everything else stays on the tile kernel"""
     from visinger_amd import _lib as L
@@ -264,8 +315,8 @@ def test_ktap_kernel_dispatch_and_fallbacks(vs_option):
         op.forward(torch.randn(B, cin, T, device="cuda"))
         return op.kernel_instance()
 
-    assert inst(128, 128, 7) == "conv_ktap_kernel<7, 0, 2, 0, 4, 1, 8>"
-    assert inst(128, 128, 9) == "conv_ktap_kernel<9, 0, 2, 0, 4, 1, 8>"
+    assert inst(128, 128, 7) == "conv_ktap_kernel<7, 0, 2, 0, 4, 1, 8, 1>"
+    assert inst(128, 128, 9) == "conv_ktap_kernel<9, 0, 2, 0, 4, 1, 8, 1>"
     assert inst(128, 128, 5) == "conv_split_kernel<1, 8, 4, 1, 3>"              # no instance for 5 taps
     assert inst(120, 128, 7) == "conv_split_kernel<1, 8, 4, 1, 3>"              # C_in not a multiple of 16
     vs_option("VS_NO_KTAP", 1)

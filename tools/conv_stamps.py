@@ -10,21 +10,23 @@ from visinger_amd.ops import ConvOp
 C, k, d, T, B = int(os.environ.get("C", 128)), int(os.environ.get("K", 3)), int(os.environ.get("D", 1)), int(os.environ.get("T", 65536)), int(os.environ.get("B", 32))
 if os.environ.get("MATH"):
     L.set_option("VS_CONV_MATH", int(os.environ["MATH"]))
-op = ConvOp(L.CONV1D, C, C, k, d, (k * d - d) // 2)
-op.set_weights(torch.randn(C, C, k, device="cuda") * 0.05, None, torch.randn(C, device="cuda"))
-x = torch.randn(B, C, T, device="cuda"); y = torch.empty_like(x); res = torch.randn_like(x)
+CO = int(os.environ.get("CO", C))                       # output channels (default: C -> C)
+ACT = {"none": L.IN_NONE, "lrelu": L.IN_LRELU}[os.environ.get("ACT", "lrelu")]
+op = ConvOp(L.CONV1D, C, CO, k, d, (k * d - d) // 2)
+op.set_weights(torch.randn(CO, C, k, device="cuda") * 0.05, None, torch.randn(CO, device="cuda"))
+x = torch.randn(B, C, T, device="cuda"); y = torch.empty(B, CO, T, device="cuda"); res = torch.randn_like(y)
 if os.environ.get("DT") == "bf16":      # bf16-resident tensors (MATH=1): conv_split_kernel_bf16io
     x, y, res = x.bfloat16(), y.bfloat16(), res.bfloat16()
 use_res = os.environ.get("RES", "1") == "1"
 for _ in range(2):
-    op.forward(x, y=y, res=res if use_res else None, in_act=L.IN_LRELU)
+    op.forward(x, y=y, res=res if use_res else None, in_act=ACT)
 nblk = 65536
 buf = torch.zeros(nblk * 64, dtype=torch.int64, device="cuda")
 lib = L.lib()
 lib.vs_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 lib.vs_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
 torch.cuda.synchronize()
-op.forward(x, y=y, res=res if use_res else None, in_act=L.IN_LRELU)
+op.forward(x, y=y, res=res if use_res else None, in_act=ACT)
 torch.cuda.synchronize()
 lib.vs_debug_set_stamp_buffer(None)
 full = buf.cpu().numpy().reshape(-1, 64)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 PMC passes into the files bench.py / profiles/README.md cite.
 
-    python tools/pmc_summarize.py <fetch_pass_dir> <write_pass_dir> <out_prefix> [workload_key]
+    python tools/pmc_summarize.py <fetch_pass_dir> <write_pass_dir> <out_prefix> [workload_key [steps_in_pass]]
 
 Each pass directory holds the `*_counter_collection.csv` of ONE `--pmc` counter (FETCH_SIZE or WRITE_SIZE: separate passes,
 as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Counter values are in KB.  Writes <out_prefix>_pmc_fetch_by_shape.csv,
@@ -69,6 +69,14 @@ def main():
                              "hbm_bytes_per_launch_corrected": 2 * fr + wr}
     if workload:
         out["workload"] = workload
+    # the whole pass, EVERY kernel (the PyTorch-ROCm elementwise / reduction / library kernels of a training step included): what a whole-step bench line
+    # (BASELINE config 3: no single dominant kernel) cites as its HBM traffic per step
+    steps_in_pass = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    tot_f = sum(tot for (_, _), (n, tot) in fetch.items()) * 1024.0
+    tot_w = sum(tot for (_, _), (n, tot) in write.items()) * 1024.0
+    out["pass_total"] = {"fetch_size_raw_bytes": tot_f, "write_size_bytes": tot_w, "hbm_bytes_corrected": 2 * tot_f + tot_w,
+                         "launches_fetch_pass": sum(n for (_, _), (n, tot) in fetch.items()), "steps_in_pass": steps_in_pass,
+                         "hbm_bytes_corrected_per_step": (2 * tot_f + tot_w) / steps_in_pass if steps_in_pass else None}
     with open(f"{prefix}_pmc_traffic.json", "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1) for k, v in out["kernels"].items()}, indent=1))

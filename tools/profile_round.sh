@@ -26,7 +26,9 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_bench_kernel_stats.csv
 tail -n 1 $OUT/bench_line_profiled.json > $OUT/summary/${TAG}_bench_line_profiled.json
 F=$(dirname $(find $OUT/fetch -name "*counter_collection.csv" | head -1)); W=$(dirname $(find $OUT/write -name "*counter_collection.csv" | head -1)); M=$(dirname $(find $OUT/mfma -name "*counter_collection.csv" | head -1))
-python3 tools/pmc_summarize.py $F $W $OUT/summary/$TAG $KEY > $OUT/pmc_traffic.txt 2>&1
+# steps the PMC passes ran (--warmup 1 --steps 1; the training configuration counts its launches on one more step)
+NSTEPS=2; case " $* " in *" --config 3 "*) NSTEPS=3;; esac
+python3 tools/pmc_summarize.py $F $W $OUT/summary/$TAG $KEY $NSTEPS > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma_summarize.py $M $OUT/summary/$TAG $KEY > $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma      # raw traces stay on the box (gpurun_out/ merges back <= 64 MiB)
 ls -la $OUT/summary; head -12 $OUT/summary/${TAG}_bench_kernel_stats.csv | cut -c1-150

@@ -20,7 +20,7 @@ NO_SCRATCH = {"conv_split.hip": "conv_split_kernel", "conv_wsplit.hip": "conv_ws
               "resblock_f16.hip": "resblock_",                # resblock_f16_kernel and resblock_bf16_kernel
               # (a spill inside the chunk body would sit between MFMAs that leave it no issue slot; ADVICE r4: the LDS-DMA ring of the attention
               #  kernel counts its vector-memory operations by hand as well)
-              "conv_ktap.hip": "conv_ktap_kernel", "conv_ktap_bf16.hip": "conv_ktap_kernel", "conv_ktap_small.hip": "conv_ktap_kernel", "attention_dma.hip": "relattn_dma_kernel"}
+              "conv_ktap.hip": "conv_ktap_kernel", "conv_ktap_bf16.hip": "conv_ktap_kernel", "conv_ktap_small.hip": "conv_ktap_kernel", "conv_ktap_pair.hip": "conv_ktap_kernel", "attention_dma.hip": "relattn_dma_kernel"}
 
 
 def check_no_scratch(src, remarks):
@@ -110,6 +110,9 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     stamp = _read_stamp().get("objects", {}) if not force else {}
+    # the hash the library will answer with is taken BEFORE anything is compiled: a source edited while the compilers run (round 5: it happened) then leaves a
+    # library whose hash differs from the tree's -- refused at load, rebuilt by the next call -- instead of a stale object under a fresh-looking stamp
+    digest = source_hash()
     objs, procs, hashes = [], [], {}
     for src in sources():
         obj = src[:-4] + ".o"
@@ -148,7 +151,6 @@ def build(force=False, verbose=True):
             os.remove(STAMP)
         raise failed
     # the source hash the library answers with (vs_source_hash): a generated C file, compiled by the host compiler only
-    digest = source_hash()
     stamp_c = os.path.join(HERE, "build_stamp.gen.c")
     with open(stamp_c, "w") as f:
         f.write('/* generated by build.py */\n__attribute__((visibility("default"))) const char *vs_source_hash(void) { return "%s"; }\n' % digest)

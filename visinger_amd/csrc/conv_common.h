@@ -183,6 +183,8 @@ bool ktap_instance(int terms, int cfg, int kt, int io, int in_act);     // cfg: 
 int launch_ktap(const ConvParams &p, int cfg, hipStream_t s);
 int launch_ktap_small(const ConvParams &p, int cfg, hipStream_t s);      // (conv_ktap_small.hip: the 64 x 256 and 32 x 128 tiles of the split-f16 arithmetic)
 int launch_ktap_bf16(const ConvParams &p, int cfg, hipStream_t s);
+bool ktap_pair_instance(int terms, int kt, int io, int in_act, int mt);      // conv_ktap_pair.hip: VS_CONV1D_PAIRED, the 128 virtual rows x 128 columns tile
+int launch_ktap_pair(const ConvParams &p, int terms, hipStream_t s);
 
 // conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)
 bool wsplit_instance(int dil, int G);

@@ -1626,6 +1626,9 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         if (h->math) {
             p.wp = h->ws.as<float>();
             p.wscale = h->wsc.as<float>();
+            if (!opt(OPT_NO_KTAP) && p.Cin % CK == 0 && ktap_pair_instance(h->math, h->KT, (p.x_bf16 ? 1 : 0) | (p.y_bf16 ? 2 : 0), p.in_act, h->MT))
+                rc = launch_ktap_pair(p, h->math, s);      // (conv_ktap_pair.hip: taps unrolled, staging in the MFMA shadows; bit-identical)
+            else
             rc = launch_split(p, (h->MT >= 4) ? 4 : 5, h->math, h->span, s);
         } else if (h->MT >= 4) {
             p.W = 128 + h->span;
@@ -1725,6 +1728,7 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         if (cfg == 2 && ncol * h->MT < t6 && h->kind != VS_CONV_TRANSPOSE1D) cfg = 6;     // 128-column tiles: twice the workgroups again
     }
     if (opt(OPT_CONV_CFG) >= 0 && h->MT >= 3) cfg = (opt(OPT_CONV_CFG) == 3) ? 3 : (opt(OPT_CONV_CFG) == 1 ? 1 : 0);   // A/B switch
+    if ((opt(OPT_CONV_CFG) == 2 || opt(OPT_CONV_CFG) == 6) && !p.x_bf16 && !p.y_bf16 && h->kind != VS_CONV_TRANSPOSE1D) cfg = (int)opt(OPT_CONV_CFG);   // (tools/ktap_tile_sweep.py)
     if (h->math) p.wp = h->ws.as<float>();
     if (h->math) p.dbg = (int)opt(OPT_SPLIT_DBG);
     p.wscale = h->wsc.as<float>();

@@ -32,7 +32,7 @@ namespace vs {
 //                         64 x 256 and 32 x 128: fp32 tensors, 1 / 9 taps, none / mask.
 bool ktap_instance(int terms, int cfg, int kt, int io, int in_act) {
     const bool plain = (in_act == VS_IN_NONE || in_act == VS_IN_MASK);
-    const bool small = (cfg == 1 || cfg == 3 || cfg == 6);
+    const bool small = (cfg == 1 || cfg == 2 || cfg == 3 || cfg == 6);
     if (!small && cfg != 0) return false;
     if (terms == 3) {
         if (io != 0) return false;
@@ -40,7 +40,7 @@ bool ktap_instance(int terms, int cfg, int kt, int io, int in_act) {
         return kt == 3 || kt == 7 || kt == 11 || (kt == 9 && plain);
     }
     if (terms != 1) return false;
-    if (small) return io == 0 && plain && (kt == 1 || kt == 9);
+    if (small) return cfg != 2 && io == 0 && plain && (kt == 1 || kt == 9);
     if (io == 3) return (kt == 3 || kt == 7 || kt == 11) && !plain;
     if (io != 0) return false;
     return kt == 7 || ((kt == 1 || kt == 9) && plain) || ((kt == 3 || kt == 11) && !plain);

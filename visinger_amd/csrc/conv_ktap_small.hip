@@ -29,13 +29,14 @@ static int launch_ktap_small_tile(const ConvParams &p, hipStream_t s) {
     return VS_EUNSUPPORTED;
 }
 
-// cfg as launch_split's: 1 / 3 -> 64 x 256, 6 -> 32 x 128
+// cfg as launch_split's: 1 / 3 -> 64 x 256, 2 -> 32 x 256, 6 -> 32 x 128
 int launch_ktap_small(const ConvParams &p, int cfg, hipStream_t s) {
     if (!ktap_geometry_ok(p) || p.x_bf16 || p.y_bf16) {
         set_error("launch_ktap_small: not a plain stride-1 conv of whole 16-channel chunks on fp32 tensors");
         return VS_EUNSUPPORTED;
     }
     if (cfg == 6) return launch_ktap_small_tile<1, 4, 1>(p, s);
+    if (cfg == 2) return launch_ktap_small_tile<1, 4, 2>(p, s);
     return launch_ktap_small_tile<2, 2, 4>(p, s);
 }
 
