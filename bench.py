@@ -151,7 +151,10 @@ def oracle_check_config5(model, hp, batch, f0_dev):
     (reference: models/visinger.py:71-90, 122-135; modules/rel_transformer.py:148-179, 290-345).  rms relative error; the stated bf16 bound is 3e-2."""
     from oracle import visinger_oracle as orc
     orc.build()
-    orc.set_threads(usable_cores())
+    cores = usable_cores()
+    orc.set_threads(cores)
+    orc.CONV_BACKEND = "torch"       # the oracle composition with its convolutions (k = 9, 512 <-> 2048 channels: 2 TFLOP) on stock PyTorch CPU kernels: 3-4x the C loops here
+    torch.set_num_threads(min(cores, 32))
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     text, pitch, dur, mel2ph, spk, noise = [t[:1].cpu().numpy() for t in batch]
     H = hp["hidden_size"]
@@ -165,6 +168,7 @@ def oracle_check_config5(model, hp, batch, f0_dev):
     spk_e = orc._c(sd["spk_id_proj.weight"], dt_)[spk][:, :, None]
     _, f0_ref, _ = orc.forward_pitch(sd, hp, prior, nonpad, spk_e, dtype=dt_)
     sec = time.perf_counter() - t0
+    orc.CONV_BACKEND = "c"
     d = f0_dev[:1].double().cpu().numpy() - f0_ref
     rms = float(np.sqrt((np.asarray(f0_ref, np.float64) ** 2).mean()))
     return {"f0_pred_rms_rel_err": float(np.sqrt((d ** 2).mean())) / rms, "f0_pred_max_abs_err": float(np.abs(d).max()), "f0_pred_rms": rms, "tolerance_rms_rel": 3e-2,
@@ -442,13 +446,11 @@ def roofline_from_profile(prof, dt, steps, workload=None):
     step_bytes = sum(v["bytes"] for v in allp.values()) / steps
     step_tflops = step_flops / (dt / steps) / 1e12
     kern_ms = sum(v["ms"] for v in prof.values())
-    if name.startswith(("conv_split_kernel", "conv_ktap_kernel", "respair_split_kernel", "resblock_f16_kernel", "conv_wsplit_kernel", "relattn_bf16_kernel")):
+    if name.startswith(("conv_split_kernel", "conv_ktap_kernel", "respair_split_kernel", "resblock_f16_kernel", "relattn_bf16_kernel")):
         targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
         ints = [int(a) for a in targs if a.isdigit()]
         if name.startswith("conv_split_kernel"):
             terms = ints[4]                                  # cross products per fp32 product (5th template argument)
-        elif name.startswith("conv_wsplit_kernel"):
-            terms = 6
         elif name.startswith("conv_ktap_kernel"):
             terms = 3 if ints[2] == 2 else 1                 # conv_ktap_kernel<taps, input transform, planes, tensors, tile...>: two f16 planes = three cross products
         elif name.startswith("resblock_f16_kernel"):

@@ -240,6 +240,30 @@ def gen_transformer():
         save(tag, **arrs)
 
 
+def gen_transformer_options():
+    """constructor options of modules/rel_transformer.py that VISinger itself never sets: proximal_bias and block_length of
+    MultiHeadAttention (rel_transformer.py:163-170), pre_ln of RelativeEncoder (:284, 301-317), activation='gelu' of FFN (:338-341)"""
+    C, nh, ws, B, T = 16, 2, 4, 2, 23
+    mask = ragged_mask(B, T, [23, 14])
+    attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    x = rnd(40, B, C, T)
+    for tag, kw in (("mha_proximal", dict(proximal_bias=True)), ("mha_block", dict(block_length=5)), ("mha_proximal_block", dict(proximal_bias=True, block_length=3))):
+        mha = randomize(MultiHeadAttention(C, C, nh, window_size=ws, **kw).eval(), 41)
+        save(tag, **sd_np(mha), x=x, attn_mask=attn_mask, mask=mask, y=mha(x, x, attn_mask),
+             cfg=np.array([C, nh, ws, int(bool(kw.get("proximal_bias"))), kw.get("block_length") or -1], dtype=np.int64))
+    ffn = randomize(FFN(C, C, 24, 9, activation="gelu").eval(), 42)
+    save("ffn_gelu", **sd_np(ffn), x=x, mask=mask, y=ffn(x, mask), cfg=np.array([C, C, 24, 9]))
+    for tag, gin in (("rel_encoder_preln", None), ("rel_encoder_preln_g", 8)):
+        enc = randomize(RelativeEncoder(C, 24, nh, 2, kernel_size=5, pre_ln=True, gin_channels=gin).eval(), 43)
+        arrs = dict(sd_np(enc), x=x, mask=mask, cfg=np.array([C, 24, nh, 2, 5, -1 if gin is None else gin]))
+        if gin is None:
+            arrs["y"] = enc(x, mask)
+        else:
+            arrs["g"] = rnd(44, B, gin, 1)
+            arrs["y"] = enc(x, mask, arrs["g"])
+        save(tag, **arrs)
+
+
 def gen_wrappers():
     C, F_, nh, B, T = 16, 24, 2, 2, 21
     mask = ragged_mask(B, T, [21, 13])
@@ -581,6 +605,7 @@ if __name__ == "__main__":
     gen_flow()
     gen_generator()
     gen_transformer()
+    gen_transformer_options()
     gen_wrappers()
     gen_integer()
     gen_discriminators()

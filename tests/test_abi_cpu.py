@@ -229,17 +229,17 @@ def test_dispatch_switches_are_read_once_and_set_through_the_abi():
     import sys
     code = ("import os, sys; sys.path.insert(0, %r)\n"
             "from visinger_amd import _lib as L\n"
-            "a = L.get_option('VS_NO_WSPLIT'), L.get_option('VS_SMALL_GRID_T6'), L.get_option('VS_CONV_MATH'), L.switch('VS_NO_RESPAIR')\n"
-            "os.environ['VS_NO_WSPLIT'] = '0'; os.environ['VS_NO_RESPAIR'] = ''\n"          # too late: read at load / import
-            "b = L.get_option('VS_NO_WSPLIT'), L.switch('VS_NO_RESPAIR')\n"
-            "L.set_option('VS_NO_WSPLIT', 0); L.set_option('VS_NO_RESPAIR', 0)\n"
-            "c = L.get_option('VS_NO_WSPLIT'), L.switch('VS_NO_RESPAIR')\n"
+            "a = L.get_option('VS_NO_KTAP'), L.get_option('VS_SMALL_GRID_T6'), L.get_option('VS_CONV_MATH'), L.switch('VS_NO_RESPAIR')\n"
+            "os.environ['VS_NO_KTAP'] = '0'; os.environ['VS_NO_RESPAIR'] = ''\n"          # too late: read at load / import
+            "b = L.get_option('VS_NO_KTAP'), L.switch('VS_NO_RESPAIR')\n"
+            "L.set_option('VS_NO_KTAP', 0); L.set_option('VS_NO_RESPAIR', 0)\n"
+            "c = L.get_option('VS_NO_KTAP'), L.switch('VS_NO_RESPAIR')\n"
             "with L.options(VS_CONV_MATH=0, VS_NO_TRAIN_ATTN=1):\n"
             "    d = L.get_option('VS_CONV_MATH'), L.switch('VS_NO_TRAIN_ATTN')\n"
             "e = L.get_option('VS_CONV_MATH'), L.switch('VS_NO_TRAIN_ATTN')\n"
             "try:\n    L.set_option('VS_NO_SUCH_SWITCH', 1); f = 'accepted'\nexcept L.VisingerHipError: f = 'refused'\n"
             "print(a, b, c, d, e, f)\n") % ROOT
-    env = dict(os.environ, VS_NO_WSPLIT="1", VS_NO_RESPAIR="1", PYTHONDONTWRITEBYTECODE="1")
+    env = dict(os.environ, VS_NO_KTAP="1", VS_NO_RESPAIR="1", PYTHONDONTWRITEBYTECODE="1")
     env.pop("VS_CONV_MATH", None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

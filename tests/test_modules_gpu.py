@@ -152,6 +152,41 @@ def test_mha(tag):
         close(m(x, x, frame_mask=mask), a["y"])
 
 
+@pytest.mark.parametrize("tag", ["mha_proximal", "mha_block", "mha_proximal_block"])
+def test_mha_options_visinger_never_sets(tag):
+    """proximal_bias / block_length (reference modules/rel_transformer.py:163-170, 245-256) against the reference's golden vectors (round 5: they used to raise)"""
+    from visinger_amd.modules.rel_transformer import MultiHeadAttention
+    w, a = load_golden(tag)
+    C, nh, ws, prox, bl = (int(v) for v in a["cfg"])
+    m = load(MultiHeadAttention(C, C, nh, window_size=ws, proximal_bias=bool(prox), block_length=None if bl < 0 else bl), w)
+    x, mask = cu(a["x"]), cu(a["mask"])
+    with torch.no_grad():
+        close(m(x, x, mask.unsqueeze(2) * mask.unsqueeze(-1)), a["y"])
+        close(m(x, x, frame_mask=mask), a["y"])
+
+
+def test_ffn_gelu():
+    """FFN(activation="gelu"), rel_transformer.py:338-341"""
+    from visinger_amd.modules.rel_transformer import FFN
+    w, a = load_golden("ffn_gelu")
+    cin, cout, fc, ks = (int(v) for v in a["cfg"])
+    m = load(FFN(cin, cout, fc, ks, activation="gelu"), w)
+    with torch.no_grad():
+        close(m(cu(a["x"]), cu(a["mask"])), a["y"])
+
+
+@pytest.mark.parametrize("tag", ["rel_encoder_preln", "rel_encoder_preln_g"])
+def test_rel_encoder_pre_ln(tag):
+    """RelativeEncoder(pre_ln=True), rel_transformer.py:284, 301-317"""
+    from visinger_amd.modules.rel_transformer import RelativeEncoder
+    w, a = load_golden(tag)
+    C, F, nh, nl, ks, gin = (int(v) for v in a["cfg"])
+    m = load(RelativeEncoder(C, F, nh, nl, kernel_size=ks, pre_ln=True, gin_channels=None if gin < 0 else gin), w)
+    with torch.no_grad():
+        y = m(cu(a["x"]), cu(a["mask"]), cu(a["g"]) if "g" in a else None)
+    close(y, a["y"], atol=5e-5)
+
+
 def test_ffn():
     from visinger_amd.modules.rel_transformer import FFN
     w, a = load_golden("ffn")

@@ -149,6 +149,6 @@ def test_outlier_channel_inside_a_chunk_costs_the_small_values_their_low_bits(or
         print(f"outlier channel C={C} k={k}: {name:9s} rows without the outlier max|err|/S_small {e_small:.3e} (2^{np.log2(max(e_small, 1e-30)):.1f}); "
               f"rows with it max|err|/S {e_big:.3e}")
         assert e_small <= bar, (name, e_small)
-        assert e_big <= 2.0 ** -21, (name, e_big)
+        assert e_big <= 4 * 2.0 ** -24 * np.sqrt(C * k) + 2.0 ** -22, (name, e_big)        # (S-normalised, as in test_wide_dynamic_range: every engine is fp32-class there)
     # and the loss is what the arithmetic's description says, not more: the small values keep at least 14 bits next to a 2^23 outlier
     assert float(np.max(np.abs(out[L.MATH_SPLIT3][0][:, :half] - ref[:, :half]) / S[:, :half])) > 2.0 ** -24      # (it IS visible: this test can see it)

@@ -483,7 +483,7 @@ def test_config3_training_step_at_full_size(vs_option):
     instances = set(PROFILER.counts())
     ref = grads(True)
     # the instances this size dispatches to (the fixture-size test never reaches the first three)
-    for name in ("conv_split_kernel<1, 1, 1, 4, 3>", "conv_split_kernel<1, 4, 2, 2, 3>", "conv_wgrad (vs_conv_wgrad)", "relattn_train_bwd"):
+    for name in ("conv_ktap_kernel<5, 0, 2, 0, 1, 4, 1, 1>", "conv_ktap_kernel<9, 0, 2, 0, 2, 2, 4, 1>", "conv_wgrad (vs_conv_wgrad)", "relattn_train_bwd"):
         assert any(k.startswith(name) for k in instances), (name, sorted(instances))
     for opt_idx in (0, 1):
         for k, v in ref[("loss", opt_idx)].items():

@@ -163,7 +163,7 @@ def get_option(name):
 
 
 class options:
-    """with options(VS_NO_WINO=1, VS_WSPLIT_FORCE=1): ...  -- switches set for the block, previous values restored after it"""
+    """with options(VS_NO_WINO=1, VS_NO_KTAP=1): ...  -- switches set for the block, previous values restored after it"""
 
     def __init__(self, **kw):
         self.kw = kw

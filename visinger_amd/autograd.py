@@ -567,7 +567,8 @@ def attention(m, x, frame_mask):
     relative terms laid onto the band through strided views (what the reference's pad / reshape skew implements)."""
     B, C, T = x.shape
     nh, dk, w = m.n_heads, m.k_channels, m.window_size
-    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and not L.switch("VS_NO_TRAIN_ATTN"):
+    plain_core = not getattr(m, "proximal_bias", False) and getattr(m, "block_length", None) is None      # (the streaming kernels carry neither option)
+    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and plain_core and not L.switch("VS_NO_TRAIN_ATTN"):
         rel_k, rel_v = (m.emb_rel_k, m.emb_rel_v) if w is not None else (None, None)
         pd = m.drop.p if m.training else 0.0
         plain = all(not hasattr(c, "weight_g") and c.bias is not None and c.kernel_size[0] == 1 for c in (m.conv_q, m.conv_k, m.conv_v))
@@ -602,9 +603,15 @@ def attention(m, x, frame_mask):
         buf = scores.new_zeros((B, nh, T, T + 2 * w))
         buf.as_strided((B, nh, T, R), (buf.stride(0), buf.stride(1), T + 2 * w + 1, 1)).copy_(qr)
         scores = scores + buf[..., w:w + T]
+    if getattr(m, "proximal_bias", False):              # rel_transformer.py:163-165, 245-256: -log(1 + |i - j|)
+        r = torch.arange(T, dtype=torch.float32, device=x.device)
+        scores = scores - torch.log1p(torch.abs(r[None, :] - r[:, None]))[None, None]
     if frame_mask is not None:
         am = frame_mask.view(B, 1, T, 1) * frame_mask.view(B, 1, 1, T)
         scores = scores.masked_fill(am == 0, -1e4)
+        if getattr(m, "block_length", None) is not None:    # rel_transformer.py:168-170 (only under a mask, as there)
+            bm = torch.ones_like(scores).triu(-m.block_length).tril(m.block_length)
+            scores = scores * bm + -1e4 * (1 - bm)
     p = m.drop(F.softmax(scores, dim=-1))
     out = torch.matmul(p, v)
     if w is not None:
@@ -625,7 +632,7 @@ def ffn(m, x, x_mask):
 
 
 def rel_encoder(m, x, x_mask, g=None):
-    """rel_transformer.py:290-320 (post-LN)"""
+    """rel_transformer.py:290-320: post-LN (VISinger's) and pre-LN (`pre_ln=True`, :301-317: the norm in front of each sub-layer, `last_ln` at the end)"""
     B, C, T = x.shape
     fm = x_mask.reshape(B, T)
     if g is not None:
@@ -634,8 +641,14 @@ def rel_encoder(m, x, x_mask, g=None):
         if g is not None:
             x = x + g
         x = x * x_mask
-        y = m.drop(attention(m.attn_layers[i], x, fm))
-        x = layer_norm(m.norm_layers_1[i], x, y)
-        y = m.drop(ffn(m.ffn_layers[i], x, x_mask))
-        x = layer_norm(m.norm_layers_2[i], x, y)
+        if m.pre_ln:
+            x = x + m.drop(attention(m.attn_layers[i], layer_norm(m.norm_layers_1[i], x), fm))
+            x = x + m.drop(ffn(m.ffn_layers[i], layer_norm(m.norm_layers_2[i], x), x_mask))
+        else:
+            y = m.drop(attention(m.attn_layers[i], x, fm))
+            x = layer_norm(m.norm_layers_1[i], x, y)
+            y = m.drop(ffn(m.ffn_layers[i], x, x_mask))
+            x = layer_norm(m.norm_layers_2[i], x, y)
+    if m.pre_ln:
+        x = layer_norm(m.last_ln, x)
     return x * x_mask

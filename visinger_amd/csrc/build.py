@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvi
 # conv_split_kernel issues its weight-fragment loads as inline asm and waits for them with hand-counted `s_waitcnt vmcnt(n)`:
 # a register spill inside its main loop would be a vector-memory instruction hipcc adds behind the count's back.  The build
 # fails instead of shipping such a kernel.
-NO_SCRATCH = {"conv_split.hip": "conv_split_kernel", "conv_wsplit.hip": "conv_wsplit_kernel",
+NO_SCRATCH = {"conv_split.hip": "conv_split_kernel",
               # (no hand-counted waits here, but a spill in this kernel is paid once per conv of a fused chain: round 3 found 112 B / lane
               #  = 0.5 GB of scratch stores per launch behind a run-time LDS pitch)
               "resblock_f16.hip": "resblock_",                # resblock_f16_kernel and resblock_bf16_kernel

@@ -186,10 +186,4 @@ int launch_ktap_bf16(const ConvParams &p, int cfg, hipStream_t s);
 bool ktap_pair_instance(int terms, int kt, int io, int in_act, int mt);      // conv_ktap_pair.hip: VS_CONV1D_PAIRED, the 128 virtual rows x 128 columns tile
 int launch_ktap_pair(const ConvParams &p, int terms, hipStream_t s);
 
-// conv_wsplit.hip: F(2,3) minimal filtering on the split-bf16 x6 arithmetic (whole 128-row blocks, odd k >= 3, dilation 1 / 3 / 5)
-bool wsplit_instance(int dil, int G);
-size_t wsplit_bytes(int MT_alloc, int nchunks, int G);
-int pack_wsplit(const float *wp, void *ws, int KT, int MT_alloc, int nchunks, int G, hipStream_t s);   // from the fp32 fragments Wp
-int launch_wsplit(const ConvParams &p, int dil, int G, hipStream_t s);
-
 }  // namespace vs

@@ -43,7 +43,7 @@ void set_error(const char *fmt, ...) {
 struct OptEntry { const char *name; long long dflt; long long value; };
 static OptEntry g_opts[OPT_COUNT] = {
     {"VS_CONV_MATH", -1, -1}, {"VS_NO_SMALL_CONV", 0, 0}, {"VS_NO_FAST_EPI", 0, 0}, {"VS_WINO_FORCE", 0, 0}, {"VS_NO_WINO", 0, 0},
-    {"VS_NO_WINO_K7", 0, 0}, {"VS_WINO_DBG", 0, 0}, {"VS_NO_WSPLIT", 0, 0}, {"VS_WSPLIT_FORCE", 0, 0}, {"VS_WSPLIT_STAGGER", 0, 0},
+    {"VS_NO_WINO_K7", 0, 0}, {"VS_WINO_DBG", 0, 0}, 
     {"VS_NO_SMALL_GRID", 0, 0}, {"VS_SMALL_GRID_T6", 512, 512}, {"VS_CONV_CFG", -1, -1}, {"VS_SPLIT_DBG", 0, 0}, {"VS_TRACE", 0, 0},
     {"VS_NO_BF16_ATTN", 0, 0}, {"VS_NO_SPLIT_ATTN", 0, 0}, {"VS_NO_WGRAD_SPLIT", 0, 0}, {"VS_RB_TILE256", 0, 0},
     {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_NO_KTAP", 0, 0}, {"VS_NO_ATTN_DMA", 0, 0},
@@ -1319,9 +1319,6 @@ int vs_conv_create(vs_conv_t **out, int kind, int c_in, int c_out, int k, int di
         h->wino_groups = (int)ceil_div(k, 3);
     h->wino_k7 = h->wino_groups == 3 && k == 7 && (h->MT % 2 == 0) && !opt(OPT_NO_WINO_K7);
     h->wino_k11 = h->wino_groups == 4 && k == 11 && ((h->MT & 1) == 0 || dil == 1) && !opt(OPT_NO_WINO_K7);
-    // F(2,3) on the split engine (conv_wsplit.hip): the same eligibility on whole 128-row blocks, plain channel order
-    h->wsplit = h->wino_groups > 0 && (h->MT % 2) == 0 && (flags & ~VS_CONV_ADJOINT) == 0 && wsplit_instance(dil, h->wino_groups) &&
-                (k >= 9 || opt(OPT_WSPLIT_FORCE));      // (where it pays: see vs_conv_forward)
     // Default arithmetic: the split-f16 x3 engine (two f16 planes under a power-of-two scale per staged tile, three cross products) --
     // measured x1.3 .. x1.45 the rate of the split-bf16 x6 engine on the 128- / 256-channel convs (tools/conv_bench.py) and CLOSER to the
     // fp64 result than it and than the fp32 MFMA on every case of tools/split3_check.py / tools/conv_accuracy.py (half the products summed
@@ -1436,7 +1433,6 @@ int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, const floa
         }
     }
     VS_CHECK_HIP(hipGetLastError());
-    h->wsplit_packed = false;      // (the F(2,3) transform of the split engine is rebuilt from Wp by the first launch that uses it)
     h->weights_set = true;
     return VS_OK;
 }
@@ -1488,7 +1484,6 @@ int vs_conv_set_weights_pair(vs_conv_t *h0, vs_conv_t *h1, const float *w, const
         sp[i].maxbits = reinterpret_cast<const unsigned *>(sp[i].wscale + 2) + (h->pack_gen & 1);
         sp[i].scratch = nullptr;
         h->wino_packed = false;
-        h->wsplit_packed = false;
         h->weights_set = true;
     }
     return pack_split_pair(sp[0], sp[1], s);
@@ -1687,27 +1682,6 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         if (h->dil == 1) return launch_wino_dil<1>(q, h->MT, span_w, spec, s);
         if (h->dil == 3) return launch_wino_dil<3>(q, h->MT, span_w, spec, s);
         return launch_wino_dil<5>(q, h->MT, span_w, spec, s);
-    }
-    // F(2,3) on the split-bf16 x6 arithmetic (conv_wsplit.hip) where it measured faster than the direct split kernel
-    // (tools/wsplit_bench.py, B=32 production shapes): k = 11 (16/22 of the matrix work) x1.06 .. x1.20, FFN k = 9 (12/18) x1.27.
-    // Its three transformed arrays cost 4x the staging work of the direct kernel per 16-channel chunk (tools/wsplit_stamps.py:
-    // 2.0 us of staging against 1.5 us of MFMAs at k = 3, 3.2 against 7.5 at k = 11), so k = 3 (4/6, x0.86 .. x0.98) and k = 7
-    // (12/14 with the zero-padded last group, x0.90 .. x1.02) stay on the direct kernel.  VS_WSPLIT_FORCE=1 / VS_NO_WSPLIT=1: A/B.
-    if (h->math == VS_MATH_SPLIT6 && h->wsplit && !p.split_row && io->out[0].mode == VS_OUT_LINEAR && !opt(OPT_NO_WSPLIT) &&
-        ((ceil_div(p.N, 120) * p.B * (h->MT / 2) >= 512 &&              // (short launches: the small direct tiles)
-          ((h->MT % 4) == 0 || h->dil == 1)) ||                         // (64-row workgroups: x1.12 at dilation 1, a tie at 3 / 5)
-         opt(OPT_WSPLIT_FORCE))) {
-        if (!h->wsplit_packed) {
-            VS_TRY(h->wsw.reserve(wsplit_bytes(h->MT_alloc, h->nchunks, h->wino_groups)));
-            VS_TRY(pack_wsplit(h->wp.as<float>(), h->wsw.p, h->KT, h->MT_alloc, h->nchunks, h->wino_groups, s));
-            h->wsplit_packed = true;
-        }
-        ConvParams q = p;
-        q.wp = h->wsw.as<float>();
-        q.KT = h->wino_groups;
-        q.lo = -h->pad;
-        q.dbg = (int)opt(OPT_WSPLIT_STAGGER);
-        return launch_wsplit(q, h->dil, h->wino_groups, s);
     }
     // tile shape: 128-row blocks unless that would leave a half-empty M block (6 tiles = 192 rows: the q/k/v/o, FFN-out,
     // coupling `pre` and last res/skip convs) AND the launch is short (T_mel-sized): there 64 x 256 blocks waste no MFMA

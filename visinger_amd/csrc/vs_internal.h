@@ -26,9 +26,6 @@ enum Opt {
     OPT_NO_WINO,          // VS_NO_WINO: fp32 engine: never F(2,3)
     OPT_NO_WINO_K7,       // VS_NO_WINO_K7: fp32 engine: no k-specialised F(2,3) instances (read at vs_conv_create)
     OPT_WINO_DBG,         // VS_WINO_DBG: timing-only perturbations of conv_wino_kernel
-    OPT_NO_WSPLIT,        // VS_NO_WSPLIT: split engine: never F(2,3)
-    OPT_WSPLIT_FORCE,     // VS_WSPLIT_FORCE: split engine: F(2,3) on every eligible conv (eligibility is read at vs_conv_create)
-    OPT_WSPLIT_STAGGER,   // VS_WSPLIT_STAGGER: debug: late start of every other dispatch round
     OPT_NO_SMALL_GRID,    // VS_NO_SMALL_GRID: keep the 128-row tile on launches that do not cover the chip
     OPT_SMALL_GRID_T6,    // VS_SMALL_GRID_T6: workgroup count below which 32 x 128 tiles are taken (default 512)
     OPT_CONV_CFG,         // VS_CONV_CFG: force a tile shape of the direct engine (-1 = automatic)
@@ -119,10 +116,7 @@ struct vs_conv {
     vs::DevBuf ws;                             // bf16 / f16 plane fragments of the split engine, when math != 0
     vs::DevBuf wsc;                            // split-f16 arithmetic (math == 3): {s_w, 1 / s_w, max |w| bits of even / odd packs} of the packed planes
     int pack_gen = 0;                          // weight versions packed in that arithmetic (selects the max slot)
-    bool wsplit = false;                       // eligible for conv_wsplit_kernel (F(2,3) on the split-bf16 x6 arithmetic)
-    bool wsplit_packed = false;                // wsw holds the transformed weights of the current version
     vs::DevBuf ldpart;                         // PAIRED coupling forward: per-tile log-det partials (fixed-order reduction, no atomics)
-    vs::DevBuf wsw;                            // Us[m_tile][chunk][group][xi][plane][64][8 bf16] (conv_wsplit.hip)
 };
 
 

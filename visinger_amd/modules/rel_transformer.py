@@ -140,8 +140,6 @@ class MultiHeadAttention(nn.Module):
         m[:, :, :, None] * m[:, :, None, :] from the frame mask m; the streaming kernel takes m itself (`frame_mask`
         [B, T]); a 4-D attn_mask is reduced back to m through its diagonal.  in_mask: multiply x by m while
         staging (fuses RelativeEncoder's `x = x * x_mask`)."""
-        if self.proximal_bias or self.block_length is not None:
-            raise NotImplementedError("proximal_bias / block_length are not used by VISinger and not implemented")
         assert x.shape == c.shape, "Relative attention is only available for self-attention."
         B, C, T = x.shape
         if frame_mask is None and attn_mask is not None:
@@ -151,7 +149,9 @@ class MultiHeadAttention(nn.Module):
             return autograd.attention(self, x * frame_mask.reshape(B, 1, T) if (in_mask and frame_mask is not None) else x,
                                       None if frame_mask is None else frame_mask.reshape(B, T).float())
         _forward_only_guard(self)
-        if self.k_channels > 256:
+        if self.k_channels > 256 or self.proximal_bias or self.block_length is not None:
+            # (proximal_bias / block_length -- rel_transformer.py:163-170, never set by VISinger -- are not in the streaming kernels: the q / k / v / o convs on
+            #  the HIP engine, the [T, T] core with the two options as PyTorch-ROCm ops, like the heads wider than 256 channels)
             # the streaming kernel covers heads of up to 256 channels (BASELINE config 5: hidden 512, 2 heads; the query tile
             # moves to LDS above 128); anything wider runs the q/k/v/o convs on the HIP engine and the [T, T] core as
             # PyTorch-ROCm ops (same index arithmetic, same -1e4 mask fill).
@@ -212,11 +212,13 @@ class RelativeEncoder(nn.Module):
             self.pre_net = HipConv1d(gin_channels, hidden_channels, 1)
 
     def forward(self, x, x_mask, g=None):
-        if self.pre_ln:
-            raise NotImplementedError("pre_ln=True is never used by VISinger (rel_transformer.py:281-282) and not implemented")
         if autograd.training_path(self):
             return autograd.rel_encoder(self, x, x_mask.reshape(x.shape[0], 1, x.shape[2]), g)
         _forward_only_guard(self)
+        if self.pre_ln:     # (rel_transformer.py:301-317, never set by VISinger: the same composition as the training path -- HIP convs / LayerNorm / attention
+            with torch.no_grad():       # kernels, the residual adds as PyTorch-ROCm ops -- instead of the fused post-LN launch sequence below)
+                return autograd.rel_encoder(self, x.contiguous().float(), x_mask.reshape(x.shape[0], 1, x.shape[2]).float(),
+                                            None if g is None else g.contiguous().float())
         B, C, T = x.shape
         m2 = mask2d(x_mask, B, T)
         x = x.contiguous().float()
@@ -255,9 +257,11 @@ class FFN(nn.Module):
         if autograd.training_path(self):
             return autograd.ffn(self, x, x_mask.reshape(x.shape[0], 1, x.shape[2]))
         _forward_only_guard(self)
-        if self.activation == "gelu":
-            raise NotImplementedError("FFN(activation='gelu') is never built by VISinger (rel_transformer.py:281-282)")
         B, _, T = x.shape
         m2 = mask2d(x_mask, B, T)
+        if self.activation == "gelu":       # (rel_transformer.py:338-341, never built by VISinger: x * sigmoid(1.702 x) between the two HIP convs as PyTorch-ROCm ops)
+            h = self.conv_1.run(x.contiguous().float(), in_act=L.IN_MASK, mask=m2)
+            h = h * torch.sigmoid(1.702 * h)
+            return self.conv_2.run(h, in_act=L.IN_MASK, mask=m2)
         h = self.conv_1.run(x.contiguous().float(), in_act=L.IN_MASK, mask=m2, out_act=L.OUT_RELU)
         return self.conv_2.run(h, in_act=L.IN_MASK, mask=m2)
