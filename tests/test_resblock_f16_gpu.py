@@ -63,7 +63,7 @@ def test_whole_resblock_equals_conv_by_conv_launches(vs_option):
         y_f = m._run_fused(x, torch.empty_like(x)).clone()
         vs_option("VS_NO_RESBLOCK_FUSED", 1)
         y_u = m._run_fused(x, torch.empty_like(x))
-    assert m.convs1[0]._op().kernel_instance().startswith("conv_split_kernel<")
+    assert m.convs1[0]._op().kernel_instance().startswith(("conv_split_kernel<", "conv_ktap_kernel<"))       # (round 5: the 64 x 256 conv_ktap instance, bit-identical to the tile kernel)
     assert float((y_f - y_u).abs().max()) <= 2e-6 * float(y_u.abs().max())
 
 

@@ -36,7 +36,8 @@ bool ktap_instance(int terms, int cfg, int kt, int io, int in_act) {
     if (!small && cfg != 0) return false;
     if (terms == 3) {
         if (io != 0) return false;
-        if (small) return (in_act == VS_IN_NONE && (kt == 1 || kt == 2 || kt == 3 || kt == 5 || kt == 7 || kt == 9 || kt == 11)) || (in_act == VS_IN_MASK && (kt == 1 || kt == 9));
+        if (small) return (in_act == VS_IN_NONE && (kt == 1 || kt == 2 || kt == 3 || kt == 5 || kt == 7 || kt == 9 || kt == 11)) || (in_act == VS_IN_MASK && (kt == 1 || kt == 9)) ||
+                          (in_act == VS_IN_LRELU && (cfg == 1 || cfg == 3) && (kt == 3 || kt == 7 || kt == 11));
         return kt == 3 || kt == 7 || kt == 11 || (kt == 9 && plain);
     }
     if (terms != 1) return false;

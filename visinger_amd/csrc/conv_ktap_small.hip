@@ -10,6 +10,11 @@ namespace vs {
 
 template <int WM, int WN, int NT>
 static int launch_ktap_small_tile(const ConvParams &p, hipStream_t s) {
+    if (p.in_act == VS_IN_LRELU && NT == 4) {          // (the generator's 64-channel resblock convs conv by conv: modules/visinger/decoder.py:91-104)
+        if (p.KT == 3) return launch_ktap_inst<3, VS_IN_LRELU, 2, 0, WM, WN, NT>(p, s);
+        if (p.KT == 7) return launch_ktap_inst<7, VS_IN_LRELU, 2, 0, WM, WN, NT>(p, s);
+        if (p.KT == 11) return launch_ktap_inst<11, VS_IN_LRELU, 2, 0, WM, WN, NT>(p, s);
+    }
     if (p.in_act == VS_IN_MASK) {
         if (p.KT == 1) return launch_ktap_inst<1, VS_IN_MASK, 2, 0, WM, WN, NT>(p, s);
         if (p.KT == 9) return launch_ktap_inst<9, VS_IN_MASK, 2, 0, WM, WN, NT>(p, s);
