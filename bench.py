@@ -456,7 +456,7 @@ def roofline_from_profile(prof, dt, steps, workload=None):
     step_bytes = sum(v["bytes"] for v in allp.values()) / steps
     step_tflops = step_flops / (dt / steps) / 1e12
     kern_ms = sum(v["ms"] for v in prof.values())
-    if name.startswith(("conv_split_kernel", "conv_ktap_kernel", "respair_split_kernel", "resblock_f16_kernel", "relattn_bf16_kernel")):
+    if name.startswith(("conv_split_kernel", "conv_ktap_kernel", "respair_split_kernel", "resblock_f16_kernel", "resblock_bf16_kernel", "relattn_bf16_kernel", "relattn_dma_kernel")):
         targs = [a.strip() for a in name[name.index("<") + 1:].rstrip(">").split(",")]
         ints = [int(a) for a in targs if a.isdigit()]
         if name.startswith("conv_split_kernel"):
@@ -465,6 +465,8 @@ def roofline_from_profile(prof, dt, steps, workload=None):
             terms = 3 if ints[2] == 2 else 1                 # conv_ktap_kernel<taps, input transform, planes, tensors, tile...>: two f16 planes = three cross products
         elif name.startswith("resblock_f16_kernel"):
             terms = 3
+        elif name.startswith(("relattn_dma_kernel", "resblock_bf16_kernel")):
+            terms = 1                                        # plain bf16 operands (BASELINE configs[4])
         else:
             terms = ints[-1] if ints[-1] in (1, 3, 6) else ints[-2]
         peak = BF16_MFMA_PEAK_TFLOPS / terms
