@@ -38,7 +38,7 @@ VS_API const char *vs_last_error(void);
  * this library, so a caller that attributes per-launch timings to kernel instances (bench.py's roofline line) reads it back
  * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
 VS_API const char *vs_last_kernel_name(void);
-VS_API int vs_abi_version(void);          /* 6: vs_source_hash, vs_bias_grad, vs_conv_set_weights_pair; 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
+VS_API int vs_abi_version(void);          /* 7: vs_conv_set_weights_batch, vs_weight_norm_multi_fwd / _bwd, vs_conv_wgrad_bias; 6: vs_source_hash, vs_bias_grad, vs_conv_set_weights_pair; 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
 /* sha256 (hex) over the sources this library was compiled from (kernels, headers, textual includes, the build recipe), embedded by
  * visinger_amd/csrc/build.py.  The loader recomputes it over the tree it sits in and refuses a library built from other sources (a
  * stale object that an mtime check would pass after a checkout).  (No reference counterpart: the reference has no native code.)  */
@@ -101,6 +101,12 @@ VS_API int vs_conv_set_weights(vs_conv_t *h, const float *w, const float *g, con
  * one pair of launches instead of two: the training step packs every weight version for both (autograd.HipConvFn).  bias0: h0's bias or
  * NULL; h1 gets none.  Falls back to two vs_conv_set_weights calls outside the split-f16 arithmetic.  (No reference counterpart.)       */
 VS_API int vs_conv_set_weights_pair(vs_conv_t *h0, vs_conv_t *h1, const float *w, const float *bias0, void *stream);
+/* The same for n handles, each from its own plain (already folded) weight w[i] and bias[i] (bias, or bias[i], may be NULL) -- every conv of a
+ * network at the top of a training pass -- in TWO launches for the whole batch (fp32 fragments + largest |w| of every handle; then the f16
+ * planes): the reference re-derives each module's weight inside its forward (torch.nn.utils.weight_norm's hook, modules/commons/... conv
+ * modules); a training step packed ~340 handles with four launches a pair.  No handle may appear twice.  Handles outside VS_MATH_SPLIT3 (and
+ * the <= 4-row VALU convs) take vs_conv_set_weights inside the call.  Stages a table through pinned host memory: not capturable into a graph.  */
+VS_API int vs_conv_set_weights_batch(vs_conv_t *const *handles, const float *const *w, const float *const *bias, int n, void *stream);
 
 /* Arithmetic of the matrix contraction of one conv handle (inputs, outputs and accumulation are fp32 in every mode):
  *   VS_MATH_F32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), Winograd F(2,3) instances where they measured faster
@@ -184,6 +190,12 @@ VS_API int vs_respair_forward(vs_conv_t *conv1, vs_conv_t *conv2, const vs_conv_
 VS_API int vs_conv_wgrad_planes(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out, int k);
 VS_API int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_out, int64_t c_in,
                          int64_t T_out, int64_t T_in, int k, int dil, int pad, void *stream);
+/* The same with the reduction of the planes done here and, with_bias != 0, the conv's bias gradient gb[co] = sum_{b,t} gy[b, co, t] from the
+ * same pass over gy (the workgroups of the first c_in tile sum their gy rows): what autograd computes for the `weight` and `bias` arguments of
+ * torch.nn.functional.conv1d, in two launches.  work: vs_conv_wgrad_planes(...) * (c_out * c_in * k + (with_bias ? c_out : 0)) floats of
+ * scratch; out: c_out * c_in * k floats of gw followed, with_bias, by c_out floats of gb.  Deterministic (fixed plane order).              */
+VS_API int vs_conv_wgrad_bias(const float *gy, const float *x, float *work, float *out, int with_bias, int64_t B, int64_t c_out,
+                              int64_t c_in, int64_t T_out, int64_t T_in, int k, int dil, int pad, void *stream);
 /* length of the time axis produced for an input of length T */
 VS_API int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T);
 
@@ -246,6 +258,13 @@ VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const fl
 /* gb[c] = sum over (b, t) of gy[b, c, t]: the bias gradient of every conv of the training path (what autograd computes for the `bias`
  * argument of torch.nn.functional.conv1d for the convs of modules/visinger under tasks/visinger.py:53-89), deterministic, one launch.     */
 VS_API int vs_bias_grad(const float *gy, float *gb, int64_t B, int64_t C, int64_t T, void *stream);
+/* torch.nn.utils.weight_norm (dim 0) of n tensors in one launch each way: w_i[r, :] = g_i[r] * v_i[r, :] / ||v_i[r, :]||, the row norms kept
+ * for the backward (what torch._weight_norm / its backward compute per tensor; the reference applies weight_norm to every conv of
+ * modules/visinger and the discriminators).  table: DEVICE memory, n rows of 8 x int64 {v, g, w, norm, rows, cols, first row, 0} with
+ * first row = the running sum of `rows`; total_rows = the sum.  grads: DEVICE memory, n rows of 4 x int64 {gw, gv, gg, 0}: gw = dL/dw_i
+ * (0: the tensor takes no gradient and its outputs are left untouched), gv / gg receive dL/dv_i and dL/dg_i.                                  */
+VS_API int vs_weight_norm_multi_fwd(const void *table, int64_t n, int64_t total_rows, void *stream);
+VS_API int vs_weight_norm_multi_bwd(const void *table, const void *grads, int64_t n, int64_t total_rows, void *stream);
 VS_API int vs_layernorm_c_bwd(const float *a, const float *r, const float *gamma, const float *dy, float *dx, float *dgamma,
                               float *dbeta, int64_t B, int64_t C, int64_t T, float eps, void *stream);
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 10
     missing = [s for s in sorted(syms) if not hasattr(lib, s)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
-    assert _lib.lib().vs_abi_version() == _lib.EXPECTED_ABI == 6
+    assert _lib.lib().vs_abi_version() == _lib.EXPECTED_ABI == 7
 
 
 def test_library_carries_the_hash_of_its_sources_and_a_foreign_build_is_refused(monkeypatch):

@@ -22,7 +22,7 @@ FLIP_IN, FLIP_OUT, CONV_ADJOINT = 1, 2, 4
 MATH_F32, MATH_BF16, MATH_SPLIT3, MATH_SPLIT6 = 0, 1, 3, 6
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
-EXPECTED_ABI = 6          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
+EXPECTED_ABI = 7          # include/visinger_hip.h VS_ABI_VERSION this binding was written against
 
 _f32p = ctypes.c_void_p
 
@@ -108,6 +108,9 @@ def lib():
     L.vs_gate_fwd.argtypes = [_f32p, _f32p, i64, _f32p, i64, i64, i64, vp]
     L.vs_gate_bwd.argtypes = [_f32p, _f32p, i64, _f32p, _f32p, _f32p, i64, i64, i64, i64, vp]
     L.vs_bias_grad.argtypes = [_f32p, _f32p, i64, i64, i64, vp]
+    L.vs_conv_set_weights_batch.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ci, vp]
+    L.vs_weight_norm_multi_fwd.argtypes = [vp, i64, i64, vp]
+    L.vs_weight_norm_multi_bwd.argtypes = [vp, vp, i64, i64, vp]
     L.vs_layernorm_c_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, i64, i64, i64, ctypes.c_float, vp]
     u64, cf = ctypes.c_uint64, ctypes.c_float
     L.vs_relattn_train_fwd.argtypes = [_f32p, _f32p, _f32p, i64, _f32p, _f32p, _f32p, _f32p, i64, _f32p, i64, ci, ci, i64, ci, ci, cf, u64, vp]
@@ -128,6 +131,7 @@ def lib():
     L.vs_resblock_forward.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ConvIO), ctypes.c_void_p]
     L.vs_conv_wgrad.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, i64, ci, ci, ci, vp]
     L.vs_conv_wgrad_planes.argtypes = [i64, i64, i64, i64, ci]
+    L.vs_conv_wgrad_bias.argtypes = [_f32p, _f32p, _f32p, _f32p, ci, i64, i64, i64, i64, i64, ci, ci, ci, vp]
     L.vs_gconv1d_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
     L.vs_gconv1d_bwd_data.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
     L.vs_gconv1d_bwd_weight.argtypes = [_f32p, _f32p, _f32p, i64, i64, i64, i64, ci, ci, ci, ci, vp]
@@ -139,7 +143,7 @@ def lib():
 # (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
 PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
                for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
-                            "VS_WGRAD_GEMM", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE", "VS_NO_FUSED_ADAMW")}
+                            "VS_WGRAD_GEMM", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE", "VS_NO_FUSED_ADAMW", "VS_NO_WEIGHT_BANK", "VS_NO_WGRAD_STREAM")}
 
 
 def switch(name):

@@ -83,8 +83,10 @@ class HipConvFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         need = ctx.needs_input_grad
         gy = gy.contiguous()
-        gx, gw = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]), key=ctx.wkey)
-        gb = bias_grad(gy) if (need[2] and ctx.has_bias) else None
+        want_b = bool(need[2] and ctx.has_bias)
+        gx, gw, gb = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]), key=ctx.wkey, need_b=want_b)
+        if want_b and gb is None:
+            gb = bias_grad(gy)
         return gx, gw, gb, None
 
 
@@ -96,7 +98,7 @@ def _bwd_op(module, key, *args):
     return ops[key]
 
 
-def conv_backward(m, x, w, gy, need_x, need_w, key=False):
+def conv_backward(m, x, w, gy, need_x, need_w, key=False, need_b=None):
     """Gradients of y = conv(x, w) for a HipConv1d / HipConvTranspose1d `m` (stride-1 dilated conv, or stride-u transposed
     conv), MIOpen-free:
 
@@ -110,7 +112,7 @@ def conv_backward(m, x, w, gy, need_x, need_w, key=False):
     """
     B, Cin, T = x.shape
     K = w.shape[2]
-    gx = gw = None
+    gx = gw = gb = None
     if m._kind != L.CONV_TRANSPOSE1D:
         Cout, d, p = w.shape[0], m.dilation[0], m.padding[0]
         Tout = gy.shape[2]
@@ -124,7 +126,10 @@ def conv_backward(m, x, w, gy, need_x, need_w, key=False):
                 op.set_weights_from(w, None, key)
             gx = op.forward(gy)
         if need_w:
-            gw = conv_wgrad(gy, x, K, d, p)
+            if need_b:      # the bias gradient from the weight-gradient kernel's pass over gy
+                gw, gb = conv_wgrad(gy, x, K, d, p, bias=True)
+            else:
+                gw = conv_wgrad(gy, x, K, d, p)
     else:
         Cout, u, p = w.shape[1], m.stride[0], m.padding[0]
         Q = -(-K // u)
@@ -145,7 +150,8 @@ def conv_backward(m, x, w, gy, need_x, need_w, key=False):
             # gw2[ci, j, q] = sum_{b,m} x[b, ci, m] * G[b, j, m + q]: the same kernel with x in the role of the output gradient
             g2 = conv_wgrad(x, G.contiguous(), Q, 1, 0)                                   # [Cin, u*Cout, Q]
             gw = g2.view(Cin, u, Cout, Q).permute(0, 2, 3, 1).reshape(Cin, Cout, Q * u)[:, :, :K].contiguous()
-    return gx, gw
+    # (need_b is None: the two-value form of the callers that take the bias gradient elsewhere; gb stays None where this path did not produce it)
+    return (gx, gw) if need_b is None else (gx, gw, gb)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -235,10 +241,12 @@ class StridedConv1dFn(torch.autograd.Function):
                 # library GEMM territory (rocBLAS); vs_conv_wgrad's 32 x 32 tiles re-read both operands once per tile pair
                 g2 = torch.stack([gyF[0] @ XF[0][:, q:q + Lf].t() for q in range(Q)], dim=2)
                 PROFILER.note("strided-conv wgrad (library GEMM per tap)", 2.0 * Cout * stride * C * Q * Lf)
+            elif has_bias and ctx.needs_input_grad[2]:
+                g2, gb = conv_wgrad(gyF, XF, Q, 1, 0, bias=True)                                # (the columns of gyF between the items are zeros: its row sums are gy's)
             else:
                 g2 = conv_wgrad(gyF, XF, Q, 1, 0)                                               # [Cout, s*C, Q]
             gw = g2.view(Cout, stride, C, Q).permute(0, 2, 3, 1).reshape(Cout, C, Q * stride)[:, :, :K].contiguous() if stride > 1 else g2
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = bias_grad(gy)
         return gx, gw, gb, None, None, None
 
@@ -273,6 +281,9 @@ def disc_conv1d(holder, x, w, b, stride, pad, groups=1):
 
 def effective_weight(m):
     """weight, or g * v / ||v|| (torch.nn.utils.weight_norm, dim 0) as a differentiable torch expression"""
+    w = m.__dict__.get("_w_eff")          # folded for the whole network at the top of the pass (weight_bank.WeightBank.refresh)
+    if w is not None:
+        return w
     if hasattr(m, "weight_g"):
         return torch._weight_norm(m.weight_v, m.weight_g, 0)
     return m.weight

@@ -34,6 +34,8 @@ struct WgradParams {
     float *gw;                   // partial planes [slices * planes][Cout][Cin][K]
     int B, Cout, Cin, Tout, Tin, K, dil, pad;
     int units_per_item, units;   // ceil(Tout / WG_TCH), B * units_per_item
+    long long plane_stride;      // floats between two partial planes: Cout * Cin * K (+ Cout with `bias`)
+    int bias;                    // the bias gradient's partial sums ride behind each plane: plane[Cout * Cin * K + co] = sum over the slice's (b, t) of gy[b, co, t]
 };
 
 __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
@@ -62,6 +64,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     for (int i = 0; i < WG_MAXTAPS; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float bsum = 0.f;
 
     for (int u = blockIdx.z; u < p.units; u += gridDim.z) {
         const int b = u / p.units_per_item;
@@ -90,6 +93,11 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
             }
         }
         __syncthreads();
+        if (p.bias && blockIdx.x == 0) {               // (the workgroups of the first ci tile also sum their gy rows: thread -> row tid / 8, 32 of its positions)
+            const float *gr = Ga + (tid >> 3) * PA + (tid & 7) * 32;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) bsum += gr[i];
+        }
         const float *ga = Ga + l31 * PA + lhalf;
         const float *xs = Xs + l31 * PX + lhalf + tap0 * p.dil;
         const int tstep = tapstep * p.dil;
@@ -103,7 +111,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     }
     // acc[i][r] -> plane[co0 + row(r)][ci0 + l31][tap0 + i * tapstep]; plane = slice (taps split over the waves: the four
     // waves fill disjoint taps of one plane) or slice * 4 + wave (positions split: one plane per wave)
-    float *plane = p.gw + (long long)(by_taps ? blockIdx.z : blockIdx.z * 4 + wave) * p.Cout * p.Cin * p.K;
+    float *plane = p.gw + (long long)(by_taps ? blockIdx.z : blockIdx.z * 4 + wave) * p.plane_stride;
+    if (p.bias && blockIdx.x == 0) {
+        // the slice's bias partial goes to its first plane; with one plane per wave the other three planes of the slice hold zeros
+        bsum += __shfl_xor(bsum, 1); bsum += __shfl_xor(bsum, 2); bsum += __shfl_xor(bsum, 4);
+        const int co = co0 + (tid >> 3);
+        if ((tid & 7) == 0 && co < p.Cout) {
+            float *bp = p.gw + (long long)(by_taps ? blockIdx.z : blockIdx.z * 4) * p.plane_stride + (long long)p.Cout * p.Cin * p.K + co;
+            bp[0] = bsum;
+            if (!by_taps) { bp[p.plane_stride] = 0.f; bp[2 * p.plane_stride] = 0.f; bp[3 * p.plane_stride] = 0.f; }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WG_MAXTAPS; ++i) {
         const int k = tap0 + i * tapstep;
@@ -154,6 +172,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
     for (int i = 0; i < KT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = p.bias && blockIdx.x == 0;      // (the workgroups of the first ci tile also sum their gy rows: 256 / CO_T threads per row)
 
     // A unit's global loads -- the gy tile (CO_T rows x 16 float4; T_out % 4 == 0, rows 16-byte aligned: host-checked) and the x tile (32 rows x 68
     // position pairs) -- are ALL unconditional on clamped addresses (what lies outside is zeroed when the registers go to LDS) and are issued for unit
@@ -231,6 +251,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
         }
         __syncthreads();
         if constexpr (PRE) { if (u + (int)gridDim.z < p.units) load_unit(u + gridDim.z); }
+        if (do_bias) {
+            constexpr int TPR = 256 / CO_T, NP = WS_TU / TPR;       // threads per row, positions per thread
+            const float *gr = Gs + (tid / TPR) * WS_GP + (tid % TPR) * NP;
+#pragma unroll
+            for (int i = 0; i < NP; i += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(gr + i);
+                bsum += (v.x + v.y) + (v.z + v.w);
+            }
+        }
         const float *ga = Gs + (cot * 32 + l31) * WS_GP + 8 * lhalf;
 #pragma unroll
         for (int ks = 0; ks < WS_TU / 16; ++ks) {
@@ -276,7 +305,14 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
             }
         }
     }
-    float *plane = p.gw + (long long)blockIdx.z * p.Cout * p.Cin * p.K;
+    float *plane = p.gw + (long long)blockIdx.z * p.plane_stride;
+    if (do_bias) {
+        constexpr int TPR = 256 / CO_T;
+        bsum += __shfl_xor(bsum, 1);
+        if constexpr (TPR == 4) bsum += __shfl_xor(bsum, 2);
+        const int co = co0 + tid / TPR;
+        if (tid % TPR == 0 && co < p.Cout) plane[(long long)p.Cout * p.Cin * p.K + co] = bsum;
+    }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         if (tapb + k < p.K) {
@@ -287,6 +323,22 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
             }
         }
     }
+}
+
+// out[i] = sum over the planes, in plane order (the same bits every run), of plane[i], i < n: the weight gradient (and, behind it, the bias gradient)
+// from the partial planes of the kernels above
+__global__ void __launch_bounds__(256) wgrad_finish_kernel(const float *__restrict__ planes, long long stride, int nplanes, float *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    int z = 0;
+    for (; z + 4 <= nplanes; z += 4) {
+        const float a = planes[(long long)z * stride + i], b = planes[(long long)(z + 1) * stride + i], c = planes[(long long)(z + 2) * stride + i],
+                    d = planes[(long long)(z + 3) * stride + i];
+        s += a; s += b; s += c; s += d;
+    }
+    for (; z < nplanes; ++z) s += planes[(long long)z * stride + i];
+    out[i] = s;
 }
 
 }  // namespace vs
@@ -317,8 +369,27 @@ int vs_conv_wgrad_planes(int64_t B, int64_t c_out, int64_t c_in, int64_t T_out, 
     return wgrad_slices(B, c_out, c_in, T_out) * (k > WG_MAXTAPS ? 1 : 4);
 }
 
+static int wgrad_launch(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_out, int64_t c_in, int64_t T_out,
+                        int64_t T_in, int k, int dil, int pad, int bias, void *stream);
+
 int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_out, int64_t c_in, int64_t T_out,
                   int64_t T_in, int k, int dil, int pad, void *stream) {
+    return wgrad_launch(gy, x, gw_planes, B, c_out, c_in, T_out, T_in, k, dil, pad, 0, stream);
+}
+
+int vs_conv_wgrad_bias(const float *gy, const float *x, float *work, float *out, int with_bias, int64_t B, int64_t c_out, int64_t c_in, int64_t T_out,
+                       int64_t T_in, int k, int dil, int pad, void *stream) {
+    VS_REQUIRE(work && out, "vs_conv_wgrad_bias: NULL work / out");
+    VS_TRY(wgrad_launch(gy, x, work, B, c_out, c_in, T_out, T_in, k, dil, pad, with_bias ? 1 : 0, stream));
+    const long long n = (long long)c_out * c_in * k + (with_bias ? c_out : 0);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), work, n,
+                       vs_conv_wgrad_planes(B, c_out, c_in, T_out, k), out, n);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+static int wgrad_launch(const float *gy, const float *x, float *gw_planes, int64_t B, int64_t c_out, int64_t c_in, int64_t T_out,
+                        int64_t T_in, int k, int dil, int pad, int bias, void *stream) {
     VS_REQUIRE(gy && x && gw_planes && B > 0 && c_out > 0 && c_in > 0 && T_out > 0 && T_in > 0, "vs_conv_wgrad: bad arguments");
     VS_REQUIRE(k >= 1 && k <= 4 * WG_MAXTAPS && dil >= 1 && pad >= 0 && (k - 1) * dil <= WG_MAXSPAN,
                "vs_conv_wgrad: k = %d, dil = %d outside the supported range (k <= 16, (k-1)*dil <= 64)", k, dil);
@@ -326,6 +397,8 @@ int vs_conv_wgrad(const float *gy, const float *x, float *gw_planes, int64_t B, 
     p.gy = gy; p.x = x; p.gw = gw_planes;
     p.B = (int)B; p.Cout = (int)c_out; p.Cin = (int)c_in; p.Tout = (int)T_out; p.Tin = (int)T_in;
     p.K = k; p.dil = dil; p.pad = pad;
+    p.bias = bias;
+    p.plane_stride = (long long)c_out * c_in * k + (bias ? c_out : 0);
     if (wgrad_split_ok(B, c_out, T_out, k)) {
         // vs_conv_wgrad_planes sized `gw_planes` for THIS kernel's reduction slices from the shape alone: an unaligned gy cannot fall back
         // to conv_wgrad_kernel (a different plane count: it would write past the buffer or leave planes unwritten)

@@ -172,6 +172,7 @@ struct vs_split_pack {            // re-pack of the fp32 fragment-order weights 
 int split_planes(int terms);
 int pack_split(const vs_split_pack &q, hipStream_t s);
 int pack_split_pair(const vs_split_pack &q0, const vs_split_pack &q1, hipStream_t s);   // terms = 3, both maxima ready: one launch
+int pack_split_multi(const vs_split_pack *jobs_dev, const unsigned *blk0_dev, int n, unsigned nblocks, hipStream_t s);   // terms = 3, maxima ready, table in device memory: one launch
 // cfg: tile shape as chosen by vs_conv_forward for the direct engine (0: 128 rows, 1/3: 64, 2: 32 x 256, 6: 32 x 128; 4/5: paired); span = receptive span
 int launch_split(const ConvParams &p, int cfg, int terms, int span, hipStream_t s);   // (p.x_bf16 / p.y_bf16: terms = 1, cfg 0 / 2 / 3 / 6)
 

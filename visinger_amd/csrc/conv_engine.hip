@@ -26,8 +26,10 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <type_traits>
+#include <vector>
 
 namespace vs {
 
@@ -872,14 +874,15 @@ __device__ __forceinline__ float packed_weight(const PackParams &q, int mt, int 
     return val;
 }
 
-__device__ __forceinline__ void pack_conv_body(const PackParams &q) {
+// blk of nblk: this block's place among the blocks that pack q (the whole grid of the one- and two-handle launches, a slice of it in the batch launch)
+__device__ __forceinline__ void pack_conv_body(const PackParams &q, unsigned blk, unsigned nblk) {
     const long long total = (long long)q.MT_alloc * q.KT * q.CP * 64;
     const long long work = max(total, (long long)q.MT_alloc * 32);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && q.maxbits_clear) *q.maxbits_clear = 0u;
+    if (blk == 0 && threadIdx.x == 0 && q.maxbits_clear) *q.maxbits_clear = 0u;
     unsigned m = 0u;
     // grid-stride: at most 1024 blocks however large the weight (the largest |w| below is ONE atomic per block: tens of thousands of
     // same-address atomics -- the discriminators' 1024 x 1024 x 5 convs -- serialised into most of a millisecond per pack)
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < work; e += (long long)gridDim.x * blockDim.x) {
+    for (long long e = (long long)blk * blockDim.x + threadIdx.x; e < work; e += (long long)nblk * blockDim.x) {
         if (e < (long long)q.MT_alloc * 32) q.biasp[e] = packed_bias(q, (int)e);   // bias over virtual rows
         if (e < total) {
             const int sub = (int)(e & 3);
@@ -905,12 +908,25 @@ __device__ __forceinline__ void pack_conv_body(const PackParams &q) {
         if (threadIdx.x == 0) atomicMax(q.maxbits, max(max(red[0], red[1]), max(red[2], red[3])));
     }
 }
-__global__ void pack_conv_kernel(const PackParams q) { pack_conv_body(q); }
+__global__ void pack_conv_kernel(const PackParams q) { pack_conv_body(q, blockIdx.x, gridDim.x); }
 // two handles fed from the same weight (a conv and the ADJOINT handle of its grad-input: vs_conv_set_weights_pair) in ONE launch:
 // blockIdx.y selects the handle.  A training step packs every weight for both; two launches per handle were 1 068 of its 6 175.
 __global__ void pack_conv_pair_kernel(const PackParams q0, const PackParams q1) {
-    if (blockIdx.y == 0) pack_conv_body(q0);
-    else pack_conv_body(q1);
+    if (blockIdx.y == 0) pack_conv_body(q0, blockIdx.x, gridDim.x);
+    else pack_conv_body(q1, blockIdx.x, gridDim.x);
+}
+// ANY number of handles in one launch (vs_conv_set_weights_batch: every conv of a network at the top of a training pass): the jobs and the first
+// block of each (blk0[n] = the grid) come from a table in device memory; a block finds its job by bisection.
+__global__ void pack_conv_multi_kernel(const PackParams *__restrict__ jobs, const unsigned *__restrict__ blk0, int n) {
+    int lo = 0, hi = n - 1;
+    const unsigned b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk0[mid] <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PackParams q = jobs[lo];
+    pack_conv_body(q, b - blk0[lo], blk0[lo + 1] - blk0[lo]);
 }
 
 // The same pack for the bf16-pipe engine in ONE launch: thread (cell = (m_tile, tap, chunk), lane) produces the eight values of its bf16
@@ -1217,7 +1233,7 @@ extern "C" {
 
 const char *vs_last_error(void) { return g_err; }
 const char *vs_last_kernel_name(void) { return g_last_kernel; }
-int vs_abi_version(void) { return 6; }
+int vs_abi_version(void) { return 7; }
 
 int vs_set_option(const char *name, long long value) {
     VS_REQUIRE(name, "vs_set_option: NULL name");
@@ -1487,6 +1503,106 @@ int vs_conv_set_weights_pair(vs_conv_t *h0, vs_conv_t *h1, const float *w, const
         h->weights_set = true;
     }
     return pack_split_pair(sp[0], sp[1], s);
+}
+
+// ---- vs_conv_set_weights_batch: the table of one batch (PackParams x n | vs_split_pack x n | first pack block x (n + 1) | first split block x (n + 1))
+// goes to the device through one of a ring of pinned staging buffers, each with a device twin and an event recorded behind the launches that read
+// it: a slot is reused only when its event has completed (normally long ago: a training step makes two or three batches).
+namespace {
+struct BatchSlot {
+    void *host = nullptr, *dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+struct BatchArena {
+    std::mutex mu;
+    static constexpr int NSLOT = 8;
+    BatchSlot slot[NSLOT];
+    int next = 0;
+};
+BatchArena g_batch;
+
+int batch_slot(size_t bytes, BatchSlot **out) {
+    BatchSlot &sl = g_batch.slot[g_batch.next];
+    g_batch.next = (g_batch.next + 1) % BatchArena::NSLOT;
+    if (sl.pending) {
+        VS_CHECK_HIP(hipEventSynchronize(sl.ev));
+        sl.pending = false;
+    }
+    if (!sl.ev) VS_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (bytes > sl.cap) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.host = sl.dev = nullptr;
+        sl.cap = 0;
+        const size_t cap = std::max<size_t>(bytes * 2, 64 * 1024);
+        VS_CHECK_HIP(hipHostMalloc(&sl.host, cap, hipHostMallocDefault));
+        VS_CHECK_HIP(hipMalloc(&sl.dev, cap));
+        sl.cap = cap;
+    }
+    *out = &sl;
+    return VS_OK;
+}
+}  // namespace
+
+int vs_conv_set_weights_batch(vs_conv_t *const *handles, const float *const *w, const float *const *bias, int n, void *stream) {
+    VS_REQUIRE(n >= 0 && (n == 0 || (handles && w)), "vs_conv_set_weights_batch: NULL array");
+    hipStream_t s = as_stream(stream);
+    // handles outside the batch kernels' case (other arithmetic, the <= 4-row VALU convs) take the plain call
+    std::vector<int> idx;
+    idx.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        vs_conv *h = handles[i];
+        VS_REQUIRE(h && w[i], "vs_conv_set_weights_batch: entry %d: NULL handle or weight", i);
+        const bool batched = h->math == VS_MATH_SPLIT3 && !(h->kind == VS_CONV1D && h->c_out <= 4 && !(h->flags & VS_CONV_ADJOINT));
+        if (!batched) VS_TRY(vs_conv_set_weights(h, w[i], nullptr, bias ? bias[i] : nullptr, stream));
+        else idx.push_back(i);
+    }
+    const int m = (int)idx.size();
+    if (m == 0) return VS_OK;
+    if (m == 1) return vs_conv_set_weights(handles[idx[0]], w[idx[0]], nullptr, bias ? bias[idx[0]] : nullptr, stream);
+    std::lock_guard<std::mutex> lock(g_batch.mu);
+    const size_t off_sp = (size_t)m * sizeof(PackParams), off_b0 = off_sp + (size_t)m * sizeof(vs_split_pack),
+                 off_b1 = off_b0 + (size_t)(m + 1) * sizeof(unsigned), bytes = off_b1 + (size_t)(m + 1) * sizeof(unsigned);
+    BatchSlot *sl = nullptr;
+    VS_TRY(batch_slot(bytes, &sl));
+    char *hb = static_cast<char *>(sl->host);
+    PackParams *q = reinterpret_cast<PackParams *>(hb);
+    vs_split_pack *sp = reinterpret_cast<vs_split_pack *>(hb + off_sp);
+    unsigned *b0 = reinterpret_cast<unsigned *>(hb + off_b0), *b1 = reinterpret_cast<unsigned *>(hb + off_b1);
+    unsigned nb0 = 0, nb1 = 0;
+    for (int j = 0; j < m; ++j) {
+        vs_conv *h = handles[idx[j]];
+        const size_t nel = (size_t)h->MT_alloc * h->KT * h->CP * 64;
+        VS_TRY(h->wp.reserve(nel * sizeof(float)));
+        VS_TRY(h->biasp.reserve((size_t)h->MT_alloc * 32 * sizeof(float)));
+        VS_TRY(reserve_wscale(h, s));
+        VS_TRY(h->ws.reserve((size_t)h->MT_alloc * h->KT * h->nchunks * 2 * 64 * 16));
+        fill_pack_params(h, w[idx[j]], bias ? bias[idx[j]] : nullptr, q[j]);
+        const long long work = std::max<long long>((long long)nel, (long long)h->MT_alloc * 32);
+        b0[j] = nb0;
+        nb0 += (unsigned)std::min<long long>(ceil_div(work, 256), 1024);
+        sp[j].wp = h->wp.as<float>(); sp[j].ws = h->ws.p; sp[j].MT_alloc = h->MT_alloc; sp[j].KT = h->KT; sp[j].nchunks = h->nchunks; sp[j].terms = 3;
+        sp[j].wscale = h->wsc.as<float>();
+        sp[j].maxbits = reinterpret_cast<const unsigned *>(sp[j].wscale + 2) + (h->pack_gen & 1);
+        sp[j].scratch = nullptr;
+        b1[j] = nb1;
+        nb1 += (unsigned)ceil_div((long long)h->MT_alloc * h->KT * h->nchunks * 64, 256);
+        h->wino_packed = false;
+        h->weights_set = true;
+    }
+    b0[m] = nb0;
+    b1[m] = nb1;
+    VS_CHECK_HIP(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, s));
+    const char *db = static_cast<const char *>(sl->dev);
+    hipLaunchKernelGGL(pack_conv_multi_kernel, dim3(nb0), dim3(256), 0, s, reinterpret_cast<const PackParams *>(db),
+                       reinterpret_cast<const unsigned *>(db + off_b0), m);
+    VS_CHECK_HIP(hipGetLastError());
+    VS_TRY(pack_split_multi(reinterpret_cast<const vs_split_pack *>(db + off_sp), reinterpret_cast<const unsigned *>(db + off_b1), m, nb1, s));
+    VS_CHECK_HIP(hipEventRecord(sl->ev, s));
+    sl->pending = true;
+    return VS_OK;
 }
 
 int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {

@@ -132,9 +132,9 @@ __global__ void wabsmax_kernel(const float *wp, long long n, unsigned *maxbits) 
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
 }
-__device__ __forceinline__ void pack_split_f16_body(const vs_split_pack &q, const unsigned *maxbits) {
+__device__ __forceinline__ void pack_split_f16_body(const vs_split_pack &q, const unsigned *maxbits, unsigned blk) {
     const long long total = (long long)q.MT_alloc * q.KT * q.nchunks * 64;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long e = (long long)blk * blockDim.x + threadIdx.x;
     const int eb = max(f16_key_exponent(*maxbits), F16_EB_MIN);      // (*maxbits: the largest f16_maxkey; all-zero weights: any scale does)
     const float sw = f16_scale(eb);
     if (e == 0) { q.wscale[0] = sw; q.wscale[1] = f16_inv_scale(eb); }
@@ -162,10 +162,28 @@ __device__ __forceinline__ void pack_split_f16_body(const vs_split_pack &q, cons
     }
 }
 
-__global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *maxbits) { pack_split_f16_body(q, maxbits); }
+__global__ void pack_split_f16_kernel(const vs_split_pack q, const unsigned *maxbits) { pack_split_f16_body(q, maxbits, blockIdx.x); }
 __global__ void pack_split_f16_pair_kernel(const vs_split_pack q0, const vs_split_pack q1) {
-    if (blockIdx.y == 0) pack_split_f16_body(q0, q0.maxbits);
-    else pack_split_f16_body(q1, q1.maxbits);
+    if (blockIdx.y == 0) pack_split_f16_body(q0, q0.maxbits, blockIdx.x);
+    else pack_split_f16_body(q1, q1.maxbits, blockIdx.x);
+}
+// the planes of any number of handles in one launch (vs_conv_set_weights_batch): jobs and their first blocks in device memory (blk0[n] = the grid)
+__global__ void pack_split_f16_multi_kernel(const vs_split_pack *__restrict__ jobs, const unsigned *__restrict__ blk0, int n) {
+    int lo = 0, hi = n - 1;
+    const unsigned b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk0[mid] <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const vs_split_pack q = jobs[lo];
+    pack_split_f16_body(q, q.maxbits, b - blk0[lo]);
+}
+
+int pack_split_multi(const vs_split_pack *jobs_dev, const unsigned *blk0_dev, int n, unsigned nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(pack_split_f16_multi_kernel, dim3(nblocks), dim3(256), 0, s, jobs_dev, blk0_dev, n);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
 }
 
 // the f16 planes of two handles (vs_conv_set_weights_pair) in one launch; both carry their ready weight maximum

@@ -182,6 +182,70 @@ __global__ void __launch_bounds__(256) phase_unstack_kernel(const float *__restr
 
 }  // namespace vs
 
+// ---- weight norm (torch.nn.utils.weight_norm, dim 0) of EVERY weight-normed conv of a network in one launch each way (the reference folds g * v / ||v||
+// per module through the parametrisation hook; a training step did it as 256 + 182 PyTorch launches).  The table (device memory, n rows of 8 x int64:
+// v, g, w, norm, rows, cols, first row, 0) lists the tensors; one wave per row of a tensor, the row's tensor found by bisection over `first row`.
+struct WnEntry {
+    const float *v, *g;
+    float *w, *norm;
+    long long rows, cols, row0, pad_;
+};
+struct WnGrad {            // per backward call: the incoming dL/dw (NULL: this tensor takes no gradient) and the two outputs
+    const float *gw;
+    float *gv, *gg;
+    long long pad_;
+};
+__device__ __forceinline__ int wn_find(const WnEntry *__restrict__ tab, int n, long long row) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].row0 <= row) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+__global__ void __launch_bounds__(256) weight_norm_multi_fwd_kernel(const WnEntry *__restrict__ tab, int n, long long total_rows) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= total_rows) return;
+    const WnEntry e = tab[wn_find(tab, n, row)];
+    const long long r = row - e.row0;
+    const float *vr = e.v + r * e.cols;
+    float ss = 0.f;
+    for (long long c = lane; c < e.cols; c += 64) ss += vr[c] * vr[c];
+    const float nrm = sqrtf(wave_sum(ss));
+    const float sc = e.g[r] / nrm;
+    float *wr = e.w + r * e.cols;
+    for (long long c = lane; c < e.cols; c += 64) wr[c] = vr[c] * sc;
+    if (lane == 0) e.norm[r] = nrm;
+}
+// dL/dg[r] = <gw_r, v_r> / ||v_r||;  dL/dv_r = (g[r] / ||v_r||) * (gw_r - v_r <gw_r, v_r> / ||v_r||^2)
+__global__ void __launch_bounds__(256) weight_norm_multi_bwd_kernel(const WnEntry *__restrict__ tab, const WnGrad *__restrict__ gr, int n,
+                                                                    long long total_rows) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= total_rows) return;
+    const int i = wn_find(tab, n, row);
+    const WnGrad d = gr[i];
+    if (!d.gw) return;
+    const WnEntry e = tab[i];
+    const long long r = row - e.row0;
+    const float *vr = e.v + r * e.cols, *gwr = d.gw + r * e.cols;
+    float dot = 0.f;
+    for (long long c = lane; c < e.cols; c += 64) dot += gwr[c] * vr[c];
+    dot = wave_sum(dot);
+    const float rn = 1.f / e.norm[r];
+    const float a = e.g[r] * rn, bcoef = e.g[r] * rn * rn * rn * dot;
+    float *gvr = d.gv + r * e.cols;
+    for (long long c = lane; c < e.cols; c += 64) gvr[c] = a * gwr[c] - bcoef * vr[c];
+    if (lane == 0) d.gg[r] = dot * rn;
+}
+
 using namespace vs;
 
 // bias gradient of a conv: gb[c] = sum over (b, t) of gy[b, c, t] -- one workgroup per channel, every thread a fixed strided subset in
@@ -230,6 +294,22 @@ extern "C" {
 int vs_bias_grad(const float *gy, float *gb, int64_t B, int64_t C, int64_t T, void *stream) {
     VS_REQUIRE(gy && gb && B > 0 && C > 0 && T > 0 && C <= 65535 * 32, "vs_bias_grad: bad arguments");
     hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), gy, gb, (int)B, (int)C, (int)T);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_weight_norm_multi_fwd(const void *table, int64_t n, int64_t total_rows, void *stream) {
+    VS_REQUIRE(table && n > 0 && total_rows > 0 && total_rows <= 4ll * 0x7fffffff, "vs_weight_norm_multi_fwd: bad arguments");
+    hipLaunchKernelGGL(weight_norm_multi_fwd_kernel, dim3((unsigned)ceil_div(total_rows, 4)), dim3(256), 0, as_stream(stream),
+                       static_cast<const WnEntry *>(table), (int)n, (long long)total_rows);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_weight_norm_multi_bwd(const void *table, const void *grads, int64_t n, int64_t total_rows, void *stream) {
+    VS_REQUIRE(table && grads && n > 0 && total_rows > 0 && total_rows <= 4ll * 0x7fffffff, "vs_weight_norm_multi_bwd: bad arguments");
+    hipLaunchKernelGGL(weight_norm_multi_bwd_kernel, dim3((unsigned)ceil_div(total_rows, 4)), dim3(256), 0, as_stream(stream),
+                       static_cast<const WnEntry *>(table), static_cast<const WnGrad *>(grads), (int)n, (long long)total_rows);
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
 }

@@ -34,9 +34,11 @@ _PERIOD_CHANNELS = (32, 128, 512, 1024, 1024)
 def _live_params(conv, x):
     """(weight [C_out, C_in/groups, k], bias) of a weight- / spectral-normed conv holder: its forward-pre hooks recompute
     ``conv.weight`` from the underlying parameters, exactly what calling the module would do first"""
-    for hook in conv._forward_pre_hooks.values():
-        hook(conv, (x,))
-    w = conv.weight
+    w = conv.__dict__.get("_w_eff")       # folded for the whole network at the top of the pass (weight_bank.WeightBank.refresh)
+    if w is None:
+        for hook in conv._forward_pre_hooks.values():
+            hook(conv, (x,))
+        w = conv.weight
     return (w.squeeze(-1) if w.dim() == 4 else w), conv.bias
 
 

@@ -198,6 +198,22 @@ class ConvOp:
         self._wkey = key
         adjoint_op._wkey = key
 
+    @staticmethod
+    def set_weights_batch(jobs):
+        """Training path: pack every (op, w, bias, key) of `jobs` -- distinct handles, each with its plain (folded) weight -- in two launches
+        for the whole list (vs_conv_set_weights_batch); each handle carries its key afterwards."""
+        if not jobs:
+            return
+        n = len(jobs)
+        keep = [(w.detach().contiguous(), None if b is None else b.detach().contiguous()) for _, w, b, _ in jobs]
+        vp = ctypes.c_void_p
+        hs = (vp * n)(*[op.h for op, _, _, _ in jobs])
+        ws = (vp * n)(*[w.data_ptr() for w, _ in keep])
+        bs = (vp * n)(*[None if b is None else b.data_ptr() for _, b in keep])
+        L.check(jobs[0][0].lib.vs_conv_set_weights_batch(hs, ws, bs, n, L.stream_ptr()))
+        for op, _, _, key in jobs:
+            op._wkey = key
+
     def forward(self, x, *, B=None, T=None, x_bs=0, in_act=L.IN_NONE, mask=None, bias_b=None, bias_b_bs=0,
                 y=None, y_bs=0, res=None, res_bs=0, acc=None, acc_bs=0, scale=1.0, out_act=L.OUT_NONE, out_mask=False,
                 mode=L.MODE_LINEAR, split_row=0, out1=None, pair_mode=L.PAIR_GATE, logdet=None,
@@ -397,9 +413,13 @@ def bias_grad(gy):
     return gb
 
 
-def conv_wgrad(gy, x, k, dil=1, pad=0):
+def conv_wgrad(gy, x, k, dil=1, pad=0, bias=False):
     """8f-1: weight gradient of a stride-1 conv, gw[co, ci, k] = sum_{b,t} gy[b, co, t] * x[b, ci, t + k*dil - pad]
-    (vs_conv_wgrad writes one partial plane per reduction slice; the planes are summed here)."""
+    (vs_conv_wgrad_bias: one partial plane per reduction slice, summed by its second launch).  bias=True: -> (gw, gb) with the conv's bias
+    gradient gb[co] = sum_{b,t} gy[b, co, t] from the same pass over gy (one launch less than vs_bias_grad next to it, and gy is read once)."""
+    if bias:
+        gw = conv_wgrad(gy, x, k, dil, pad, bias=None)
+        return gw if isinstance(gw, tuple) else (gw, bias_grad(gy))
     lib = L.require_gpu()
     gy, x = gy.contiguous().float(), x.contiguous().float()
     B, Cout, Tout = gy.shape
@@ -417,10 +437,15 @@ def conv_wgrad(gy, x, k, dil=1, pad=0):
     if gy.data_ptr() % 16:       # (an offset view that is contiguous: the split kernel loads float4 rows of gy)
         gy = gy.clone()
     planes = lib.vs_conv_wgrad_planes(B, Cout, Cin, Tout, int(k))
-    part = torch.empty((planes, Cout, Cin, k), device=x.device, dtype=torch.float32)
-    L.check(lib.vs_conv_wgrad(L.ptr(gy), L.ptr(x), L.ptr(part), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad), L.stream_ptr()))
+    with_bias = bias is None                  # (asked for by the bias=True wrapper above; the special cases before this line return gw alone)
+    n = Cout * Cin * k
+    part = torch.empty((planes, n + (Cout if with_bias else 0)), device=x.device, dtype=torch.float32)
+    out = torch.empty(n + (Cout if with_bias else 0), device=x.device, dtype=torch.float32)
+    L.check(lib.vs_conv_wgrad_bias(L.ptr(gy), L.ptr(x), L.ptr(part), L.ptr(out), int(with_bias), B, Cout, Cin, Tout, Tin, int(k), int(dil), int(pad),
+                                   L.stream_ptr()))
     PROFILER.note("conv_wgrad (vs_conv_wgrad)", 2.0 * B * Cout * Cin * k * Tout)
-    return part.sum(0) if planes > 1 else part[0]
+    gw = out[:n].view(Cout, Cin, k)
+    return (gw, out[n:]) if with_bias else gw
 
 
 def _gconv_out_len(T, k, stride, pad):

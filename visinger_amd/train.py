@@ -160,7 +160,26 @@ class VISingerTrainer(nn.Module):
 
     def forward(self, batch, optimizer_idx):
         """DDP entry point (the reference routes DDP.forward to training_step, ddp_utils.py:75-80)"""
-        return self.generator_pass(batch) if optimizer_idx == 0 else self.discriminator_pass(batch)
+        banks = self._weight_banks(optimizer_idx)
+        try:
+            for bank in banks:
+                bank.refresh()
+            return self.generator_pass(batch) if optimizer_idx == 0 else self.discriminator_pass(batch)
+        finally:
+            for bank in banks:
+                bank.release()
+
+    def _weight_banks(self, optimizer_idx):
+        """the networks whose weights the pass derives: folded and packed in a handful of launches before the forward (weight_bank.py)"""
+        from ._lib import switch
+        if switch("VS_NO_WEIGHT_BANK") or not (self.training and torch.is_grad_enabled()) or not next(self.parameters()).is_cuda:
+            return ()
+        if self.__dict__.get("_banks") is None:
+            from .weight_bank import WeightBank
+            self.__dict__["_banks"] = (WeightBank(self.model), WeightBank(self.mel_disc))
+        bg, bd = self.__dict__["_banks"]
+        disc_on = self.global_step >= self.hp["disc_start_steps"] and self.hp["lambda_mel_adv"] > 0
+        return ((bg, bd) if disc_on else (bg,)) if optimizer_idx == 0 else (bd,)
 
     def backward_pass(self, batch, opt_idx, runner=None):
         """forward + backward of one optimizer's pass with the other network frozen (trainer.py:312-375): afterwards the gradients of
