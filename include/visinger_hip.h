@@ -38,7 +38,7 @@ VS_API const char *vs_last_error(void);
  * this library, so a caller that attributes per-launch timings to kernel instances (bench.py's roofline line) reads it back
  * here instead of restating the selection.  Thread-local; "" before the first launch.  (No reference counterpart.)          */
 VS_API const char *vs_last_kernel_name(void);
-VS_API int vs_abi_version(void);          /* 7: vs_conv_set_weights_batch, vs_weight_norm_multi_fwd / _bwd, vs_conv_wgrad_bias; 6: vs_source_hash, vs_bias_grad, vs_conv_set_weights_pair; 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
+VS_API int vs_abi_version(void);          /* 7: vs_conv_set_weights_batch, vs_weight_norm_multi_fwd / _bwd, vs_conv_wgrad_bias, vs_wn_step_fwd / _bwd, vs_l1_mean_fwd / _bwd; 6: vs_source_hash, vs_bias_grad, vs_conv_set_weights_pair; 5: vs_relattn_fwd_work / vs_relattn_kv_work_bytes; 4: vs_set_option / vs_get_option / vs_reset_option; 3: vs_dtype in vs_conv_io_t; 2: vs_relattn_fwd(math) */
 /* sha256 (hex) over the sources this library was compiled from (kernels, headers, textual includes, the build recipe), embedded by
  * visinger_amd/csrc/build.py.  The loader recomputes it over the tree it sits in and refuses a library built from other sources (a
  * stale object that an mtime check would pass after a checkout).  (No reference counterpart: the reference has no native code.)  */
@@ -255,6 +255,19 @@ VS_API int vs_layernorm_c_fwd(const float *a, const float *r, const float *gamma
 VS_API int vs_gate_fwd(const float *x_in, const float *g, int64_t g_bs, float *acts, int64_t B, int64_t H, int64_t T, void *stream);
 VS_API int vs_gate_bwd(const float *x_in, const float *g, int64_t g_bs, const float *dacts, float *dx_in, float *dg, int64_t dg_bs,
                        int64_t B, int64_t H, int64_t T, void *stream);
+/*   vs_wn_step_fwd / vs_wn_step_bwd: the residual / skip update behind a WaveNet layer's res_skip conv (modules/visinger/encoder.py:186-193):
+ *     x_new = (x + rs[:, :H]) * mask, out_new = out_acc + rs[:, H:] with rs [B, 2H, T], x / out_acc / x_new / out_new [B, H, T], mask [B, T];
+ *     out_acc NULL: the first layer (out_new = rs[:, H:]).  Backward: d_rs[:, :H] = dx = dx_new * mask, d_rs[:, H:] = dout_new (NULL inputs: zeros);
+ *     the gradient of out_acc is dout_new itself.                                                                                              */
+VS_API int vs_wn_step_fwd(const float *x, const float *rs, const float *out_acc, const float *mask, float *x_new, float *out_new, int64_t B,
+                          int64_t H, int64_t T, void *stream);
+/*   vs_l1_mean_fwd / vs_l1_mean_bwd: out[0] = mean |a - b| over n elements and d/da = sign(a - b) * gout[0] / n (the feature-matching loss terms,
+ *     tasks/visinger.py:162-169), one launch each, deterministic.  work: 257 floats the caller keeps (work[256] starts as 0 and returns to 0);
+ *     calls that share `work` must be ordered on one stream.                                                                                       */
+VS_API int vs_l1_mean_fwd(const float *a, const float *b, float *work, float *out, int64_t n, void *stream);
+VS_API int vs_l1_mean_bwd(const float *a, const float *b, const float *gout, float *da, int64_t n, void *stream);
+VS_API int vs_wn_step_bwd(const float *dx_new, const float *dout_new, const float *mask, float *d_rs, float *dx, int64_t B, int64_t H,
+                          int64_t T, void *stream);
 /* gb[c] = sum over (b, t) of gy[b, c, t]: the bias gradient of every conv of the training path (what autograd computes for the `bias`
  * argument of torch.nn.functional.conv1d for the convs of modules/visinger under tasks/visinger.py:53-89), deterministic, one launch.     */
 VS_API int vs_bias_grad(const float *gy, float *gb, int64_t B, int64_t C, int64_t T, void *stream);

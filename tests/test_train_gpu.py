@@ -268,6 +268,71 @@ def test_bias_grad_and_single_position_wgrad(B, C, T):
         assert float((gw.double() - want).abs().max()) <= 1e-5 * (1.0 + float(want.abs().max()))
 
 
+@pytest.mark.parametrize("Cin,Cout,K,d,T,B", [(192, 384, 5, 1, 512, 4), (192, 768, 9, 1, 64, 8), (96, 200, 7, 1, 516, 2), (32, 64, 11, 1, 8192, 1),
+                                              (192, 192, 1, 1, 512, 16), (24, 40, 5, 1, 77, 2), (16, 48, 1, 1, 50, 3), (40, 33, 3, 2, 301, 2), (64, 1, 3, 1, 640, 2)])
+def test_wgrad_with_fused_bias_gradient(Cin, Cout, K, d, T, B):
+    """ops.conv_wgrad(..., bias=True) (vs_conv_wgrad_bias): the weight gradient is the one of the plain call bit for bit, and the bias gradient -- the
+    gy row sums taken by the weight-gradient kernel's first c_in tile, both kernels (split-bf16 and exact-fp32, taps split over waves or positions), then
+    the fixed-order plane reduction -- equals the fp64 sum and is run-to-run bit-identical."""
+    from visinger_amd.ops import conv_wgrad
+    torch.manual_seed(Cin * 7 + Cout + K + T)
+    pad = d * (K - 1) // 2
+    x = torch.randn(B, Cin, T, device="cuda")
+    gy = torch.randn(B, Cout, T + 2 * pad - d * (K - 1), device="cuda")
+    gw0 = conv_wgrad(gy, x, K, d, pad)
+    gw, gb = conv_wgrad(gy, x, K, d, pad, bias=True)
+    assert torch.equal(gw, gw0) and gb.shape == (Cout,)
+    ref = gy.double().sum((0, 2))
+    assert float((gb.double() - ref).abs().max()) <= 1e-5 * (1.0 + float(gy.abs().double().sum((0, 2)).max()) * 0.05)
+    gw2, gb2 = conv_wgrad(gy, x, K, d, pad, bias=True)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    ref64 = torch.ops.aten.convolution_backward(gy.double(), x.double(), torch.zeros(Cout, Cin, K, device="cuda", dtype=torch.double), None, [1], [pad], [d],
+                                                False, [0], 1, [False, True, False])[1]
+    assert float((gw.double() - ref64).abs().max()) <= 2e-5 * float(ref64.abs().max())
+
+
+def test_wavenet_step_and_l1_mean_functions_match_torch_autograd():
+    """autograd.WnStepFn (vs_wn_step_fwd / _bwd) and autograd.L1MeanFn (vs_l1_mean_fwd / _bwd) against PyTorch autograd of the reference expressions
+    (encoder.py:186-193; tasks/visinger.py:162-169): values and gradients, odd sizes, the first layer's missing accumulator, permuted dense layouts."""
+    from visinger_amd.autograd import L1MeanFn, WnStepFn, l1_mean
+    torch.manual_seed(5)
+    for B, H, T in ((2, 192, 512), (3, 24, 37), (1, 16, 1030)):
+        x = torch.randn(B, H, T, device="cuda", requires_grad=True)
+        rs = torch.randn(B, 2 * H, T, device="cuda", requires_grad=True)
+        acc = torch.randn(B, H, T, device="cuda", requires_grad=True)
+        mask = (torch.rand(B, 1, T, device="cuda") > 0.2).float()
+        wx, wo = torch.randn(B, H, T, device="cuda"), torch.randn(B, H, T, device="cuda")
+        for a in (acc, None):
+            xn, on = WnStepFn.apply(x, rs, a, mask.reshape(B, T).contiguous())
+            rx = (x + rs[:, :H]) * mask
+            ro = rs[:, H:] if a is None else a + rs[:, H:]
+            assert torch.equal(xn, rx) and torch.equal(on, ro)
+            ins = [x, rs] + ([a] if a is not None else [])
+            got = torch.autograd.grad((xn * wx).sum() + (on * wo).sum(), ins, retain_graph=True)
+            want = torch.autograd.grad((rx * wx).sum() + (ro * wo).sum(), ins)
+            for g_, w_ in zip(got, want):
+                assert torch.equal(g_, w_)
+            got1 = torch.autograd.grad((on * wo).sum(), [rs])[0]              # only one of the outputs takes a gradient
+            assert torch.equal(got1, torch.autograd.grad((ro * wo).sum(), [rs])[0])
+    for shape, perm in (((4, 64, 33, 3), (0, 2, 3, 1)), ((2, 1024, 7), None), ((1, 1, 5), None), ((3, 300000), None)):
+        a = torch.randn(shape, device="cuda")
+        b = torch.randn(shape, device="cuda")
+        if perm:
+            a, b = a.permute(perm), b.permute(perm)
+        a.requires_grad_(True)
+        assert L1MeanFn.dense_pair(a, b)
+        got = l1_mean(a, b)
+        ref = torch.mean(torch.abs(b - a))
+        assert abs(float(got) - float(ref)) <= 2e-6 * float(ref)
+        assert float(l1_mean(a, b)) == float(got)                               # deterministic (fixed-order partials)
+        ga = torch.autograd.grad(got * 3.0, [a])[0]
+        ra = torch.autograd.grad(ref * 3.0, [a])[0]
+        assert ga.stride() == a.stride() and float((ga - ra).abs().max()) <= 1e-9
+    a = torch.randn(4, 8, 6, device="cuda", requires_grad=True)
+    assert not L1MeanFn.dense_pair(a[:, :, :5], torch.randn(4, 8, 5, device="cuda"))      # a gap in the layout: the PyTorch formulation
+    assert float(l1_mean(a[:, :, :5], torch.zeros(4, 8, 5, device="cuda"))) == float(a[:, :, :5].abs().mean())
+
+
 def _attn_core_torch(q, k, v, rel_k, rel_v, mask, nh, w, keep=None):
     """rel_transformer.py:148-179 + 181-243 with plain torch ops on [B, nh, T, T] (fp64): the definition the streaming kernels are
     checked against.  keep: dropout factor per (b, h, query, key) (0 or 1 / (1 - p)), or None."""

@@ -110,6 +110,10 @@ def lib():
     L.vs_bias_grad.argtypes = [_f32p, _f32p, i64, i64, i64, vp]
     L.vs_conv_set_weights_batch.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ci, vp]
     L.vs_weight_norm_multi_fwd.argtypes = [vp, i64, i64, vp]
+    L.vs_wn_step_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, i64, i64, i64, vp]
+    L.vs_wn_step_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, i64, i64, i64, vp]
+    L.vs_l1_mean_fwd.argtypes = [_f32p, _f32p, _f32p, _f32p, i64, vp]
+    L.vs_l1_mean_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, i64, vp]
     L.vs_weight_norm_multi_bwd.argtypes = [vp, vp, i64, i64, vp]
     L.vs_layernorm_c_bwd.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, i64, i64, i64, ctypes.c_float, vp]
     u64, cf = ctypes.c_uint64, ctypes.c_float
@@ -143,7 +147,7 @@ def lib():
 # (vs_set_option): no os.environ lookup on any forward / backward path.  set_option() changes either kind by name.
 PY_SWITCHES = {name: (int(os.environ[name]) if os.environ.get(name, "").lstrip("-").isdigit() else int(bool(os.environ.get(name))))
                for name in ("VS_NO_TRAIN_FUSED", "VS_NO_TRAIN_ATTN", "VS_NO_FUSED_QKV", "VS_NO_ATTN_KSPLIT", "VS_ATTN_KSPLIT",
-                            "VS_WGRAD_GEMM", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE", "VS_NO_FUSED_ADAMW", "VS_NO_WEIGHT_BANK", "VS_NO_WGRAD_STREAM")}
+                            "VS_WGRAD_GEMM", "VS_NO_PAIR_PACK", "VS_NO_RESPAIR", "VS_RESPAIR_FORCE", "VS_NO_RESBLOCK_FUSED", "VS_RESBLOCK_PAIRS", "VS_NO_PACK_CACHE", "VS_NO_FUSED_ADAMW", "VS_NO_WEIGHT_BANK")}
 
 
 def switch(name):

@@ -116,6 +116,13 @@ def conv_backward(m, x, w, gy, need_x, need_w, key=False, need_b=None):
     if m._kind != L.CONV_TRANSPOSE1D:
         Cout, d, p = w.shape[0], m.dilation[0], m.padding[0]
         Tout = gy.shape[2]
+        if need_w:
+            # (round 5 tried these launches on a second stream beside the grad-input conv: the kernels slow each other down -- device time 81 -> 89 ms a step,
+            #  step time 86 -> 89-104 ms -- so they stay in line)
+            if need_b:      # the bias gradient from the weight-gradient kernel's pass over gy
+                gw, gb = conv_wgrad(gy, x, K, d, p, bias=True)
+            else:
+                gw = conv_wgrad(gy, x, K, d, p)
         if need_x:
             pb = d * (K - 1) - p
             assert pb >= 0, "conv backward-data: padding larger than the receptive field is not supported"
@@ -125,11 +132,6 @@ def conv_backward(m, x, w, gy, need_x, need_w, key=False, need_b=None):
             if not op.has_weights_of(key):
                 op.set_weights_from(w, None, key)
             gx = op.forward(gy)
-        if need_w:
-            if need_b:      # the bias gradient from the weight-gradient kernel's pass over gy
-                gw, gb = conv_wgrad(gy, x, K, d, p, bias=True)
-            else:
-                gw = conv_wgrad(gy, x, K, d, p)
     else:
         Cout, u, p = w.shape[1], m.stride[0], m.padding[0]
         Q = -(-K // u)
@@ -227,14 +229,6 @@ class StridedConv1dFn(torch.autograd.Function):
         gyF = torch.empty((1, Cout, Lf), device=gy.device, dtype=torch.float32)
         L.check(lib.vs_phase_items(L.ptr(gy), L.ptr(gyF), N, Cout, Tout, Hq, Lf, 1, L.stream_ptr()))
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            op = _cached_op(holder, ("dxa", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, L.CONV_ADJOINT)
-            key = ctx.wkey      # (not param_key(holder) now: parameters stepped between forward and backward would label the OLD weight with the new key)
-            if not op.has_weights_of(key):      # (the handle packs the adjoint of the phase-stacked forward weight)
-                op.set_weights_from(_phase_weights(w.detach(), stride, Q) if stride > 1 else w, None, key)
-            gXF = op.forward(gyF)                                                               # [1, s*C, N*Hq + Q - 1]
-            gx = torch.empty((N, C, T), device=gy.device, dtype=torch.float32)
-            L.check(lib.vs_phase_unstack(L.ptr(gXF), Lf + Q - 1, L.ptr(gx), N, C, T, stride, pad, Hq, L.stream_ptr()))
         if ctx.needs_input_grad[1]:
             if Cout * stride * C >= 256 * 256 or Q > 16:       # (vs_conv_wgrad covers up to 16 taps)
                 # wide layers (512 / 1024 channels): per tap a plain [Cout x P] x [P x s*C] GEMM over the folded sequence --
@@ -246,6 +240,14 @@ class StridedConv1dFn(torch.autograd.Function):
             else:
                 g2 = conv_wgrad(gyF, XF, Q, 1, 0)                                               # [Cout, s*C, Q]
             gw = g2.view(Cout, stride, C, Q).permute(0, 2, 3, 1).reshape(Cout, C, Q * stride)[:, :, :K].contiguous() if stride > 1 else g2
+        if ctx.needs_input_grad[0]:
+            op = _cached_op(holder, ("dxa", C, Cout, K, stride), L.CONV1D, Cout, stride * C, Q, 1, Q - 1, L.CONV_ADJOINT)
+            key = ctx.wkey      # (not param_key(holder) now: parameters stepped between forward and backward would label the OLD weight with the new key)
+            if not op.has_weights_of(key):      # (the handle packs the adjoint of the phase-stacked forward weight)
+                op.set_weights_from(_phase_weights(w.detach(), stride, Q) if stride > 1 else w, None, key)
+            gXF = op.forward(gyF)                                                               # [1, s*C, N*Hq + Q - 1]
+            gx = torch.empty((N, C, T), device=gy.device, dtype=torch.float32)
+            L.check(lib.vs_phase_unstack(L.ptr(gXF), Lf + Q - 1, L.ptr(gx), N, C, T, stride, pad, Hq, L.stream_ptr()))
         if has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = bias_grad(gy)
         return gx, gw, gb, None, None, None
@@ -363,31 +365,111 @@ class LayerNormFn(torch.autograd.Function):
         return dx, (dx if ctx.has_r else None), dgb[0], dgb[1], None
 
 
+class WnStepFn(torch.autograd.Function):
+    """x_new = (x + rs[:, :H]) * x_mask, out_new = out_acc + rs[:, H:] (encoder.py:186-193; out_acc None: the first layer): one HIP launch each way
+    (vs_wn_step_fwd / vs_wn_step_bwd) where autograd recorded two slices, two adds and a multiply -- 3 launches forward, ~9 backward, per layer."""
+
+    @staticmethod
+    def forward(ctx, x, rs, out_acc, mask2):
+        x, rs = x.contiguous(), rs.contiguous()
+        B, H, T = x.shape
+        x_new, out_new = torch.empty_like(x), torch.empty_like(x)
+        L.check(L.require_gpu().vs_wn_step_fwd(L.ptr(x), L.ptr(rs), L.ptr(None if out_acc is None else out_acc.contiguous()), L.ptr(mask2), L.ptr(x_new),
+                                               L.ptr(out_new), B, H, T, L.stream_ptr()))
+        ctx.save_for_backward(mask2)
+        ctx.set_materialize_grads(False)
+        ctx.has_acc = out_acc is not None
+        return x_new, out_new
+
+    @staticmethod
+    def backward(ctx, dx_new, dout_new):
+        mask2, = ctx.saved_tensors
+        if dx_new is None and dout_new is None:
+            return None, None, None, None
+        ref = dx_new if dx_new is not None else dout_new
+        B, H, T = ref.shape
+        dx_new = None if dx_new is None else dx_new.contiguous()
+        dout_new = None if dout_new is None else dout_new.contiguous()
+        d_rs = torch.empty((B, 2 * H, T), device=ref.device, dtype=torch.float32)
+        dx = torch.empty((B, H, T), device=ref.device, dtype=torch.float32)
+        L.check(L.require_gpu().vs_wn_step_bwd(L.ptr(dx_new), L.ptr(dout_new), L.ptr(mask2), L.ptr(d_rs), L.ptr(dx), B, H, T, L.stream_ptr()))
+        return dx, d_rs, (dout_new if ctx.has_acc else None), None
+
+
+class L1MeanFn(torch.autograd.Function):
+    """mean |a - b| with the gradient to `a` only (b: the detached target): vs_l1_mean_fwd / _bwd, one launch each way.  a and b must share one dense
+    layout (equal strides, no gaps): the kernels walk the storage."""
+
+    _work = {}
+
+    @staticmethod
+    def dense_pair(a, b):
+        if not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.stride() == b.stride() and a.numel() > 0):
+            return False
+        order = sorted(range(a.dim()), key=lambda d: -a.stride(d))
+        return a.permute(order).is_contiguous()
+
+    @staticmethod
+    def forward(ctx, a, b):
+        work = L1MeanFn._work.get(a.device)
+        if work is None:
+            work = L1MeanFn._work[a.device] = torch.zeros(257, device=a.device, dtype=torch.float32)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        L.check(L.require_gpu().vs_l1_mean_fwd(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), L.ptr(work), ctypes.c_void_p(out.data_ptr()),
+                                               a.numel(), L.stream_ptr()))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a)            # (preserve_format: a's dense strides)
+        gout = gout.contiguous().float()
+        L.check(L.require_gpu().vs_l1_mean_bwd(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(gout.data_ptr()),
+                                               ctypes.c_void_p(da.data_ptr()), a.numel(), L.stream_ptr()))
+        return da, None
+
+
+def l1_mean(a, b):
+    """mean |a - b|, differentiable in `a` (b is treated as a constant)"""
+    b = b.detach()
+    if L1MeanFn.dense_pair(a, b) and not L.switch("VS_NO_TRAIN_FUSED"):
+        return L1MeanFn.apply(a, b)
+    return torch.mean(torch.abs(b - a))
+
+
 def wavenet(m, x, x_mask, g=None):
     """encoder.py:167-195"""
     H = m.hidden_channels
-    output = torch.zeros_like(x)
     if g is not None:
         g = conv(m.cond_layer, g)
     # (the gate kernel reads the conditioning as ONE column per item, g[b, c, 0]: a time-varying [B, gin, T] condition -- which the
     # reference's WN broadcasts as well -- or a non-fp32 one takes the PyTorch formulation)
     fused = (x.is_cuda and not L.switch("VS_NO_TRAIN_FUSED") and (m.p_dropout == 0 or not m.training) and
              (g is None or (g.shape[2] == 1 and g.dtype == torch.float32)))
+    # (one split of the conditioning for all layers -- a single cat backward -- where a slice per layer ran zeros + copy + accumulate each)
+    gs = None if g is None else torch.split(g, 2 * H, dim=1)
+    step_fused = x.is_cuda and x.dtype == torch.float32 and x_mask.numel() == x.shape[0] * x.shape[2] and not L.switch("VS_NO_TRAIN_FUSED")
+    mask2 = x_mask.reshape(x.shape[0], x.shape[2]).float().contiguous() if step_fused else None
+    output = None
     for i in range(m.n_layers):
         x_in = conv(m.in_layers[i], x)
         if fused:
-            acts = GateFn.apply(x_in, None if g is None else g[:, i * 2 * H:(i + 1) * 2 * H, :])
+            acts = GateFn.apply(x_in, None if gs is None else gs[i])
         else:
-            if g is not None:
-                x_in = x_in + g[:, i * 2 * H:(i + 1) * 2 * H, :]
+            if gs is not None:
+                x_in = x_in + gs[i]
             acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
             acts = m.drop(acts)
         rs = conv(m.res_skip_layers[i], acts)
         if i < m.n_layers - 1:
-            x = (x + rs[:, :H]) * x_mask
-            output = output + rs[:, H:]
+            if step_fused:
+                x, output = WnStepFn.apply(x, rs, output, mask2)
+            else:
+                x = (x + rs[:, :H]) * x_mask
+                output = rs[:, H:] if output is None else output + rs[:, H:]
         else:
-            output = output + rs
+            output = rs if output is None else output + rs
     return output * x_mask
 
 

@@ -10,6 +10,8 @@
 // over (batch, time) as one float atomic per channel and 64-frame block (LayerNorm: into one row per batch item, summed by the caller).
 #include "vs_internal.h"
 
+#include <algorithm>
+
 namespace vs {
 
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -246,6 +248,99 @@ __global__ void __launch_bounds__(256) weight_norm_multi_bwd_kernel(const WnEntr
     if (lane == 0) d.gg[r] = dot * rn;
 }
 
+// ---- the residual / skip update of a WaveNet layer (encoder.py:186-193): rs = res_skip_layer(acts) [B, 2H, T];
+//        x_new = (x + rs[:, :H]) * mask,   out_new = out_acc + rs[:, H:]       (out_acc NULL: the first layer, out_new = rs[:, H:])
+// one launch where autograd recorded two slices, two adds and a multiply (and ran ~9 kernels backward); backward:
+//        d_rs[:, :H] = dx = dx_new * mask,   d_rs[:, H:] = dout_new            (d out_acc = dout_new itself)
+__global__ void __launch_bounds__(256) wn_step_fwd_kernel(const float *__restrict__ x, const float *__restrict__ rs, const float *__restrict__ out_acc,
+                                                          const float *__restrict__ mask, float *__restrict__ x_new, float *__restrict__ out_new, int H, int T) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t >= T) return;
+    const long long o = ((long long)b * H + c) * T + t, r0 = ((long long)b * 2 * H + c) * T + t, r1 = r0 + (long long)H * T;
+    const float *m = mask + (long long)b * T + t;
+    if (t + 4 <= T && (T & 3) == 0) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + o), ra = *reinterpret_cast<const float4 *>(rs + r0), rb = *reinterpret_cast<const float4 *>(rs + r1);
+        const float4 mv = *reinterpret_cast<const float4 *>(m);
+        float4 oa = out_acc ? *reinterpret_cast<const float4 *>(out_acc + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 xn, on;
+        xn.x = (xv.x + ra.x) * mv.x; xn.y = (xv.y + ra.y) * mv.y; xn.z = (xv.z + ra.z) * mv.z; xn.w = (xv.w + ra.w) * mv.w;
+        on.x = oa.x + rb.x; on.y = oa.y + rb.y; on.z = oa.z + rb.z; on.w = oa.w + rb.w;
+        *reinterpret_cast<float4 *>(x_new + o) = xn;
+        *reinterpret_cast<float4 *>(out_new + o) = on;
+    } else {
+        for (int i = 0; i < 4 && t + i < T; ++i) {
+            x_new[o + i] = (x[o + i] + rs[r0 + i]) * m[i];
+            out_new[o + i] = (out_acc ? out_acc[o + i] : 0.f) + rs[r1 + i];
+        }
+    }
+}
+// dx_new / dout_new may be NULL (that output took no gradient): zeros
+__global__ void __launch_bounds__(256) wn_step_bwd_kernel(const float *__restrict__ dx_new, const float *__restrict__ dout_new, const float *__restrict__ mask,
+                                                          float *__restrict__ d_rs, float *__restrict__ dx, int H, int T) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t >= T) return;
+    const long long o = ((long long)b * H + c) * T + t, r0 = ((long long)b * 2 * H + c) * T + t, r1 = r0 + (long long)H * T;
+    const float *m = mask + (long long)b * T + t;
+    for (int i = 0; i < 4 && t + i < T; ++i) {
+        const float v = dx_new ? dx_new[o + i] * m[i] : 0.f;
+        dx[o + i] = v;
+        d_rs[r0 + i] = v;
+        d_rs[r1 + i] = dout_new ? dout_new[o + i] : 0.f;
+    }
+}
+
+// ---- mean |a - b| over n elements (the feature-matching loss, tasks/visinger.py:162-169: one such term per discriminator layer, 54 a step; autograd ran
+// sub / abs / mean forward and div / sgn / mul / neg backward for each).  One launch each way.  Forward: <= 256 workgroups leave fixed-order partial sums in
+// work[0 .. 255]; the last one to finish (a ticket in work[256], reset for the next call) adds them up in index order: deterministic, no second launch.
+__global__ void __launch_bounds__(256) l1_mean_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ work, float *__restrict__ out,
+                                                          long long n, float inv_n) {
+    __shared__ float red[256];
+    __shared__ unsigned ticket;
+    const int tid = threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long i = (long long)blockIdx.x * 1024 + tid; i < n; i += stride) {
+        s0 += fabsf(a[i] - b[i]);
+        if (i + 256 < n) s1 += fabsf(a[i + 256] - b[i + 256]);
+        if (i + 512 < n) s2 += fabsf(a[i + 512] - b[i + 512]);
+        if (i + 768 < n) s3 += fabsf(a[i + 768] - b[i + 768]);
+    }
+    red[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    unsigned *counter = reinterpret_cast<unsigned *>(work + 256);
+    if (tid == 0) {
+        work[blockIdx.x] = red[0];
+        __threadfence();
+        ticket = atomicAdd(counter, 1u);
+    }
+    __syncthreads();
+    if (ticket == gridDim.x - 1) {          // every partial is in memory
+        __threadfence();
+        red[tid] = (tid < (int)gridDim.x) ? __builtin_nontemporal_load(work + tid) : 0.f;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) { out[0] = red[0] * inv_n; *counter = 0u; }
+    }
+}
+// d loss / d a = sign(a - b) * gout / n (sign(0) = 0, as torch.abs' backward); the gradient of b is its negative
+__global__ void __launch_bounds__(256) l1_mean_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ gout,
+                                                          float *__restrict__ da, long long n, float inv_n) {
+    const float g = gout[0] * inv_n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        da[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    }
+}
+
 using namespace vs;
 
 // bias gradient of a conv: gb[c] = sum over (b, t) of gy[b, c, t] -- one workgroup per channel, every thread a fixed strided subset in
@@ -310,6 +405,39 @@ int vs_weight_norm_multi_bwd(const void *table, const void *grads, int64_t n, in
     VS_REQUIRE(table && grads && n > 0 && total_rows > 0 && total_rows <= 4ll * 0x7fffffff, "vs_weight_norm_multi_bwd: bad arguments");
     hipLaunchKernelGGL(weight_norm_multi_bwd_kernel, dim3((unsigned)ceil_div(total_rows, 4)), dim3(256), 0, as_stream(stream),
                        static_cast<const WnEntry *>(table), static_cast<const WnGrad *>(grads), (int)n, (long long)total_rows);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_wn_step_fwd(const float *x, const float *rs, const float *out_acc, const float *mask, float *x_new, float *out_new, int64_t B, int64_t H,
+                   int64_t T, void *stream) {
+    VS_REQUIRE(x && rs && mask && x_new && out_new && B > 0 && B <= 65535 && H > 0 && H <= 65535 && T > 0, "vs_wn_step_fwd: bad arguments");
+    dim3 grid((unsigned)ceil_div(T, 1024), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(wn_step_fwd_kernel, grid, dim3(256), 0, as_stream(stream), x, rs, out_acc, mask, x_new, out_new, (int)H, (int)T);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_wn_step_bwd(const float *dx_new, const float *dout_new, const float *mask, float *d_rs, float *dx, int64_t B, int64_t H, int64_t T, void *stream) {
+    VS_REQUIRE(mask && d_rs && dx && B > 0 && B <= 65535 && H > 0 && H <= 65535 && T > 0, "vs_wn_step_bwd: bad arguments");
+    dim3 grid((unsigned)ceil_div(T, 1024), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(wn_step_bwd_kernel, grid, dim3(256), 0, as_stream(stream), dx_new, dout_new, mask, d_rs, dx, (int)H, (int)T);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_l1_mean_fwd(const float *a, const float *b, float *work, float *out, int64_t n, void *stream) {
+    VS_REQUIRE(a && b && work && out && n > 0, "vs_l1_mean_fwd: bad arguments");
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 1024), 256);
+    hipLaunchKernelGGL(l1_mean_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, work, out, (long long)n, 1.0f / (float)n);
+    VS_CHECK_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int vs_l1_mean_bwd(const float *a, const float *b, const float *gout, float *da, int64_t n, void *stream) {
+    VS_REQUIRE(a && b && gout && da && n > 0, "vs_l1_mean_bwd: bad arguments");
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n, 256), 2048);
+    hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, gout, da, (long long)n, 1.0f / (float)n);
     VS_CHECK_HIP(hipGetLastError());
     return VS_OK;
 }

@@ -47,7 +47,8 @@ def generator_loss(gen_outputs):
 
 def feature_matching_loss(fmap_tgt, fmap_gen):
     """tasks/visinger.py:162-169"""
-    return sum(torch.mean(torch.abs(t.float().detach() - g.float())) for ft, fg in zip(fmap_tgt, fmap_gen) for t, g in zip(ft, fg))
+    from .autograd import l1_mean            # (one launch each way per term where sub / abs / mean and their backward ran eight)
+    return sum(l1_mean(g.float(), t.float()) for ft, fg in zip(fmap_tgt, fmap_gen) for t, g in zip(ft, fg))
 
 
 def pitch_losses(f0_pred, f0, uv, mel2ph, lambda_uv, lambda_f0):
