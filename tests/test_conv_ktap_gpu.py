@@ -321,3 +321,55 @@ def test_ktap_kernel_dispatch_and_fallbacks(vs_option):
     assert inst(120, 128, 7) == "conv_split_kernel<1, 8, 4, 1, 3>"              # C_in not a multiple of 16
     vs_option("VS_NO_KTAP", 1)
     assert inst(128, 128, 7) == "conv_split_kernel<1, 8, 4, 1, 3>"
+
+
+TR_CASES = [
+    # C_in, C_out, k, stride, pad, B, T_in, in_act, acc  -- the generator's upsamplers (decoder.py:36-48: ConvTranspose1d(k = 2 * stride, padding = (k - stride) / 2) behind a leaky-relu)
+    (512, 256, 16, 8, 4, 4, 1024, 1, False),        # stage 1 of the hop-256 generator
+    (256, 128, 16, 8, 4, 2, 2048 + 37, 1, False),   # stage 2, ragged last tile (the element-wise polyphase stores)
+    (128, 64, 4, 2, 1, 3, 8192, 1, False),          # stage 3: stride 2, 128 virtual rows = one row block
+    (128, 64, 4, 2, 1, 2, 4096, 0, False),          # no input transform
+    (256, 128, 8, 4, 2, 2, 3000, 1, True),          # stride 4; + accumulator (the generic epilogue behind the fast one)
+]
+
+
+@pytest.mark.parametrize("case", TR_CASES, ids=lambda c: "c%d-%d_k%d_s%d_B%d_T%d_a%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7]))
+def test_transposed_ktap_instance_is_bit_identical_to_the_tile_kernel(case, vs_option):
+    """conv_ktap_kernel<2, ACT, 2, 4, 4, 1, 8, 1> (conv_ktap.inc IO bit 2: a transposed conv whose every phase uses two of the three packed taps; per-wave first
+    tap, polyphase epilogue) against conv_split_tr_kernel<1, 8, 4, 1, 3>: same planes, same MFMA order (the skipped products are exact zeros), same stores."""
+    from visinger_amd import _lib as L
+    from visinger_amd.ops import ConvOp
+    cin, cout, k, st, pad, B, T, in_act, use_acc = case
+    vs_option("VS_CONV_MATH", 3)
+    vs_option("VS_NO_SMALL_GRID", 1)
+    g = torch.Generator(device="cuda").manual_seed(77 + k + st + cin)
+    op = ConvOp(L.CONV_TRANSPOSE1D, cin, cout, k, st, pad)
+    w = torch.randn(cin, cout, k, device="cuda", generator=g) * (cin * k / st) ** -0.5
+    bias = torch.randn(cout, device="cuda", generator=g) * 0.1
+    op.set_weights(w, None, bias)
+    x = torch.randn(B, cin, T, device="cuda", generator=g)
+    x[:, : cin // 2] *= torch.exp2(torch.randint(-6, 7, (B, cin // 2, 1), device="cuda", generator=g).float())
+    x[0, 5, 100:400] = 2.0 ** 9
+    Tout = op.out_len(T)
+    acc = torch.randn(B, cout, Tout, device="cuda", generator=g) if use_acc else None
+    ia = (L.IN_NONE, L.IN_LRELU)[in_act]
+
+    def run():
+        y = torch.empty((B, cout, Tout), device="cuda")
+        op.forward(x, y=y, acc=acc, in_act=ia)
+        return y, op.kernel_instance()
+
+    vs_option("VS_NO_KTAP", 1)
+    y_ref, k_ref = run()
+    vs_option("VS_NO_KTAP", 0)
+    y_new, k_new = run()
+    assert k_ref == "conv_split_tr_kernel<1, 8, 4, 1, 3>" and k_new == "conv_ktap_kernel<2, %d, 2, 4, 4, 1, 8, 1>" % in_act, (k_ref, k_new)
+    assert torch.equal(y_new, y_ref), float((y_new - y_ref).abs().max())
+    assert torch.equal(run()[0], y_new)
+    xs = x[:1].double()
+    xs = torch.where(xs > 0, xs, 0.1 * xs) if in_act == 1 else xs
+    ref = torch.nn.functional.conv_transpose1d(xs, w.double(), bias.double(), stride=st, padding=pad)
+    if use_acc:
+        ref = ref + acc[:1].double()
+    err = float((y_new[:1].double() - ref).abs().max())
+    assert err <= 3e-6 * float(ref.abs().max()) + 1e-6, err

@@ -186,5 +186,7 @@ int launch_ktap_small(const ConvParams &p, int cfg, hipStream_t s);      // (con
 int launch_ktap_bf16(const ConvParams &p, int cfg, hipStream_t s);
 bool ktap_pair_instance(int terms, int kt, int io, int in_act, int mt);      // conv_ktap_pair.hip: VS_CONV1D_PAIRED, the 128 virtual rows x 128 columns tile
 int launch_ktap_pair(const ConvParams &p, int terms, hipStream_t s);
+bool ktap_tr_instance(const ConvParams &p, int terms, int cfg);               // conv_ktap.hip: VS_CONV_TRANSPOSE1D with two taps per phase (k = 2 * stride), the 128 x 256 tile, split-f16 on fp32 tensors
+int launch_ktap_tr(const ConvParams &p, hipStream_t s);
 
 }  // namespace vs

@@ -1839,6 +1839,11 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         p.row_hi = h->c_out;
         return h->math == VS_MATH_SPLIT3 ? launch_ktap(p, cfg, s) : launch_ktap_bf16(p, cfg, s);
     }
+    if (h->kind == VS_CONV_TRANSPOSE1D && !opt(OPT_NO_KTAP) && !opt(OPT_NO_TR_EPI) && ktap_tr_instance(p, h->math, cfg)) {      // the generator's upsamplers (k = 2 * stride): conv_ktap.inc, IO bit 2
+        p.row_lo = 0;
+        p.row_hi = h->c_out;
+        return launch_ktap_tr(p, s);
+    }
     auto launch = [&](const ConvParams &q) -> int {
         if (h->math) return launch_split(q, cfg, h->math, h->span, s);
         switch (cfg) {

@@ -245,14 +245,14 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         }
         rb_stamp(p, 4 + 4 * c);
         // ---- scale out, bias in; the second conv of a pair adds the residual stream
-        const float inv = (PLANES == 2) ? f16_inv_scale(eb) * p.wscale[c][1] : 1.f;
+        const float isx = (PLANES == 2) ? f16_inv_scale(eb) : 1.f, isw = (PLANES == 2) ? p.wscale[c][1] : 1.f;      // (one after the other: conv_split_body.inc)
         const float *const bias = p.bias[c] + wm * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float bv = bias[(r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
             for (int j = 0; j < NT_W; ++j) {
-                const float v = fmaf(acc[j][r], inv, bv);
+                const float v = fmaf(acc[j][r] * isx, isw, bv);
                 if (second) xr[j][r] += v;
                 else acc[j][r] = v;
             }
