@@ -46,7 +46,7 @@ def values(tag):
     trc = grp("conv_split_tr_kernel", "conv_ktap_kernel<2, 1, 2, 4,")      # the transposed convs (k = 2 * stride on conv_ktap since round 5)
     k3 = stats(f"{tag}_config3_bench_kernel_stats.csv")
     tot3 = sum(float(x["TotalDurationNs"]) for x in k3)
-    vs3 = sum(float(x["TotalDurationNs"]) for x in k3 if "vs::" in x["Name"] or x["Name"].startswith(("bias_grad_kernel", "l1_mean_")))
+    vs3 = sum(float(x["TotalDurationNs"]) for x in k3 if "vs::" in x["Name"] or x["Name"].startswith(("bias_grad_kernel", "l1_mean_", "wn_step_", "weight_norm_multi_")))
     calls3 = sum(int(x["Calls"]) for x in k3)
     steps3 = int(J(f"{tag}_config3_bench_line_profiled.json").get("steps", 5)) + int(J(f"{tag}_config3_bench_line_profiled.json").get("warmup", 2)) + 1
     cb = h["cpu_baseline"]
@@ -57,9 +57,9 @@ def values(tag):
         "DOM_TF": f"{r['achieved']:.0f}", "DOM_MS": f"{r['avg_launch_ms']:.3f}", "DOM_RP": f"{float(rp['AverageNs']) / 1e6:.3f}", "DOM_FRAC": f"{r['frac']:.3f}",
         "DOM_BUSY": f"{mf[key]['mfma_pipe_util']:.2f}", "DOM_GHZ": f"{mf[key]['gfx_clock_ghz']:.2f}", "DOM_EXE": f"{mf[key]['mfma_tflops_executed']:.0f}",
         "K7_BUSY": f"{k7['mfma_pipe_util']:.2f}", "K7_GHZ": f"{k7['gfx_clock_ghz']:.2f}",
-        "DOM_TRAF": f"{(r.get('traffic') or tr.get('hbm_bytes_per_launch', 0)) / 1e9:.2f}", "DOM_ALGB": f"{r['algorithmic_bytes_per_launch'] / 1e9:.2f}",
+        "DOM_TRAF": f"{(r.get('traffic') or tr.get('hbm_bytes_per_launch_corrected', 0)) / 1e9:.2f}", "DOM_ALGB": f"{r['algorithmic_bytes_per_launch'] / 1e9:.2f}",
         "STEP_TF": f"{r['step']['achieved']:.0f}", "STEP_FRAC": f"{r['step']['frac']:.2f}",
-        "STEP_GB": f"{(J(f'{tag}_pmc_traffic.json').get('pass_total', {}) or {}).get('hbm_bytes_per_step', 0) / 1e9:.0f}",
+        "STEP_GB": f"{(J(f'{tag}_pmc_traffic.json').get('pass_total', {}) or {}).get('hbm_bytes_corrected_per_step', 0) / 1e9:.0f}",
         "INST_K11": one("conv_ktap_kernel<11, 1, 2, 0, 4, 1, 8, 1>"), "INST_K7": one("conv_ktap_kernel<7, 1, 2, 0, 4, 1, 8, 1>"),
         "INST_K9": one("conv_ktap_kernel<9, 2, 2, 0, 4, 1, 8, 1>"), "INST_K3": one("conv_ktap_kernel<3, 1, 2, 0, 4, 1, 8, 1>"),
         "INST_RB": f"{rb[0]:.1f} / {rb[1]:.0f}–{rb[2]:.0f}", "RB_MS": f"{rb[0]:.1f}", "INST_TR": f"{trc[0]:.1f} / {trc[1]:.0f}–{trc[2]:.0f}",

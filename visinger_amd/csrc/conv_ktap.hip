@@ -79,11 +79,11 @@ int launch_ktap(const ConvParams &p, int cfg, hipStream_t s) {
 }
 
 // ---- transposed convs (the generator's upsamplers, modules/visinger/decoder.py:36-48: nn.ConvTranspose1d(k = 2 * stride) behind a leaky-relu): conv_ktap.inc IO bit 2.
-// Instance: 128 x 256 tiles, two taps per phase, fp32 tensors, leaky-relu (or no) input transform.  Every phase must use exactly two of the packed taps, a 32-row
+// Instance: 128 x 256 tiles, two taps per phase, fp32 tensors, leaky-relu input transform.  Every phase must use exactly two of the packed taps, a 32-row
 // tile must lie inside one phase and the four row tiles of a workgroup must exist.
 bool ktap_tr_instance(const ConvParams &p, int terms, int cfg) {
     if (terms != 3 || cfg != 0 || p.kind != VS_CONV_TRANSPOSE1D || p.Cin % CK != 0 || p.tstep != -1 || p.KT - 1 > MAX_SPAN || p.x_bf16 || p.y_bf16) return false;
-    if (!(p.in_act == VS_IN_LRELU || p.in_act == VS_IN_NONE) || p.bias_b || p.split_row || (p.c_out % 32) != 0 || (p.MT % 4) != 0 || p.KT < 2 || p.KT > 3) return false;
+    if (p.in_act != VS_IN_LRELU || p.bias_b || p.split_row || (p.c_out % 32) != 0 || (p.MT % 4) != 0 || p.KT < 2 || p.KT > 3) return false;
     for (int phase = 0; phase < p.up; ++phase) {        // (the tap range of conv_split_body.inc / conv_ktap.inc, per phase)
         const int num_lo = -(phase + p.uppad), num_hi = p.upK - 1 - phase - p.uppad;
         const int dlo = (num_lo >= 0) ? (num_lo + p.up - 1) / p.up : -((-num_lo) / p.up);
@@ -98,7 +98,7 @@ int launch_ktap_tr(const ConvParams &p, hipStream_t s) {
         set_error("launch_ktap_tr: not a two-taps-per-phase transposed conv of whole 16-channel chunks on fp32 tensors");
         return VS_EUNSUPPORTED;
     }
-    return p.in_act == VS_IN_LRELU ? launch_ktap_inst<2, VS_IN_LRELU, 2, 4>(p, s) : launch_ktap_inst<2, VS_IN_NONE, 2, 4>(p, s);
+    return launch_ktap_inst<2, VS_IN_LRELU, 2, 4>(p, s);      // (the instance without an input transform -- the training forward's -- spills 728 bytes per lane: not built)
 }
 
 }  // namespace vs

@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_tr_kernel(const ConvParams 
     constexpr bool XB = false;
 #define VS_EPILOGUE_INC "conv_epilogue_tr.inc"
 #define VS_EPI_BIAS_IN_LOOP 1      // (the vector epilogue behind the polyphase stores is the rare path here: no bias register held for it)
+#define VS_EPI_NO_FAST 1           // (... and the row-contiguous fast path never applies to polyphase rows: compiled out)
 #include "conv_split_body.inc"
+#undef VS_EPI_NO_FAST
 #undef VS_EPI_BIAS_IN_LOOP
 #undef VS_EPILOGUE_INC
 }
