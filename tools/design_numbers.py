@@ -62,7 +62,7 @@ def values(tag):
         "STEP_GB": f"{(J(f'{tag}_pmc_traffic.json').get('pass_total', {}) or {}).get('hbm_bytes_corrected_per_step', 0) / 1e9:.0f}",
         "INST_K11": one("conv_ktap_kernel<11, 1, 2, 0, 4, 1, 8, 1>"), "INST_K7": one("conv_ktap_kernel<7, 1, 2, 0, 4, 1, 8, 1>"),
         "INST_K9": one("conv_ktap_kernel<9, 2, 2, 0, 4, 1, 8, 1>"), "INST_K3": one("conv_ktap_kernel<3, 1, 2, 0, 4, 1, 8, 1>"),
-        "INST_RB": f"{rb[0]:.1f} / {rb[1]:.0f}–{rb[2]:.0f}", "RB_MS": f"{rb[0]:.1f}", "INST_TR": f"{trc[0]:.1f} / {trc[1]:.0f}–{trc[2]:.0f}",
+        "INST_RB": f"{rb[0]:.1f} / {rb[1]:.0f}–{rb[2]:.0f}", "RB_MS": f"{rb[0]:.1f}", "INST_TR": f"{trc[0]:.1f} / {trc[1]:.0f}–{trc[2]:.0f}", "TR_MS": f"{trc[0]:.1f}",
         "INST_ATT": one("relattn_bf16_kernel<3, 32, 6>"), "INST_GATE": one("conv_ktap_kernel<5, 0, 2, 0, 2, 2, 2, 2>"),
         "C2_MS": f"{c2['ms_per_step']:.1f}", "C2_MSPS": f"{c2['value'] / 1e6:.1f}", "C3_MS": f"{c3['ms_per_step']:.1f}",
         "C3_LAUNCH": f"{calls3 / steps3:,.0f}".replace(",", " "), "C3_ATEN": f"{1 - vs3 / tot3:.2f}", "C3_DEV": f"{tot3 / 1e6 / steps3:.1f}",
