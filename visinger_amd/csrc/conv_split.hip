@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(256, 2) conv_split_tr_kernel_bf16io(const Conv
     constexpr bool XB = true;
     constexpr bool EPI_YB = true;
 #define VS_EPILOGUE_INC "conv_epilogue_tr_bf16.inc"
+#define VS_EPI_NO_FAST 1
 #include "conv_split_body.inc"
+#undef VS_EPI_NO_FAST
 #undef VS_EPILOGUE_INC
 }
 
