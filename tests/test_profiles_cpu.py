@@ -2,6 +2,7 @@
 import csv
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOM = "conv_split_kernel<1,8,4,1,6>"
@@ -185,7 +186,7 @@ def test_round4_profiles_parse_and_agree(tag, ms_max, c5_max, c3_max):
 
 
 
-@pytest.mark.parametrize("tag", ["r05_a"])
+@pytest.mark.parametrize("tag", ["r05_a", "r05_b"])
 def test_round5_profiles_parse_and_agree(tag):
     """profiles/r05_a_* (`tools/profile_round.sh r05_a`, `r05_a_config{2,3,5} --config N`): the dominant instance is conv_ktap_kernel (taps unrolled, staging in the MFMA
     shadows: DESIGN.md 4.2); rocprofv3's average launch equals the HIP-event average of the same run; the MFMA-counter pass shows the pipe >= 70 % busy in it (VERDICT r4 next #2's
@@ -222,3 +223,14 @@ def test_round5_profiles_parse_and_agree(tag):
     assert t3["steps_in_pass"] == 3 and t3["hbm_bytes_corrected_per_step"] > 1e10
     assert bench.pmc_step_traffic("c3_B16_T512_h192_hop256_f32")["bytes_per_step"] > 1e10
     assert bench.pmc_traffic(dom, "c2_B8_T512_h192_hop256_f32")["source"].startswith("recorded: profiles/r05_")       # config 2's own shapes
+    if tag == "r05_b":      # the committed end state: the transposed convs on their conv_ktap instance, the training step's launch census, DESIGN.md's numbers
+        assert "void vs::conv_ktap_kernel<2, 1, 2, 4, 4, 1, 8, 1>(vs::ConvParams)" in rows and not any("conv_split_tr_kernel<1, 8, 4, 1, 3>" in n for n in rows)
+        assert c3["ms_per_step"] < 86.0
+        census = open(os.path.join(ROOT, "profiles", f"{tag}_config3_launch_census.txt")).read()
+        m = re.search(r"kernel launches: (\d+), device time ([0-9.]+) ms", census)
+        assert int(m.group(1)) < 4100 and float(m.group(2)) < 83.0
+        k3 = open(os.path.join(ROOT, "profiles", f"{tag}_config3_bench_kernel_stats.csv")).read()
+        for name in ("pack_conv_multi_kernel", "weight_norm_multi_fwd_kernel", "weight_norm_multi_bwd_kernel", "wgrad_finish_kernel", "wn_step_fwd_kernel", "l1_mean_fwd_kernel"):
+            assert name in k3, name
+        design = open(os.path.join(ROOT, "DESIGN.md")).read()
+        assert f"**{head['ms_per_step']:.1f} ms/step" in design and f"`frac` {r['frac']:.3f}" in design and f"{int(m.group(1)):,d}".replace(",", " ") + " launches" in design

@@ -49,6 +49,11 @@ def values(tag):
     vs3 = sum(float(x["TotalDurationNs"]) for x in k3 if "vs::" in x["Name"] or x["Name"].startswith(("bias_grad_kernel", "l1_mean_", "wn_step_", "weight_norm_multi_")))
     calls3 = sum(int(x["Calls"]) for x in k3)
     steps3 = int(J(f"{tag}_config3_bench_line_profiled.json").get("steps", 5)) + int(J(f"{tag}_config3_bench_line_profiled.json").get("warmup", 2)) + 1
+    # launches and device time of ONE steady-state step by the torch profiler (tools/train_launch_count.py); rocprofv3's totals include the first step, which
+    # creates and packs every handle one by one
+    census = open(os.path.join(P, f"{tag}_config3_launch_census.txt")).read()
+    m = re.search(r"kernel launches: (\d+), device time ([0-9.]+) ms", census)
+    launches3, dev3 = int(m.group(1)), float(m.group(2))
     cb = h["cpu_baseline"]
     v = {
         "HEAD_MS": f"{h['ms_per_step']:.1f}", "HEAD_MSPS": f"{h['value'] / 1e6:.1f}", "F32_MS": f"{h['fp32_mfma_engine']['ms_per_step']:.1f}",
@@ -65,7 +70,7 @@ def values(tag):
         "INST_RB": f"{rb[0]:.1f} / {rb[1]:.0f}–{rb[2]:.0f}", "RB_MS": f"{rb[0]:.1f}", "INST_TR": f"{trc[0]:.1f} / {trc[1]:.0f}–{trc[2]:.0f}", "TR_MS": f"{trc[0]:.1f}",
         "INST_ATT": one("relattn_bf16_kernel<3, 32, 6>"), "INST_GATE": one("conv_ktap_kernel<5, 0, 2, 0, 2, 2, 2, 2>"),
         "C2_MS": f"{c2['ms_per_step']:.1f}", "C2_MSPS": f"{c2['value'] / 1e6:.1f}", "C3_MS": f"{c3['ms_per_step']:.1f}",
-        "C3_LAUNCH": f"{calls3 / steps3:,.0f}".replace(",", " "), "C3_ATEN": f"{1 - vs3 / tot3:.2f}", "C3_DEV": f"{tot3 / 1e6 / steps3:.1f}",
+        "C3_LAUNCH": f"{launches3:,d}".replace(",", " "), "C3_RP_LAUNCH": f"{calls3 / steps3:,.0f}".replace(",", " "), "C3_ATEN": f"{1 - vs3 / tot3:.2f}", "C3_DEV": f"{dev3:.1f}",
         "C5_MS": f"{c5['ms_per_step']:.1f}", "C5_MSPS": f"{c5['value'] / 1e6:.1f}", "C5ERR": f"{c5['oracle_check']['layer_rms_rel_err']:.1e}",
     }
     return v
