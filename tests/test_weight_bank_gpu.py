@@ -18,7 +18,8 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_batched_weight_norm_matches_torch_autograd():
+@pytest.mark.parametrize("per_tensor", [False, True])
+def test_batched_weight_norm_matches_torch_autograd(per_tensor):
     from visinger_amd.weight_bank import WeightBank
     torch.manual_seed(0)
     net = torch.nn.ModuleList([
@@ -29,7 +30,7 @@ def test_batched_weight_norm_matches_torch_autograd():
         torch.nn.utils.weight_norm(torch.nn.Conv1d(1024, 1, 3)),
         torch.nn.Conv1d(4, 4, 3),                                        # (no weight norm: not the bank's business)
     ]).cuda()
-    bank = WeightBank(net)
+    bank = WeightBank(net, per_tensor_backward=per_tensor)      # (True: the per-tensor backward nodes taken under data parallelism)
     bank.refresh()
     ws = [m.__dict__["_w_eff"] for m in list(net)[:5]]
     cs = [torch.randn_like(w) for w in ws]

@@ -10,7 +10,8 @@ adjoint handle of its grad-input).  Per training step that was 256 + 182 weight-
 
 * one launch folds every weight-normed tensor of the network (vs_weight_norm_multi_fwd) into a persistent flat buffer; the folded
   weights are the outputs of ONE autograd node whose backward (vs_weight_norm_multi_bwd, one launch) runs when all the weight
-  gradients of the pass have arrived;
+  gradients of the pass have arrived -- or, under data parallelism, of one light node per tensor (torch's own backward each), so
+  that DistributedDataParallel's bucketed all-reduce keeps overlapping the backward;
 * two launches pack every conv handle whose packed weights are stale (vs_conv_set_weights_batch).
 
 The modules then find their weight in ``module.__dict__["_w_eff"]`` (autograd.effective_weight, discriminator._live_params) and their
@@ -60,9 +61,33 @@ class _BatchedWeightNorm(torch.autograd.Function):
         return tuple(grads)
 
 
+class _FoldedSlot(torch.autograd.Function):
+    """One tensor of a batch that vs_weight_norm_multi_fwd has already folded: the forward hands out its view of the buffer, the backward is torch's own
+    per-tensor weight-norm backward.  Used under data parallelism: every weight-normed gradient then leaves the graph when its conv's weight gradient arrives,
+    and DistributedDataParallel overlaps the bucketed all-reduce with the rest of the backward -- the single batched node delivers all of them at the very
+    end (one launch instead of ~180, but nothing left to overlap with)."""
+
+    @staticmethod
+    def forward(ctx, v, g, w_view, norm_view):
+        ctx.save_for_backward(v, g, norm_view)
+        return w_view.view(w_view.shape)
+
+    @staticmethod
+    def backward(ctx, gw):
+        v, g, norm = ctx.saved_tensors
+        gv, gg = torch.ops.aten._weight_norm_interface_backward(gw.contiguous(), v, g, norm.view(g.shape), 0)
+        return gv, gg, None, None
+
+
+def _data_parallel():
+    d = torch.distributed
+    return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
+
 class WeightBank:
-    def __init__(self, net):
+    def __init__(self, net, per_tensor_backward=None):
         self.net = net
+        self.per_tensor_backward = per_tensor_backward      # None: per-tensor backward nodes under data parallelism, the batched node otherwise
         self._state = None
         self._gen = 0
         self._live = []
@@ -113,7 +138,15 @@ class WeightBank:
         self._gen += 1
         st["gen"] = self._gen
         if st["n"]:
-            ws = _BatchedWeightNorm.apply(self, *st["params"])
+            split = _data_parallel() if self.per_tensor_backward is None else self.per_tensor_backward
+            if split and any(p.requires_grad for p in st["params"]):
+                L.check(L.require_gpu().vs_weight_norm_multi_fwd(st["table"].data_ptr(), st["n"], st["total_rows"], L.stream_ptr()))
+                ws, row0 = [], 0
+                for m, (o, nel, shape), r in zip(st["mods"], st["wviews"], st["rows"]):
+                    ws.append(_FoldedSlot.apply(m.weight_v, m.weight_g, st["wbuf"][o:o + nel].view(shape), st["nbuf"][row0:row0 + r]))
+                    row0 += r
+            else:
+                ws = _BatchedWeightNorm.apply(self, *st["params"])
             for m, w in zip(st["mods"], ws):
                 m.__dict__["_w_eff"] = w
             self._live = st["mods"]
