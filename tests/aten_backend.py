@@ -15,12 +15,16 @@ def aten_backend():
     from visinger_amd import autograd as A
     from visinger_amd.modules import discriminator as D
 
-    def conv(m, x):
+    def conv(m, x, lrelu=False, res=None):
         """reference modules' Conv1d / ConvTranspose1d under weight norm (e.g. modules/visinger/decoder.py:24, 72-87) on aten"""
         w = A.effective_weight(m)
+        if lrelu:
+            x = F.leaky_relu(x, A.LRELU_SLOPE)
         if m._kind == L.CONV_TRANSPOSE1D:
-            return F.conv_transpose1d(x, w, m.bias, stride=m.stride[0], padding=m.padding[0])
-        return F.conv1d(x, w, m.bias, padding=m.padding[0], dilation=m.dilation[0])
+            y = F.conv_transpose1d(x, w, m.bias, stride=m.stride[0], padding=m.padding[0])
+        else:
+            y = F.conv1d(x, w, m.bias, padding=m.padding[0], dilation=m.dilation[0])
+        return y if res is None else y + res
 
     def disc_conv1d(holder, x, w, b, stride, pad, groups=1):
         """modules/discriminator.py:28-47, 64-75: the discriminators' strided / grouped convs on aten"""

@@ -60,7 +60,9 @@ class HipConvFn(torch.autograd.Function):
     """y = conv(x, w, b) with the forward on the HIP engine and the backward through torch.nn.functional."""
 
     @staticmethod
-    def forward(ctx, x, w, b, module):
+    def forward(ctx, x, w, b, module, lrelu=False, res=None):
+        """lrelu: y = conv(leaky_relu(x)) with the activation applied on the conv's load path; res: + res in its epilogue (the two neighbours of every conv
+        of a HiFi-GAN residual pair, decoder.py:92-101 -- three PyTorch launches per pair forward and their saved outputs)"""
         x = x.contiguous().float()
         op = module._op(bind=False)
         key = param_key(module)
@@ -71,11 +73,15 @@ class HipConvFn(torch.autograd.Function):
                 op.set_weights_pair(adj, w, b, key)
             else:
                 op.set_weights_from(w, b, key)
-        y = op.forward(x)
+        if lrelu or res is not None:
+            y = op.forward(x, in_act=L.IN_LRELU if lrelu else L.IN_NONE, res=None if res is None else res.contiguous().float())
+        else:
+            y = op.forward(x)
         ctx.module = module
         ctx.wkey = key                  # the backward handles pack the adjoint of THIS weight: keyed by the forward's key, not by the parameters' state at backward time
         ctx.save_for_backward(x, w, b if b is not None else x.new_empty(0))
         ctx.has_bias = b is not None
+        ctx.lrelu, ctx.has_res = bool(lrelu), res is not None
         return y
 
     @staticmethod
@@ -84,10 +90,14 @@ class HipConvFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         gy = gy.contiguous()
         want_b = bool(need[2] and ctx.has_bias)
-        gx, gw, gb = conv_backward(ctx.module, x, w, gy, bool(need[0]), bool(need[1]), key=ctx.wkey, need_b=want_b)
+        # (lrelu: the conv's input was leaky_relu(x): recomputed for the weight gradient -- one launch, nothing saved -- and its derivative applied to the grad-input)
+        xin = F.leaky_relu(x, LRELU_SLOPE) if (ctx.lrelu and need[1]) else x
+        gx, gw, gb = conv_backward(ctx.module, xin, w, gy, bool(need[0]), bool(need[1]), key=ctx.wkey, need_b=want_b)
+        if ctx.lrelu and gx is not None:
+            gx = torch.ops.aten.leaky_relu_backward(gx, x, LRELU_SLOPE, False)
         if want_b and gb is None:
             gb = bias_grad(gy)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None, (gy if (ctx.has_res and need[5]) else None)
 
 
 def _bwd_op(module, key, *args):
@@ -291,9 +301,9 @@ def effective_weight(m):
     return m.weight
 
 
-def conv(m, x):
-    """differentiable conv through HipConv1d / HipConvTranspose1d `m`"""
-    return HipConvFn.apply(x, effective_weight(m), m.bias, m)
+def conv(m, x, lrelu=False, res=None):
+    """differentiable conv through HipConv1d / HipConvTranspose1d `m`; lrelu / res: y = conv(leaky_relu(x)) + res in the one launch (stride-1 convs)"""
+    return HipConvFn.apply(x, effective_weight(m), m.bias, m, lrelu, res)
 
 
 def training_path(module):
@@ -506,7 +516,11 @@ def flow_block(m, x, x_mask, g=None, reverse=False):
 
 def resblock1(m, x, x_mask=None):
     """decoder.py:91-104"""
+    fuse = x_mask is None and x.is_cuda and x.dtype == torch.float32 and not L.switch("VS_NO_TRAIN_FUSED")
     for c1, c2 in zip(m.convs1, m.convs2):
+        if fuse:      # both activations on the convs' load paths, the residual add in the second conv's epilogue: two launches where five ran
+            x = conv(c2, conv(c1, x, lrelu=True), lrelu=True, res=x)
+            continue
         xt = F.leaky_relu(x, LRELU_SLOPE)
         if x_mask is not None:
             xt = xt * x_mask
@@ -676,7 +690,7 @@ def attention(m, x, frame_mask):
                 holder.__dict__["_hip_math"] = arith
             wqkv = torch.cat([m.conv_q.weight, m.conv_k.weight, m.conv_v.weight], 0)
             bqkv = torch.cat([m.conv_q.bias, m.conv_k.bias, m.conv_v.bias], 0)
-            out = AttnCoreFn.apply(HipConvFn.apply(x, wqkv, bqkv, holder), None, None, rel_k, rel_v, frame_mask, nh, w if w is not None else -1, pd)
+            out = AttnCoreFn.apply(HipConvFn.apply(x, wqkv, bqkv, holder, False, None), None, None, rel_k, rel_v, frame_mask, nh, w if w is not None else -1, pd)
         else:
             out = AttnCoreFn.apply(conv(m.conv_q, x), conv(m.conv_k, x), conv(m.conv_v, x), rel_k, rel_v, frame_mask, nh,
                                    w if w is not None else -1, pd)
