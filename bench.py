@@ -802,12 +802,15 @@ def main():
         details = {"headline": out, "other_configs": {}}
         lines = []
         if headline and not args.no_other_configs:
-            # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each after 3 warm-up steps): one compact line each,
+            # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each -- 20 for the training step -- after 6 warm-up steps): one compact line each,
             # printed BEFORE the headline line (the driver parses the last line of stdout)
             del wl, model, out_dev, wav
             torch.cuda.empty_cache()
             for c in (2, 3, 5):
-                oc = other_config_line(c, dev, 10, 3, barrier)
+                # (six warm-up steps: a training step's first creates and packs every conv handle one by one, the second builds the weight bank's tables and the
+                #  grad-input handles' packs; the caching allocator of every configuration settles over the next few -- with three, the long-form step read
+                #  54.9-59.5 ms across boxes where its own run reads 56.2)
+                oc = other_config_line(c, dev, 20 if c == 3 else 10, 6, barrier)      # (the training step is as much host- as device-bound: 20 steps average its jitter)
                 oc["n_gpus"] = 1
                 details["other_configs"][str(c)] = oc
                 lines.append(compact_line(oc, CONFIGS[c].get("math", "split3")))
