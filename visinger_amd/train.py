@@ -173,7 +173,7 @@ class VISingerTrainer(nn.Module):
     def _weight_banks(self, optimizer_idx):
         """the networks whose weights the pass derives: folded and packed in a handful of launches before the forward (weight_bank.py)"""
         from ._lib import switch
-        if switch("VS_NO_WEIGHT_BANK") or not (self.training and torch.is_grad_enabled()) or not next(self.parameters()).is_cuda:
+        if switch("VS_NO_WEIGHT_BANK") or not (self.training and torch.is_grad_enabled()) or not self._param_lists()[0][0].is_cuda:
             return ()
         if self.__dict__.get("_banks") is None:
             from .weight_bank import WeightBank
@@ -182,14 +182,32 @@ class VISingerTrainer(nn.Module):
         disc_on = self.global_step >= self.hp["disc_start_steps"] and self.hp["lambda_mel_adv"] > 0
         return ((bg, bd) if disc_on else (bg,)) if optimizer_idx == 0 else (bd,)
 
+    def train(self, mode=True):
+        """(also drops the per-parameter-set caches -- parameter lists, weight banks: structural surgery such as remove_weight_norm happens between mode switches)"""
+        self.__dict__.pop("_plists", None)
+        self.__dict__.pop("_banks", None)
+        return super().train(mode)
+
+    def _param_lists(self):
+        """(generator parameters, discriminator parameters) as lists, built once per parameter set: a step walks them seven times (requires_grad of both
+        networks per pass, the clip norm, the restore) and `Module.parameters()` re-walks ~700 modules each time -- 5 ms of host time a step on a path that is
+        as much host- as device-bound"""
+        c = self.__dict__.get("_plists")
+        n = sum(1 for _ in self._modules)      # (cheap guard against a swapped sub-network)
+        if c is None or c[2] != (id(self.model), id(self.mel_disc), n):
+            c = (list(self.model.parameters()), list(self.mel_disc.parameters()), (id(self.model), id(self.mel_disc), n))
+            self.__dict__["_plists"] = c
+        return c[0], c[1]
+
     def backward_pass(self, batch, opt_idx, runner=None):
         """forward + backward of one optimizer's pass with the other network frozen (trainer.py:312-375): afterwards the gradients of
         `own` are in place -- under DDP already all-reduced (averaged over the ranks)."""
         runner = runner or self
-        own, other = (self.model, self.mel_disc) if opt_idx == 0 else (self.mel_disc, self.model)
-        for p in other.parameters():
+        pg, pd = self._param_lists()
+        own, other = (pg, pd) if opt_idx == 0 else (pd, pg)
+        for p in other:
             p.requires_grad_(False)
-        for p in own.parameters():
+        for p in own:
             p.requires_grad_(True)
         loss, parts = runner(batch, opt_idx)
         loss.backward()                          # under DDP: the bucketed gradient all-reduce over RCCL happens here
@@ -204,13 +222,14 @@ class VISingerTrainer(nn.Module):
         for opt_idx, opt in enumerate((self.opt_gen, self.opt_disc)):
             parts = self.backward_pass(batch, opt_idx, runner)
             if self.hp["clip_grad_norm"] > 0:    # (the other network holds no gradients: zeroed right after ITS step, as below)
-                torch.nn.utils.clip_grad_norm_(self.parameters(), self.hp["clip_grad_norm"])
+                torch.nn.utils.clip_grad_norm_(self._param_lists()[0] + self._param_lists()[1], self.hp["clip_grad_norm"])
             opt.step()
             opt.zero_grad(set_to_none=True)      # trainer.py:373-374: no stale gradients in the next pass's clip norm
             self.on_after_optimization()
             logs.update({k: v.detach() for k, v in parts.items()})
-        for p in self.parameters():
-            p.requires_grad_(True)
+        for plist in self._param_lists():
+            for p in plist:
+                p.requires_grad_(True)
         self.global_step += 1
         # the loss values go to the host ONCE, at the end of the step: reading the generator pass's values before launching the
         # discriminator pass drained the queue in the middle of every step (tools/train_phases.py: 15 ms of host wait, after which the

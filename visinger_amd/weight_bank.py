@@ -94,13 +94,17 @@ class WeightBank:
 
     # -- the weight-normed tensors of the network and their table ---------------------------------------------------------------
     def _scan(self):
+        st = self._state
+        if st is not None:      # (the module walk is done once: a refresh re-checks only that the known tensors still sit where the table says -- a network
+            #                      whose MODULES change needs a new bank)
+            ok = all(isinstance(m._parameters.get("weight_v"), torch.nn.Parameter) for m in st["mods"]) and \
+                st["ident"] == tuple((m.weight_v.data_ptr(), m.weight_g.data_ptr(), tuple(m.weight_v.shape)) for m in st["mods"])
+            if ok:
+                return st
         mods = [m for m in self.net.modules()
                 if isinstance(m.__dict__.get("_parameters", {}).get("weight_g"), torch.nn.Parameter) and
                 isinstance(m._parameters.get("weight_v"), torch.nn.Parameter)]
         ident = tuple((m.weight_v.data_ptr(), m.weight_g.data_ptr(), tuple(m.weight_v.shape)) for m in mods)
-        st = self._state
-        if st is not None and st["ident"] == ident:
-            return st
         for m in mods:
             v, g = m.weight_v, m.weight_g
             assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and g.is_contiguous() and g.numel() == v.shape[0], \
