@@ -664,6 +664,11 @@ def timed_run(step, steps, warmup, profile, barrier):
     from visinger_amd.ops import PROFILER
     for _ in range(warmup):
         out = step()
+    import gc
+    nogc = not os.environ.get("VS_BENCH_GC")      # (the cyclic collector out of the timed steps, as in train_line)
+    if nogc:
+        gc.collect()
+        gc.disable()
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     if profile:
@@ -675,6 +680,8 @@ def timed_run(step, steps, warmup, profile, barrier):
         marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    if nogc:
+        gc.enable()
     if profile:
         PROFILER.stop()
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
@@ -845,11 +852,21 @@ def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barri
     batch = synthetic_train_batch(B, T, T // 8, tr.hop, 64, hp["num_linear_bins"], 1234 + rank, dev)
     for _ in range(warmup):
         tr.training_step(batch, runner=runner)
+    # Python's cyclic collector stays out of the timed steps, as `timeit` keeps it out of what it times (collected right before, re-enabled right after): a
+    # training step allocates ~10^5 Python objects and a generation-2 pass in the middle of one stalls the launch queue -- 0.3-3 ms a step in A/B runs on one
+    # box (84.1 / 81.7 / 81.4 against 87.2 / 83.8 / 81.8 ms).  VS_BENCH_GC=1 leaves it on.
+    import gc
+    nogc = not os.environ.get("VS_BENCH_GC")
+    if nogc:
+        gc.collect()
+        gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         logs = tr.training_step(batch, runner=runner)
     barrier()
+    if nogc:
+        gc.enable()
     dt = max_over_ranks(time.perf_counter() - t0, device=dev if dist is not None else None)
     PROFILER.start(count_only=True)
     tr.training_step(batch, runner=runner)
