@@ -753,6 +753,18 @@ def main():
             dist.destroy_process_group()
         return
 
+    # BASELINE configs 3 / 2 / 5 of the default run FIRST (one compact line each, printed before the headline line -- the driver parses the last line of
+    # stdout -- 10 timed steps each, 20 for the training step, after 6 warm-up steps).  They used to follow the headline's runs in the same process; the training
+    # step, which is as much host- as device-bound, then read 87-90 ms where its own process reads 81-84 (seven default runs against nine of its own, round 5):
+    # it goes first, before the CPU baselines have started their thread pools and the headline's ~10^5 launches have gone through the runtime.
+    pre = {}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config in (0, 4) and not args.no_other_configs:
+        for c in (3, 2, 5):
+            oc = other_config_line(c, dev, 20 if c == 3 else 10, 6, barrier)
+            oc["n_gpus"] = 1
+            pre[c] = oc
+            torch.cuda.empty_cache()
+
     wl = InferenceWorkload(args.config, B, T, args.hidden, args.math, args.storage, args.hop, args.ragged, dev, rank, world)
     model, hp = wl.model, wl.hp
     out_dev, dt, per_step = timed_run(wl.step, args.steps, args.warmup, True, barrier)
@@ -808,20 +820,10 @@ def main():
             set_conv_math(model, MATH[args.math])
         details = {"headline": out, "other_configs": {}}
         lines = []
-        if headline and not args.no_other_configs:
-            # BASELINE configs 2 / 3 / 5 in the same driver-observed run (10 timed steps each -- 20 for the training step -- after 6 warm-up steps): one compact line each,
-            # printed BEFORE the headline line (the driver parses the last line of stdout)
-            del wl, model, out_dev, wav
-            torch.cuda.empty_cache()
-            for c in (2, 3, 5):
-                # (six warm-up steps: a training step's first creates and packs every conv handle one by one, the second builds the weight bank's tables and the
-                #  grad-input handles' packs; the caching allocator of every configuration settles over the next few -- with three, the long-form step read
-                #  54.9-59.5 ms across boxes where its own run reads 56.2)
-                oc = other_config_line(c, dev, 20 if c == 3 else 10, 6, barrier)      # (the training step is as much host- as device-bound: 20 steps average its jitter)
-                oc["n_gpus"] = 1
-                details["other_configs"][str(c)] = oc
-                lines.append(compact_line(oc, CONFIGS[c].get("math", "split3")))
-                torch.cuda.empty_cache()
+        for c in (2, 3, 5):
+            if c in pre:
+                details["other_configs"][str(c)] = pre[c]
+                lines.append(compact_line(pre[c], CONFIGS[c].get("math", "split3")))
         det = write_details(details)
         for ln in lines:
             print(ln, flush=True)
