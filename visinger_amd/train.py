@@ -182,6 +182,12 @@ class VISingerTrainer(nn.Module):
         disc_on = self.global_step >= self.hp["disc_start_steps"] and self.hp["lambda_mel_adv"] > 0
         return ((bg, bd) if disc_on else (bg,)) if optimizer_idx == 0 else (bd,)
 
+    def __getstate__(self):                  # (the per-parameter-set caches hold device buffers and table pointers: process-local, rebuilt on demand)
+        state = self.__dict__.copy()
+        state.pop("_plists", None)
+        state.pop("_banks", None)
+        return state
+
     def train(self, mode=True):
         """(also drops the per-parameter-set caches -- parameter lists, weight banks: structural surgery such as remove_weight_norm happens between mode switches)"""
         self.__dict__.pop("_plists", None)
