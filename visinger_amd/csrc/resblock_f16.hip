@@ -247,14 +247,23 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         // ---- scale out, bias in; the second conv of a pair adds the residual stream
         const float isx = (PLANES == 2) ? f16_inv_scale(eb) : 1.f, isw = (PLANES == 2) ? p.wscale[c][1] : 1.f;      // (one after the other: conv_split_body.inc)
         const float *const bias = p.bias[c] + wm * 32;
+        // (two values per instruction: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 on the register pairs (r, r + 1) of an accumulator tile)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 isx2 = {isx, isx}, isw2 = {isw, isw};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float bv = bias[(r & 3) + 8 * (r >> 2) + 4 * lh];
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 bv2 = {bias[(r & 3) + 8 * (r >> 2) + 4 * lh], bias[((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh]};
 #pragma unroll
             for (int j = 0; j < NT_W; ++j) {
-                const float v = fmaf(acc[j][r] * isx, isw, bv);
-                if (second) xr[j][r] += v;
-                else acc[j][r] = v;
+                const f32x2 a = {acc[j][r], acc[j][r + 1]};
+                const f32x2 v = __builtin_elementwise_fma(a * isx2, isw2, bv2);
+                if (second) {
+                    f32x2 x2 = {xr[j][r], xr[j][r + 1]};
+                    x2 += v;
+                    xr[j][r] = x2.x; xr[j][r + 1] = x2.y;
+                } else {
+                    acc[j][r] = v.x; acc[j][r + 1] = v.y;
+                }
             }
         }
         rb_stamp(p, 5 + 4 * c);
