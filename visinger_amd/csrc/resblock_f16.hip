@@ -160,14 +160,19 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         const int lh = lane_c >> 5, l5 = lane_c & 31;
         // ---- this conv's input in the accumulator registers: lrelu(x) (first conv of a pair) or lrelu(conv1 + b1) (second), zero outside
         unsigned mkey = 0u;
+        // (0.1 v for two values per instruction: v_pk_mul_f32 on the register pairs of the accumulator tile)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 slope2 = {0.1f, 0.1f};
 #pragma unroll
         for (int j = 0; j < NT_W; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = second ? acc[j][r] : xr[j][r];
-                v = inside[j] ? fmaxf(v, 0.1f * v) : 0.f;
-                acc[j][r] = v;
-                if constexpr (PLANES == 2) mkey = f16_maxkey(mkey, v);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 v2 = second ? f32x2{acc[j][r], acc[j][r + 1]} : f32x2{xr[j][r], xr[j][r + 1]};
+                const f32x2 t2 = v2 * slope2;
+                const float v0 = inside[j] ? fmaxf(v2.x, t2.x) : 0.f, v1 = inside[j] ? fmaxf(v2.y, t2.y) : 0.f;
+                acc[j][r] = v0;
+                acc[j][r + 1] = v1;
+                if constexpr (PLANES == 2) mkey = f16_maxkey(f16_maxkey(mkey, v0), v1);
             }
         // ---- the tile's scale: largest exponent over the four waves (the barrier also ends every wave's reads of the previous tile)
         int eb = 127;
@@ -192,8 +197,10 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
             for (int g = 0; g < 4; ++g) {
                 unsigned d0[PLANES], d1[PLANES];
                 if constexpr (PLANES == 2) {
-                    split_pair_h(acc[j][4 * g] * sx, acc[j][4 * g + 1] * sx, d0);
-                    split_pair_h(acc[j][4 * g + 2] * sx, acc[j][4 * g + 3] * sx, d1);
+                    const f32x2 sx2 = {sx, sx};
+                    const f32x2 a0 = f32x2{acc[j][4 * g], acc[j][4 * g + 1]} * sx2, a1 = f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]} * sx2;      // (v_pk_mul_f32)
+                    split_pair_h(a0.x, a0.y, d0);
+                    split_pair_h(a1.x, a1.y, d1);
                 } else {
                     split_pair<1>(acc[j][4 * g], acc[j][4 * g + 1], d0);
                     split_pair<1>(acc[j][4 * g + 2], acc[j][4 * g + 3], d1);
@@ -248,20 +255,29 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         const float isx = (PLANES == 2) ? f16_inv_scale(eb) : 1.f, isw = (PLANES == 2) ? p.wscale[c][1] : 1.f;      // (one after the other: conv_split_body.inc)
         const float *const bias = p.bias[c] + wm * 32;
         // (two values per instruction: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 on the register pairs (r, r + 1) of an accumulator tile)
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 isx2 = {isx, isx}, isw2 = {isw, isw};
+        // (`second` is wave-uniform: a branch around each form -- as selects inside one loop the update cost two v_cndmask per value)
+        if (second) {
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2 bv2 = {bias[(r & 3) + 8 * (r >> 2) + 4 * lh], bias[((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh]};
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 bv2 = {bias[(r & 3) + 8 * (r >> 2) + 4 * lh], bias[((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh]};
 #pragma unroll
-            for (int j = 0; j < NT_W; ++j) {
-                const f32x2 a = {acc[j][r], acc[j][r + 1]};
-                const f32x2 v = __builtin_elementwise_fma(a * isx2, isw2, bv2);
-                if (second) {
+                for (int j = 0; j < NT_W; ++j) {
+                    const f32x2 a = {acc[j][r], acc[j][r + 1]};
+                    const f32x2 v = __builtin_elementwise_fma(a * isx2, isw2, bv2);
                     f32x2 x2 = {xr[j][r], xr[j][r + 1]};
                     x2 += v;
                     xr[j][r] = x2.x; xr[j][r + 1] = x2.y;
-                } else {
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 bv2 = {bias[(r & 3) + 8 * (r >> 2) + 4 * lh], bias[((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * lh]};
+#pragma unroll
+                for (int j = 0; j < NT_W; ++j) {
+                    const f32x2 a = {acc[j][r], acc[j][r + 1]};
+                    const f32x2 v = __builtin_elementwise_fma(a * isx2, isw2, bv2);
                     acc[j][r] = v.x; acc[j][r + 1] = v.y;
                 }
             }
