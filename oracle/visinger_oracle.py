@@ -67,6 +67,46 @@ _i64 = ctypes.c_int64
 CONV_BACKEND = "c"
 
 
+# Operand rounding (tests only): None = the reference's arithmetic; "bf16" = every matrix-product operand (conv inputs after their input
+# transform, effective conv weights, q / k / v of the attention core) rounded to bfloat16, round-to-nearest-even, products and sums in
+# `dtype` -- the arithmetic BASELINE configs[4] names ("bf16 activations/weights, fp32 accumulate") and the device's VS_MATH_BF16
+# computes.  A parity test of that configuration compares against THIS, so that what is left is accumulation order and roundings that
+# fall on a bf16 boundary, not the 2^-9 operand error itself (VERDICT r5 next #1c).
+OPERAND_ROUNDING = None
+
+
+class operand_rounding:
+    """with operand_rounding("bf16"): ... -- scoped setting of OPERAND_ROUNDING"""
+
+    def __init__(self, mode):
+        assert mode in (None, "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        global OPERAND_ROUNDING
+        self.prev, OPERAND_ROUNDING = OPERAND_ROUNDING, self.mode
+
+    def __exit__(self, *exc):
+        global OPERAND_ROUNDING
+        OPERAND_ROUNDING = self.prev
+
+
+def round_bf16(a):
+    """round-to-nearest-even to bfloat16, returned in a's dtype (NaN / inf pass through)"""
+    a = np.asarray(a)
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    r = np.where(np.isfinite(f), r, f)
+    return r.astype(a.dtype if a.dtype in (np.float32, np.float64) else np.float32)
+
+
+def _operands(*arrays):
+    if OPERAND_ROUNDING is None:
+        return arrays
+    return tuple(None if a is None else round_bf16(a) for a in arrays)
+
+
 def _torch_conv(x, w, bias, transposed, **kw):
     import torch
     import torch.nn.functional as F
@@ -101,6 +141,7 @@ def _get_w(sd, name, dtype):
 def conv1d(x, w, bias=None, dilation=1, padding=0, dtype=np.float64):
     """nn.Conv1d, stride 1, zero padding (all Conv1d sites of the hot path)."""
     x, w, bias = _c(x, dtype), _c(w, dtype), _c(bias, dtype)
+    x, w = _operands(x, w)
     B, Cin, T = x.shape
     Cout, Cin2, K = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
@@ -116,6 +157,7 @@ def conv1d(x, w, bias=None, dilation=1, padding=0, dtype=np.float64):
 def conv_transpose1d(x, w, bias=None, stride=1, padding=0, dtype=np.float64):
     """nn.ConvTranspose1d (decoder.py:24-26,47); w is [Cin, Cout, K]."""
     x, w, bias = _c(x, dtype), _c(w, dtype), _c(bias, dtype)
+    x, w = _operands(x, w)
     B, Cin, T = x.shape
     Cin2, Cout, K = w.shape
     assert Cin == Cin2
@@ -330,6 +372,7 @@ def mha_rel(sd, x, c, attn_mask_1d=None, *, n_heads, window_size=4, return_attn=
     q = conv1d(x, sd["conv_q.weight"], sd["conv_q.bias"], dtype=dtype)
     k = conv1d(c, sd["conv_k.weight"], sd["conv_k.bias"], dtype=dtype)
     v = conv1d(c, sd["conv_v.weight"], sd["conv_v.bias"], dtype=dtype)
+    q, k, v = _operands(q, k, v)
     B, C, T = q.shape
     dk = C // n_heads
     out = np.empty_like(q)

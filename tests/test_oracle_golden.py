@@ -252,3 +252,23 @@ def test_discriminators(oracle):
         close(fmap[-1], a[f"p{p}_fmap_last"], atol=5e-5)
     man = json.load(open(os.path.join(GOLDEN, "mpd_state_dict_manifest.json")))
     assert {k: list(v.shape) for k, v in MultiPeriodDiscriminator().state_dict().items()} == man
+
+
+def test_operand_rounding_mode_is_bf16_rne_and_scoped():
+    """oracle.operand_rounding("bf16") (the referee of BASELINE configs[4]'s arithmetic): round-to-nearest-even to bfloat16 exactly as
+    torch's conversion does, applied to conv / attention operands only, bias and accumulation untouched, and switched off again at scope exit"""
+    import torch
+    from oracle import visinger_oracle as orc
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal(50000) * np.exp(rng.standard_normal(50000) * 6)).astype(np.float32)
+    a[:4] = [0.0, -0.0, np.inf, -np.inf]
+    assert np.array_equal(orc.round_bf16(a), torch.from_numpy(a).to(torch.bfloat16).float().numpy())
+    x = rng.standard_normal((2, 24, 50)); w = rng.standard_normal((8, 24, 5)); b = rng.standard_normal(8)
+    plain = orc.conv1d(x, w, b, padding=2)
+    with orc.operand_rounding("bf16"):
+        rounded = orc.conv1d(x, w, b, padding=2)
+        tr = orc.conv_transpose1d(x, w.transpose(1, 0, 2).copy()[:, :4], None, stride=2, padding=1)
+    want = orc.conv1d(orc.round_bf16(x), orc.round_bf16(w), b, padding=2)
+    assert np.array_equal(rounded, want) and not np.array_equal(rounded, plain)
+    assert np.abs(rounded - plain).max() < 0.2 and tr.shape[1] == 4
+    assert orc.OPERAND_ROUNDING is None and np.array_equal(orc.conv1d(x, w, b, padding=2), plain)
