@@ -278,3 +278,33 @@ def test_isa_lint_finds_full_waits_inside_loops(tmp_path):
         "\ts_waitcnt lgkmcnt(0)",
     ]) + "\n")
     assert mod.scan(str(asm)) == {"_Z6kernelv": [5, 8]}
+
+
+def test_build_gate_refuses_packed_fp32_op_sel_on_the_second_source(tmp_path):
+    """csrc/build.py disassembles every object and fails on v_pk_mul/add/fma_f32 ... op_sel:[_,1] (gfx950: wrong low results in lanes 48-63 beside MFMAs;
+    tools/ubench/pk_opsel_probe.hip).  The scanner on sample lines, on a freshly compiled object that holds the form, and on the objects of the
+    library as built."""
+    import subprocess
+    from visinger_amd.csrc import build
+    isa = "\n".join([
+        "0000000000001000 <_Z1kv>:",
+        "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]            // 000000001000: D3B14000 18020902",
+        "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]                         // broadcast of the low half: fine",
+        "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]                            // first source: fine",
+        "\tv_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[1,1]                            // not arithmetic: fine",
+        "0000000000002000 <_Z1gv>:",
+        "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1]",
+        "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]                  // third source: fine",
+        "\tv_pk_add_f32 v[0:1], v[2:3], v[2:3] op_sel:[0,1] op_sel_hi:[1,0]",
+    ])
+    assert [k for k, _ in build.packed_opsel_hits(isa)] == ["_Z1kv", "_Z1gv", "_Z1gv"]
+    src = tmp_path / "k.hip"
+    src.write_text('#include <hip/hip_runtime.h>\ntypedef unsigned long long u64;\n__global__ void k(const u64 *a, u64 *y) {\n'
+                   '    u64 r; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(r) : "v"(a[threadIdx.x]), "v"(a[threadIdx.x + 64]));\n'
+                   '    y[threadIdx.x] = r;\n}\n')
+    obj = tmp_path / "k.o"
+    subprocess.check_call([build.HIPCC, "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(obj)], stderr=subprocess.DEVNULL)
+    with pytest.raises(RuntimeError, match=r"op_sel:\[_,1\]"):
+        build.check_packed_opsel(str(src), str(obj))
+    for unit in ("conv_split", "conv_backward", "resblock_f16"):          # (the units that held such instructions before round 6, and the one that packs by hand)
+        assert build.packed_opsel_hits(build.device_isa(os.path.join(build.HERE, unit + ".o"))) == [], unit

@@ -1,12 +1,16 @@
-"""A masked input transform must be the identity where the mask is 1, and a launch must give the same bits every time.
+"""A masked input transform must be the identity where the mask is 1, must equal the conv of the pre-masked input bit for bit, and a launch must give the same
+bits every time.
 
-Round 5 found that the plain-bf16 instances of the TILE kernel (conv_split_kernel<..., 1>, csrc/conv_split_body.inc) violate both at production sizes -- B >= 2
-items of T = 4096 frames, two workgroups per CU: with `in_act = VS_IN_MASK` an all-ones mask changed 2-25 % of the outputs by up to 0.7 of their rms, differently
-from run to run, always in the staged columns that lanes 32-63 of every second column group wrote (tools/mask_race_probe.py).  The BASELINE configs[4] transformer
-convs (masked 1 x 1 projections and FFN convs at hidden 512, reference modules/rel_transformer.py:290-345) ran exactly there in round 4; the bf16 tolerances of the
-model-level tests did not see it.  conv_ktap_kernel (csrc/conv_ktap.inc) has no such race and takes over every masked plain-bf16 launch of that configuration:
-this file holds the PRODUCTION dispatch to the two properties at those shapes, in both arithmetics, and checks that the config-5 graph never reaches a legacy
-plain-bf16 instance with a masked input."""
+Round 5 found that the plain-bf16 instances of the TILE kernel (conv_split_kernel<..., 1>, csrc/conv_split_body.inc) violate this at production sizes -- two
+workgroups per CU: with `in_act = VS_IN_MASK` an all-ones mask changed 2-25 % of the outputs by up to 0.7 of their rms, differently from run to run, always in
+lanes 48-63 of a staged column group (tools/mask_race_probe.py).  Round 6 root-caused it (tools/mask_race_probe2.py, tools/ubench/pk_opsel_probe.hip, DESIGN.md
+4.5): NOT a race in the kernel's protocol but an instruction form -- hipcc's SLP vectoriser had paired `value * mask` into
+`v_pk_mul_f32 d, a, m op_sel:[0,1] op_sel_hi:[1,0]`, and on gfx950 a packed-fp32 instruction whose low result reads the HIGH register of its second source returns
+wrong low results in lanes 48-63 while the other wave of its SIMD issues MFMAs (standalone: 0.1-0.5 % of such instructions, none with one wave per SIMD, none for
+any other op_sel form).  The multiply is an opaque scalar instruction now (conv_common.h: mul_f32_scalar) and csrc/build.py fails the build on any such
+instruction in any object.  This file holds BOTH dispatches -- conv_ktap_kernel and, under VS_NO_KTAP=1, the legacy tile kernel -- to the three properties at the
+shapes where it showed, plus tap counts / channel counts that only the tile kernel serves (k = 5, k = 4, C_in = 200), in both arithmetics, with all-ones and
+with ragged masks (the split-f16 path multiplied IN PLACE: there a dropped lane left the unmasked value behind, which an all-ones mask cannot see)."""
 import pytest
 import torch
 
@@ -22,6 +26,45 @@ SHAPES = [   # C_in, C_out, k, B, T
     (192, 768, 9, 32, 1024),      # the headline's width
     (768, 192, 1, 32, 1024),
 ]
+
+
+LEGACY_ONLY_SHAPES = [      # no conv_ktap instance: the tile kernel serves these in production too
+    (512, 1536, 5, 2, 4096),      # k = 5 on unpaired rows
+    (512, 1536, 4, 2, 4096),      # an even tap count
+    (200, 1536, 1, 2, 4096),      # C_in not a multiple of 16 (the last chunk is partly padding)
+]
+
+
+@pytest.mark.parametrize("math", [1, 3], ids=["bf16", "split3"])
+@pytest.mark.parametrize("noktap", [0, 1], ids=["ktap", "legacy"])
+@pytest.mark.parametrize("shape", SHAPES + LEGACY_ONLY_SHAPES, ids=lambda s: "c%d-%d_k%d_B%d_T%d" % s)
+def test_masked_launch_equals_the_conv_of_the_premasked_input(shape, math, noktap, vs_option):
+    """y(x, IN_MASK, m) == y(x * m, IN_NONE) bit for bit for a ragged 0 / 1 mask (x * 1 = x and x * 0 = 0 exactly, so the two launches stage identical
+    values): a lane whose masked value was dropped shows up as the un-masked x in a padded frame, leaking into the valid outputs through the taps.  Four runs,
+    other work in between (different co-residency every time)."""
+    from visinger_amd import _lib as L
+    from visinger_amd.ops import ConvOp
+    cin, cout, k, B, T = shape
+    vs_option("VS_CONV_MATH", math)
+    vs_option("VS_NO_KTAP", noktap)
+    vs_option("VS_NO_SMALL_GRID", 1)
+    g = torch.Generator(device="cuda").manual_seed(23 + cin + k)
+    op = ConvOp(L.CONV1D, cin, cout, k, 1, k // 2)
+    op.set_weights(torch.randn(cout, cin, k, device="cuda", generator=g) * (cin * k) ** -0.5, None, torch.randn(cout, device="cuda", generator=g) * 0.1)
+    x = torch.randn(B, cin, T, device="cuda", generator=g)
+    lens = torch.randint(T // 3, T, (B,), device="cuda", generator=g)
+    lens[0] = T
+    mask = (torch.arange(T, device="cuda")[None] < lens[:, None]).float()
+    want = op.forward((x * mask[:, None]).contiguous(), in_act=L.IN_NONE).clone()
+    for _ in range(4):
+        got = op.forward(x, in_act=L.IN_MASK, mask=mask).clone()
+        name = op.kernel_instance()
+        op.forward(torch.randn_like(x), in_act=L.IN_MASK, mask=mask)
+        assert torch.equal(got, want), (name, float((got - want).abs().max()), int((got != want).sum()))
+    if noktap:
+        assert not name.startswith("conv_ktap_kernel<"), name
+    ones = torch.ones_like(mask)
+    assert torch.equal(op.forward(x, in_act=L.IN_MASK, mask=ones), op.forward(x, in_act=L.IN_NONE)), name
 
 
 @pytest.mark.parametrize("math", [1, 3], ids=["bf16", "split3"])

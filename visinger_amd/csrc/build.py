@@ -39,6 +39,48 @@ def check_no_scratch(src, remarks):
         raise RuntimeError(f"{src}: kernels with hand-counted vmcnt waits must not use scratch: {bad}")
 
 
+# gfx950, round 6 (tools/ubench/pk_opsel_probe.hip, conv_common.h): v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 with the op_sel bit of their SECOND source set (the low
+# result reads the high register of src1) return wrong low results in lanes 48-63 beside a wave that issues MFMAs.  hipcc's SLP vectoriser forms them from scalar code
+# whenever it likes, so every object is disassembled and the build fails on one.
+LLVM_BIN = os.environ.get("VS_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+PK_OPSEL_SRC1 = r"\bv_pk_(?:mul|add|fma)_f32\b[^\n]*\bop_sel:\[[01],1"
+
+
+def device_isa(obj):
+    """gfx950 disassembly of the device code bundled in a host object"""
+    fat, co = obj + ".fat.tmp", obj + ".co.tmp"
+    try:
+        subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj])
+        subprocess.check_call([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               "--input=" + fat, "--output=" + co], stderr=subprocess.DEVNULL)
+        return subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        for f in (fat, co):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def packed_opsel_hits(isa):
+    """(kernel symbol, instruction) of every packed-fp32 instruction whose low result reads the high register of src1"""
+    import re
+    hits, name = [], None
+    for line in isa.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            name = m.group(1)
+        elif re.search(PK_OPSEL_SRC1, line):
+            hits.append((name, line.split("//")[0].strip()))
+    return hits
+
+
+def check_packed_opsel(src, obj):
+    hits = packed_opsel_hits(device_isa(obj))
+    if hits:
+        kernels = sorted({k for k, _ in hits})
+        raise RuntimeError(f"{src}: {len(hits)} packed-fp32 instruction(s) with op_sel:[_,1] (wrong low results in lanes 48-63 beside MFMAs on gfx950; "
+                           f"conv_common.h: mul_f32_scalar / add_f32_scalar) in {len(kernels)} kernel(s), e.g. {kernels[0]}: {hits[0][1]}")
+
+
 def sources():
     return sorted(glob.glob(os.path.join(HERE, "*.hip")))
 
@@ -140,6 +182,7 @@ def build(force=False, verbose=True):
                 raise RuntimeError(f"hipcc failed on {src}")
             if guarded:
                 check_no_scratch(src, err)
+            check_packed_opsel(src, tmp)
             os.replace(tmp, obj)
         except RuntimeError as e:
             failed = failed or e

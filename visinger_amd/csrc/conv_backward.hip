@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_split_kernel(const WgradPar
 #pragma unroll
             for (int i = 0; i < NP; i += 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(gr + i);
-                bsum += (v.x + v.y) + (v.z + v.w);
+                // (scalar adds: as `(v.x + v.y) + (v.z + v.w)` this became v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0], the form conv_common.h describes)
+                bsum += add_f32_scalar(add_f32_scalar(v.x, v.y), add_f32_scalar(v.z, v.w));
             }
         }
         const float *ga = Gs + (cot * 32 + l31) * WS_GP + 8 * lhalf;

@@ -1826,8 +1826,9 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
     // the next chunk dealt out over the MFMA gaps of the current one (conv_ktap.inc; bit-identical to the tile kernels, VS_NO_KTAP=1: A/B); likewise the
     // plain-bf16 arithmetic (BASELINE configs[4]: the hidden-512 transformer convs on fp32 tensors, the generator's wide convs on bf16-resident tensors)
     // ... and the 64 x 256 / 32 x 128 tiles of short launches (T_mel-sized tensors, the training step): conv_ktap_small.hip
-    // (plain bf16 behind a MASKED input transform: the tile kernel's instances race there -- DESIGN.md 4.5 -- so a launch whose chosen tile shape has no conv_ktap
-    //  instance takes another shape that has one before it falls back to them)
+    // (plain bf16 behind a MASKED input transform: a launch whose chosen tile shape has no conv_ktap instance takes another shape that has one before it falls back to
+    //  the tile kernel -- round 5 did this for safety, the tile kernel's masked instances gave wrong lanes then; round 6 root-caused and fixed that, DESIGN.md 4.5,
+    //  tests/test_conv_mask_race_gpu.py, and the preference stays because the conv_ktap instances are faster)
     if (h->math == VS_MATH_BF16 && p.in_act >= VS_IN_MASK && h->kind == VS_CONV1D && !opt(OPT_NO_KTAP) && p.Cin % CK == 0 && !p.x_bf16 && !p.y_bf16 &&
         !ktap_instance(h->math, cfg, h->KT, 0, p.in_act)) {
         for (int alt : {3, 6, 0})

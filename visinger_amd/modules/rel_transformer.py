@@ -40,40 +40,41 @@ class LayerNorm(nn.Module):
 
 
 class SinusoidalPositionalEmbedding(nn.Module):
-    """rel_transformer.py:45-100.  Positions are integer bookkeeping (cumsum of `!= padding_idx`), bit-exact; the
-    table is built on the CPU with the reference's formula and moved to the input's device."""
+    """rel_transformer.py:45-100 -- the fairseq-style table: row p holds sin(p * f_i) for the first half of the columns and cos(p * f_i) for the
+    second, f_i = 10000^(-i / (half - 1)); an odd width gets a zero column, the padding row is zero.  Positions are integer bookkeeping
+    (running count of the non-padding entries), bit-exact on the device (csrc/index_ops.hip); the table is evaluated in fp32 with the
+    reference's operation order, so the looked-up rows equal the reference's bit for bit."""
 
     def __init__(self, embedding_dim, padding_idx, init_size=1024):
         super().__init__()
-        self.embedding_dim = embedding_dim
-        self.padding_idx = padding_idx
-        self.weights = SinusoidalPositionalEmbedding.get_embedding(init_size, embedding_dim, padding_idx)
-        self.register_buffer('_float_tensor', torch.FloatTensor(1))
+        self.embedding_dim, self.padding_idx = embedding_dim, padding_idx
+        self.weights = self.get_embedding(init_size, embedding_dim, padding_idx)
+        self.register_buffer('_float_tensor', torch.FloatTensor(1))          # (the reference's device / dtype anchor; part of its state_dict)
 
     @staticmethod
     def get_embedding(num_embeddings, embedding_dim, padding_idx=None):
-        half_dim = embedding_dim // 2
-        emb = math.log(10000) / (half_dim - 1)
-        emb = torch.exp(torch.arange(half_dim, dtype=torch.float) * -emb)
-        emb = torch.arange(num_embeddings, dtype=torch.float).unsqueeze(1) * emb.unsqueeze(0)
-        emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1).view(num_embeddings, -1)
-        if embedding_dim % 2 == 1:
-            emb = torch.cat([emb, torch.zeros(num_embeddings, 1)], dim=1)
+        half = embedding_dim // 2
+        inv_freq = (torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))).exp()
+        angle = torch.outer(torch.arange(num_embeddings, dtype=torch.float32), inv_freq)              # [positions, half]
+        table = torch.zeros(num_embeddings, embedding_dim)
+        table[:, :half] = angle.sin()
+        table[:, half:2 * half] = angle.cos()
         if padding_idx is not None:
-            emb[padding_idx, :] = 0
-        return emb
+            table[padding_idx].zero_()
+        return table
 
     def make_positions(tensor, padding_idx):
         from ..ops import make_positions as _make_positions_hip
         return _make_positions_hip(tensor, padding_idx)
 
     def forward(self, bsz, seq_len, input):
-        max_pos = self.padding_idx + 1 + seq_len
-        if self.weights is None or max_pos > self.weights.size(0):
-            self.weights = SinusoidalPositionalEmbedding.get_embedding(max_pos, self.embedding_dim, self.padding_idx)
+        rows_needed = self.padding_idx + 1 + seq_len
+        if self.weights is None or self.weights.shape[0] < rows_needed:         # grow the table on demand
+            self.weights = self.get_embedding(rows_needed, self.embedding_dim, self.padding_idx)
         self.weights = self.weights.to(self._float_tensor)
         positions = SinusoidalPositionalEmbedding.make_positions(input, self.padding_idx)
-        return self.weights.index_select(0, positions.view(-1)).view(bsz, seq_len, -1).detach()
+        # ([B * T, D] rows regrouped as [bsz, seq_len, -1]: the text encoder calls this with seq_len = D, see TextEncoder.forward_text_embedding)
+        return torch.nn.functional.embedding(positions.reshape(-1), self.weights).view(bsz, seq_len, -1).detach()
 
 
 class MultiHeadAttention(nn.Module):

@@ -188,15 +188,13 @@ class TextEncoder(nn.Module):
         return _expand_states_hip(enc_out, mel2ph, h_channels_first=True, out_channels_first=True)
 
     def forward_text_embedding(self, text_tokens, pitch_tokens, dur_tokens, nonpadding):
-        # T_ph-sized glue (embedding lookups + one Linear): plain PyTorch-ROCm ops, negligible next to the encoder
-        text_emb = self.ph_emb(text_tokens) * self.embed_scale
-        pitch_emb = self.pitch_emb(pitch_tokens) * self.embed_scale
-        dur_emb = self.dur_emb(dur_tokens) * self.embed_scale
-        token_emb = torch.cat([text_emb, pitch_emb, dur_emb], 2)
-        token_emb = self.linear(token_emb) * nonpadding
+        """encoder.py:42-55: the three token streams embedded, scaled by sqrt(H), concatenated and mixed by one Linear; with use_pos_embed the
+        sinusoidal rows of the running token count are added.  T_ph-sized glue on plain PyTorch-ROCm ops (negligible next to the encoder)."""
+        streams = ((self.ph_emb, text_tokens), (self.pitch_emb, pitch_tokens), (self.dur_emb, dur_tokens))
+        mixed = self.linear(torch.cat([table(ids) * self.embed_scale for table, ids in streams], dim=2)) * nonpadding      # [B, T_ph, H]
         if self.use_pos_embed:
-            pos_in = token_emb[..., 0]
-            # the reference passes seq_len = token_emb.shape[2] (= hidden), reproduced as is (encoder.py:52-54)
-            positions = self.embed_positions(token_emb.shape[0], token_emb.shape[2], pos_in)
-            token_emb = token_emb + positions.transpose(1, 2)
-        return token_emb * nonpadding
+            # the reference hands embed_positions seq_len = mixed.shape[2] (the hidden width, not T_ph) and transposes the result: reproduced
+            # literally -- it type-checks because B * T_ph * H elements come back either way (encoder.py:52-54, SURVEY.md 3.5)
+            batch, _, width = mixed.shape
+            mixed = mixed + self.embed_positions(batch, width, mixed[..., 0]).transpose(1, 2)
+        return mixed * nonpadding
