@@ -105,6 +105,47 @@ def set_activation_storage(module, dtype):
     return module
 
 
+def weight_row_drop_bits(conv):
+    """How far the weakest OUTPUT ROW of a HIP conv sits below the conv's largest weight, in bits: log2(max |w| / min over rows of the row's max |w|) of the
+    effective (weight-norm-folded) weight; all-zero rows do not count.  The split-f16 arithmetic (L.MATH_SPLIT3) packs a conv's weights under ONE power-of-two
+    scale: a row d bits below the largest weight keeps its own largest element to 22 bits while d <= 18, but an element another c bits below that only to
+    40 - d - c bits (absolute floor 2^-25 of the scaled planes) -- INTEGRATION.md 4."""
+    w, g = conv._weights()
+    w = w.detach().float()
+    if g is not None:       # torch.nn.utils.weight_norm, dim 0: w = g * v / ||v|| over every dim but 0
+        w = w * (g.detach().float().reshape(-1, 1, 1) / w.flatten(1).norm(dim=1).clamp_min(1e-30).reshape(-1, 1, 1))
+    out_dim = 1 if isinstance(conv, nn.ConvTranspose1d) else 0
+    row_max = w.abs().amax(dim=[d for d in range(3) if d != out_dim])
+    row_max = row_max[row_max > 0]
+    if row_max.numel() == 0:
+        return 0.0
+    return float(torch.log2(row_max.max() / row_max.min()))
+
+
+def select_math_by_weight_range(module, max_row_drop_bits=10.0, fallback=None):
+    """Load-time check for real checkpoints (call once after load_state_dict; it reads the weights on the host side of the stream: a synchronisation).
+    Every HIP conv under `module` whose weakest output row sits more than `max_row_drop_bits` below its largest weight is switched from the split-f16
+    arithmetic to `fallback` (default L.MATH_SPLIT6: three exact bf16 planes, no scale, any dynamic range, twice the matrix work).  With the default bound a
+    weight 2^-13 below its ROW's largest still carries 17 significant bits.  Returns [(qualified module name, drop in bits)] of the convs it switched.
+    Random-init and weight-normed HiFi-GAN / WaveNet checkpoints sit at 1-6 bits; tests/test_split_robustness_gpu.py drives whole generators with per-channel
+    gains over 2^-10 .. 2^10 through it."""
+    fallback = L.MATH_SPLIT6 if fallback is None else fallback
+    library_default = int(L.get_option("VS_CONV_MATH"))          # (-1: no override -> new handles take the split-f16 arithmetic, csrc/conv_engine.hip vs_conv_create)
+    if library_default < 0:
+        library_default = L.MATH_SPLIT3
+    switched = []
+    for name, m in module.named_modules():
+        if isinstance(m, _HipConvMixin):
+            cur = m.__dict__.get("_hip_math", library_default)
+            if cur != L.MATH_SPLIT3:
+                continue
+            drop = weight_row_drop_bits(m)
+            if drop > max_row_drop_bits:
+                m.__dict__["_hip_math"] = int(fallback)
+                switched.append((name, drop))
+    return switched
+
+
 def repack_weights(module):
     """Drop every packed-weight cache under `module`: the next forward re-folds and re-packs from the live parameters.  The
     cache key (data_ptr, in-place version) of visinger_amd.ops.ConvOp.set_weights follows optimizer steps, ``load_state_dict``
