@@ -103,7 +103,18 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(model, hp, batch, backend="c", wav_dev=None, f0_dev=None, T_cap=1024):
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model, hp, batch, backend="c", wav_dev=None, f0_dev=None, T_cap=1024, runs=3):
     """The CPU oracle (fp32 'port' of the reference arithmetic, oracle/) timed on a bounded sample of the SAME workload and the
     SAME graph as `value` (same weights, pitch predictor on): ITEM 0 of the timed batch (B=1 of the 32, T_mel as timed, capped at
     T_cap).  backend "c": the C/OpenMP restatement; "torch": the same composition with the convolutions (98 % of the CPU time) on stock
@@ -124,16 +135,19 @@ def cpu_baseline(model, hp, batch, backend="c", wav_dev=None, f0_dev=None, T_cap
     T = min(int(mel2ph.shape[1]), T_cap)
     assert T == mel2ph.shape[1], "the baseline runs whole items of the timed batch"
     hint = None if f0_dev is None else (f0_dev[:1, :, 1] <= 0).cpu().numpy()
-    t0 = time.perf_counter()
-    out = orc.visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk, noise, dtype=np.float32, return_all=True, voiced_hint=hint,
-                             hint_tol=1e-3 if hint is not None else 0.0)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(max(1, runs)):           # the median of >= 3 runs
+        t0 = time.perf_counter()
+        out = orc.visinger_infer(sd, hp, text, pitch, dur, mel2ph, spk, noise, dtype=np.float32, return_all=True, voiced_hint=hint,
+                                 hint_tol=1e-3 if hint is not None else 0.0)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     orc.CONV_BACKEND = "c"
     n = out["wav_out"].size
     what = "C+numpy port (OpenMP" if backend == "c" else "numpy composition with torch-CPU oneDNN convolutions (torch threads"
     res = {"value": n / dt, "unit": "audio samples/s", "cores": cores, "kind": "port", "items": 1, "of_items": int(batch[0].shape[0]),
-           "seconds": dt, "samples": int(n),
-           "sample": f"oracle/ fp32 {what}, {cores} threads), item 0 of the timed batch: B=1 T_mel={T} hop={HOP}: {n} samples in {dt:.2f}s; the "
+           "seconds": dt, "samples": int(n), "runs": len(times), "run_seconds": [round(t, 3) for t in times], "cpu": cpu_model_name(),
+           "sample": f"oracle/ fp32 {what}, {cores} threads), median of {len(times)} runs of item 0 of the timed batch: B=1 T_mel={T} hop={HOP}: {n} samples in {dt:.2f}s; the "
                      f"graph `value` times (text-encoder + pitch-predictor + frame-prior + flow-inverse + generator, use_pitch_embed="
                      f"{bool(hp.get('use_pitch_embed'))})"}
     if wav_dev is not None:
@@ -185,9 +199,9 @@ def oracle_check_config5(model, hp, batch, f0_dev):
             "what": f"pitch-predictor encoder layer 0 (hidden {H}, T {T}, plain bf16: the timed run's attention / FFN dispatch, last launch {kernel}) vs oracle.rel_encoder (fp32), item 0"}
 
 
-def cpu_baseline_config2(model, hp, batch, items=2):
-    """BASELINE.md 4 asks for the config-2 shape next to the GPU number: flow inverse + HiFi-GAN decode at T_mel=512, a bounded sample of
-    `items` of the 8 utterances, on the fp32 C/OpenMP port."""
+def cpu_baseline_config2(model, hp, batch, items=8):
+    """BASELINE.md 4 asks for the config-2 shape next to the GPU number: flow inverse + HiFi-GAN decode at T_mel=512, all 8 utterances once
+    (about 20 s of CPU), on the fp32 C/OpenMP port."""
     from oracle import visinger_oracle as orc
     orc.build()
     cores = usable_cores()
@@ -203,7 +217,7 @@ def cpu_baseline_config2(model, hp, batch, items=2):
                         upsample_kernel_sizes=hp["upsample_kernel_sizes"], dtype=np.float32)[:, 0]
     dt = time.perf_counter() - t0
     return {"value": wav.size / dt, "unit": "audio samples/s", "cores": cores, "kind": "port", "items": items, "of_items": int(batch[0].shape[0]),
-            "seconds": dt, "samples": int(wav.size),
+            "seconds": dt, "samples": int(wav.size), "runs": 1, "cpu": cpu_model_name(),
             "sample": f"oracle/ fp32 C+numpy port (OpenMP, {cores} threads), {items} of the 8 items of BASELINE config 2 (flow inverse + "
                       f"HiFi-GAN decode, T_mel={z_p.shape[2]}): {wav.size} samples in {dt:.2f}s"}, wav
 
@@ -565,7 +579,7 @@ def compact_line(full, math=None, details=None):
         out["roofline"] = rc
     c = full.get("cpu_baseline")
     if c:
-        out["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "items", "of_items", "seconds", "samples", "waveform_max_abs_err"))
+        out["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "items", "of_items", "runs", "seconds", "samples", "waveform_max_abs_err"))
         out["cpu_baseline"]["sample"] = c.get("sample", "").split(":")[0][:160]
     for k in ("waveform_max_abs_err", "flow_logdet_rel_err", "generated_samples_per_s"):
         if k in full:
@@ -578,7 +592,7 @@ def compact_line(full, math=None, details=None):
     if "oracle_check" in full:
         out["oracle_check"] = _pick(full["oracle_check"], ("layer_rms_rel_err", "layer_max_abs_err", "tolerance_rms_rel", "seconds"))
     if "cpu_baseline_torch" in full:
-        out["cpu_baseline_torch"] = _pick(full["cpu_baseline_torch"], ("value", "cores", "items", "seconds"))
+        out["cpu_baseline_torch"] = _pick(full["cpu_baseline_torch"], ("value", "cores", "items", "runs", "seconds"))
     if "losses_last_step" in full:
         out["losses_finite"] = bool(all(np.isfinite(v) for v in full["losses_last_step"].values()))
     if details:
@@ -665,23 +679,25 @@ def timed_run(step, steps, warmup, profile, barrier):
     for _ in range(warmup):
         out = step()
     import gc
-    nogc = not os.environ.get("VS_BENCH_GC")      # (the cyclic collector out of the timed steps, as in train_line)
-    if nogc:
+    nogc = not os.environ.get("VS_BENCH_GC") and gc.isenabled()      # (the cyclic collector out of the timed synthesis steps, as `timeit` does; a synthesis
+    if nogc:                                                          #  loop allocates little: 0-0.2 ms a step either way)
         gc.collect()
         gc.disable()
-    barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    if profile:
-        PROFILER.start()
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(steps):
-        out = step()
-        marks[i + 1].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    if nogc:
-        gc.enable()
+    try:
+        barrier()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        if profile:
+            PROFILER.start()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            out = step()
+            marks[i + 1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        if nogc:
+            gc.enable()
     if profile:
         PROFILER.stop()
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
@@ -854,21 +870,15 @@ def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barri
     batch = synthetic_train_batch(B, T, T // 8, tr.hop, 64, hp["num_linear_bins"], 1234 + rank, dev)
     for _ in range(warmup):
         tr.training_step(batch, runner=runner)
-    # Python's cyclic collector stays out of the timed steps, as `timeit` keeps it out of what it times (collected right before, re-enabled right after): a
-    # training step allocates ~10^5 Python objects and a generation-2 pass in the middle of one stalls the launch queue -- 0.3-3 ms a step in A/B runs on one
-    # box (84.1 / 81.7 / 81.4 against 87.2 / 83.8 / 81.8 ms).  VS_BENCH_GC=1 leaves it on.
-    import gc
-    nogc = not os.environ.get("VS_BENCH_GC")
-    if nogc:
-        gc.collect()
-        gc.disable()
+    # (the cyclic collector: VISingerTrainer.training_step keeps it out of a step and runs it between steps every `gc_every` steps -- the PRODUCT's policy since
+    #  round 6 (the benchmark used to switch it off around the timed loop, which a user's loop did not); VS_BENCH_GC=1: the collector left alone)
+    if os.environ.get("VS_BENCH_GC"):
+        tr.gc_every = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         logs = tr.training_step(batch, runner=runner)
     barrier()
-    if nogc:
-        gc.enable()
     dt = max_over_ranks(time.perf_counter() - t0, device=dev if dist is not None else None)
     PROFILER.start(count_only=True)
     tr.training_step(batch, runner=runner)

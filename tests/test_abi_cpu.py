@@ -95,6 +95,12 @@ def test_arguments_are_validated_without_a_gpu():
     L.vs_conv_set_weights_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
     assert L.vs_conv_set_weights_pair(h0, h1, fp, None, None) == 1 and b"ADJOINT" in L.vs_last_error()
     assert L.vs_conv_set_weights_pair(h0, h2, fp, None, None) == 1
+    # vs_conv_set_weights_batch: the same handle twice in one batch is refused before anything is reserved or launched (each job flips its handle's
+    # weight-maximum slot, a duplicate made one job clear the slot the other reads)
+    hs = (ctypes.c_void_p * 3)(h0, h1, h0)
+    ws = (ctypes.POINTER(ctypes.c_float) * 3)(fp, fp, fp)
+    L.vs_conv_set_weights_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    assert L.vs_conv_set_weights_batch(hs, ws, None, 3, None) == 1 and b"twice" in L.vs_last_error()
     for hh in (h0, h1, h2):
         L.vs_conv_destroy(hh)
 

@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_set>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -1514,6 +1515,17 @@ struct BatchSlot {
     size_t cap = 0;
     hipEvent_t ev = nullptr;
     bool pending = false;
+    int device = -1;          // the device `dev` and `ev` belong to (the ring served whichever device was current at first use)
+};
+// marks a slot busy from the moment its host buffer has been handed to an asynchronous copy, whatever happens afterwards (on an error behind the copy
+// the slot stayed "free" and its host buffer could be rewritten while the copy was still in flight)
+struct SlotInFlight {
+    BatchSlot *sl;
+    hipStream_t s;
+    ~SlotInFlight() {
+        if (hipEventRecord(sl->ev, s) == hipSuccess) sl->pending = true;
+        else (void)hipStreamSynchronize(s);
+    }
 };
 struct BatchArena {
     std::mutex mu;
@@ -1529,6 +1541,17 @@ int batch_slot(size_t bytes, BatchSlot **out) {
     if (sl.pending) {
         VS_CHECK_HIP(hipEventSynchronize(sl.ev));
         sl.pending = false;
+    }
+    int cur = 0;
+    VS_CHECK_HIP(hipGetDevice(&cur));
+    if (sl.device != cur) {       // first use, or the process moved to another device: this slot's device buffer and event are re-made there
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+        sl.ev = nullptr;
+        sl.host = sl.dev = nullptr;
+        sl.cap = 0;
+        sl.device = cur;
     }
     if (!sl.ev) VS_CHECK_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (bytes > sl.cap) {
@@ -1562,6 +1585,11 @@ int vs_conv_set_weights_batch(vs_conv_t *const *handles, const float *const *w, 
     const int m = (int)idx.size();
     if (m == 0) return VS_OK;
     if (m == 1) return vs_conv_set_weights(handles[idx[0]], w[idx[0]], nullptr, bias ? bias[idx[0]] : nullptr, stream);
+    {   // no handle twice in one batch: each job flips its handle's weight-maximum slot (pack_gen), so a duplicate would make one job clear the slot the other reads
+        std::unordered_set<const vs_conv *> seen;
+        for (int j = 0; j < m; ++j)
+            VS_REQUIRE(seen.insert(handles[idx[j]]).second, "vs_conv_set_weights_batch: entry %d: the same handle appears twice in one batch", idx[j]);
+    }
     std::lock_guard<std::mutex> lock(g_batch.mu);
     const size_t off_sp = (size_t)m * sizeof(PackParams), off_b0 = off_sp + (size_t)m * sizeof(vs_split_pack),
                  off_b1 = off_b0 + (size_t)(m + 1) * sizeof(unsigned), bytes = off_b1 + (size_t)(m + 1) * sizeof(unsigned);
@@ -1595,13 +1623,12 @@ int vs_conv_set_weights_batch(vs_conv_t *const *handles, const float *const *w, 
     b0[m] = nb0;
     b1[m] = nb1;
     VS_CHECK_HIP(hipMemcpyAsync(sl->dev, sl->host, bytes, hipMemcpyHostToDevice, s));
+    SlotInFlight in_flight{sl, s};         // (records the slot's event behind everything launched below, on every way out)
     const char *db = static_cast<const char *>(sl->dev);
     hipLaunchKernelGGL(pack_conv_multi_kernel, dim3(nb0), dim3(256), 0, s, reinterpret_cast<const PackParams *>(db),
                        reinterpret_cast<const unsigned *>(db + off_b0), m);
     VS_CHECK_HIP(hipGetLastError());
     VS_TRY(pack_split_multi(reinterpret_cast<const vs_split_pack *>(db + off_sp), reinterpret_cast<const unsigned *>(db + off_b1), m, nb1, s));
-    VS_CHECK_HIP(hipEventRecord(sl->ev, s));
-    sl->pending = true;
     return VS_OK;
 }
 

@@ -68,15 +68,19 @@ class _FoldedSlot(torch.autograd.Function):
     end (one launch instead of ~180, but nothing left to overlap with)."""
 
     @staticmethod
-    def forward(ctx, v, g, w_view, norm_view):
+    def forward(ctx, v, g, w_view, norm_view, bank):
         ctx.save_for_backward(v, g, norm_view)
+        ctx.bank, ctx.gen = bank, bank._state["gen"]
         return w_view.view(w_view.shape)
 
     @staticmethod
     def backward(ctx, gw):
+        # (ADVICE r5: refresh() rewrites wbuf / nbuf through raw pointers -- no autograd version bump -- so a second refresh between a forward and its backward
+        #  would hand this node the NEXT pass's norms: refuse, as the batched node does)
+        assert ctx.bank._state["gen"] == ctx.gen, "WeightBank: the bank was refreshed between this pass's forward and its backward"
         v, g, norm = ctx.saved_tensors
         gv, gg = torch.ops.aten._weight_norm_interface_backward(gw.contiguous(), v, g, norm.view(g.shape), 0)
-        return gv, gg, None, None
+        return gv, gg, None, None, None
 
 
 def _data_parallel():
@@ -147,7 +151,7 @@ class WeightBank:
                 L.check(L.require_gpu().vs_weight_norm_multi_fwd(st["table"].data_ptr(), st["n"], st["total_rows"], L.stream_ptr()))
                 ws, row0 = [], 0
                 for m, (o, nel, shape), r in zip(st["mods"], st["wviews"], st["rows"]):
-                    ws.append(_FoldedSlot.apply(m.weight_v, m.weight_g, st["wbuf"][o:o + nel].view(shape), st["nbuf"][row0:row0 + r]))
+                    ws.append(_FoldedSlot.apply(m.weight_v, m.weight_g, st["wbuf"][o:o + nel].view(shape), st["nbuf"][row0:row0 + r], self))
                     row0 += r
             else:
                 ws = _BatchedWeightNorm.apply(self, *st["params"])
