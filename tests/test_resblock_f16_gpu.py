@@ -33,7 +33,9 @@ def _block(C, k, seed):
 
 @pytest.mark.parametrize("C,k,B,T", [(32, 3, 2, 3000), (64, 3, 2, 1501), (32, 7, 1, 2048), (64, 7, 2, 777), (32, 11, 2, 1000), (64, 11, 1, 4096),
                                      (64, 5, 1, 100), (32, 3, 3, 7), (64, 9, 1, 232), (32, 5, 1, 233), (128, 3, 2, 1000), (128, 7, 1, 515),
-                                     (128, 11, 1, 300), (32, 7, 2, 5000)])
+                                     (128, 11, 1, 300), (32, 7, 2, 5000),
+                                     # (round 6: 64 channels with a wide halo on launches that fill the chip twice over -> 512-column tiles on eight waves)
+                                     (64, 11, 16, 14000), (64, 7, 24, 10001)])
 @pytest.mark.parametrize("pairs", [3, 1])
 def test_whole_resblock_launch_vs_oracle(oracle, vs_option, C, k, B, T, pairs):
     m, sd = _block(C, k, C + k)
@@ -49,6 +51,8 @@ def test_whole_resblock_launch_vs_oracle(oracle, vs_option, C, k, B, T, pairs):
         acc_t = torch.from_numpy(acc).cuda()
         m._run_fused(xd, acc_t, first=False, scale=1.0 / 3.0)                  # in place on the MRF accumulator, averaged
     assert m.convs1[0]._op().kernel_instance().startswith("resblock_f16_kernel<"), m.convs1[0]._op().kernel_instance()
+    if C == 64 and B >= 16:
+        assert m.convs1[2]._op().kernel_instance().startswith("resblock_f16_kernel<4, 2, 4,"), m.convs1[2]._op().kernel_instance()      # the last pair / the whole block: H >= 20
     assert np.abs(y.double().cpu().numpy() - ref).max() <= 1e-5 * scale
     assert np.abs(acc_t.double().cpu().numpy() - (ref + acc) / 3.0).max() <= 1e-5 * scale
     assert torch.equal(xd.cpu(), torch.from_numpy(x))                            # the input is left untouched
@@ -109,7 +113,7 @@ def _bf16_emulation(m, x, acc=None, scale=1.0, pairs=3):
 
 
 @pytest.mark.parametrize("C,k,B,T", [(32, 3, 2, 3000), (64, 3, 2, 1501), (32, 7, 1, 2048), (64, 7, 2, 777), (32, 11, 2, 1000), (64, 11, 1, 1024),
-                                     (32, 3, 3, 7), (64, 9, 1, 232), (128, 3, 2, 1000), (128, 7, 1, 515), (128, 11, 1, 300)])
+                                     (32, 3, 3, 7), (64, 9, 1, 232), (128, 3, 2, 1000), (128, 7, 1, 515), (128, 11, 1, 300), (64, 7, 16, 14000)])
 @pytest.mark.parametrize("pairs", [3, 1])
 def test_bf16_resident_resblock_launch_vs_its_arithmetic(vs_option, C, k, B, T, pairs):
     """resblock_bf16_kernel (VS_MATH_BF16 on bf16-RESIDENT tensors, BASELINE configs[4]): the launch against an fp64 restatement of exactly

@@ -490,6 +490,16 @@ int vs_resblock_forward(vs_conv_t *const *convs, int nconv, const vs_conv_io_t *
             return launch_resblock_cfg<4, 4, 1>(p, s);
         return launch_resblock_cfg<4, 4, 2>(p, s);
     }
+    // 64 channels: 256-column tiles on four waves, two workgroups per CU -- unless the chain's halo is wide (H >= 20 columns at each end: the k = 7 pair at dilation 5,
+    // the k = 11 pairs at dilations 3 and 5, whole k >= 5 blocks): then 512-column tiles on eight waves, one workgroup per CU, recompute half as many halo columns per
+    // output.  Under the chip's power limit the launch time follows the EXECUTED matrix work (tools/resblock_stamps.py: the same MFMA cycle counts at 1.25-1.55 GHz):
+    // round 6, B = 32 x T = 131072, launch spans 3.23 -> 2.98 ms (k = 11, d = 3), 3.43 -> 3.03 (k = 11, d = 5), 2.30 -> 2.06 (k = 7, d = 5); with H <= 12 the narrow
+    // tile's two independent workgroups per CU win or tie (profiles/r06_resblock_wide64_ab.txt).
+#ifndef VS_RB_NO_WIDE64      // (tools/build_variant.py: the A/B library without this branch)
+    if (p.H >= 20 && (long long)ceil_div(p.T, 512 - 2 * p.H) * p.B >= 512 && !opt(OPT_RB_TILE256) &&      // (and the launch still fills the chip twice over)
+        resblock_lds<4, 2, 4>(margin_of(p.MP), bf ? 1 : 2) <= 160 * 1024)
+        return launch_resblock_cfg<4, 2, 4>(p, s);
+#endif
     return launch_resblock_cfg<4, 2, 2>(p, s);
 }
 
