@@ -24,8 +24,15 @@
 #include "conv_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace vs {
+
+__device__ __forceinline__ unsigned max3_u32(unsigned a, unsigned b, unsigned c) {      // one v_max3_u32
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 constexpr int RB_MAXCONV = 6;
 constexpr int RB_MAXPAD = 28;      // largest pad of a conv of the chain: (k - 1) * d / 2 = 25 at k = 11, d = 5
@@ -124,9 +131,17 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
             for (int r = 0; r < 16; ++r) xr[j][r] = inside[j] ? xr[j][r] : 0.f;
     }
 
+    // (wave-uniform: every column of this wave's tiles lies inside the sequence)
+    bool all_in = true;
+#pragma unroll
+    for (int j = 0; j < NT_W; ++j) all_in = all_in && (__builtin_amdgcn_ballot_w64(inside[j]) == ~0ull);
     rb_stamp(p, 1);
     // one (chunk, tap) step: NT_W column tiles x 3 cross products; the planes of tile j+1 are read under the MFMAs of tile j
-    auto mma_step = [&](const u32x4 (&acur)[PLANES], const unsigned *xs) __attribute__((always_inline)) {
+    // ZC: the first step of a conv -- the first product of every column tile takes a ZERO C operand (an inline constant of the instruction) instead of the
+    // accumulators being cleared by 64 moves per conv beforehand
+    auto mma_step = [&](const u32x4 (&acur)[PLANES], const unsigned *xs, auto zc_c) __attribute__((always_inline)) {
+        constexpr bool ZC = decltype(zc_c)::value;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 bf[PLANES], bn[PLANES];
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) bf[pl] = *reinterpret_cast<const u32x4 *>(xs + pl * TPL);
@@ -141,9 +156,11 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
                 auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[ta]), __builtin_bit_cast(f16x8, bf[tb]), acc[j], 0, 0, 0);
                 };
-                mm(1, 0); mm(0, 1); mm(0, 0);        // smallest terms first
+                if constexpr (ZC) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, acur[1]), __builtin_bit_cast(f16x8, bf[0]), zero16, 0, 0, 0);
+                else mm(1, 0);
+                mm(0, 1); mm(0, 0);        // smallest terms first
             } else {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[0]), __builtin_bit_cast(bf16x8, bf[0]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, acur[0]), __builtin_bit_cast(bf16x8, bf[0]), ZC ? zero16 : acc[j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -163,17 +180,25 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         // (0.1 v for two values per instruction: v_pk_mul_f32 on the register pairs of the accumulator tile)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 slope2 = {0.1f, 0.1f};
+        // (round 6, VALU diet -- under the chip's power limit instructions saved come back as clock: a tile wholly inside the sequence, i.e. all but the two
+        //  at an item's ends, skips the two selects per pair; the maximum key of a pair is ONE v_max3_u32)
+        auto transform = [&](auto in_c) __attribute__((always_inline)) {
+            constexpr bool ALL_IN = decltype(in_c)::value;
 #pragma unroll
-        for (int j = 0; j < NT_W; ++j)
+            for (int j = 0; j < NT_W; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 v2 = second ? f32x2{acc[j][r], acc[j][r + 1]} : f32x2{xr[j][r], xr[j][r + 1]};
-                const f32x2 t2 = v2 * slope2;
-                const float v0 = inside[j] ? fmaxf(v2.x, t2.x) : 0.f, v1 = inside[j] ? fmaxf(v2.y, t2.y) : 0.f;
-                acc[j][r] = v0;
-                acc[j][r + 1] = v1;
-                if constexpr (PLANES == 2) mkey = f16_maxkey(f16_maxkey(mkey, v0), v1);
-            }
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v2 = second ? f32x2{acc[j][r], acc[j][r + 1]} : f32x2{xr[j][r], xr[j][r + 1]};
+                    const f32x2 t2 = v2 * slope2;
+                    float v0 = fmaxf(v2.x, t2.x), v1 = fmaxf(v2.y, t2.y);
+                    if constexpr (!ALL_IN) { v0 = inside[j] ? v0 : 0.f; v1 = inside[j] ? v1 : 0.f; }
+                    acc[j][r] = v0;
+                    acc[j][r + 1] = v1;
+                    if constexpr (PLANES == 2) mkey = max3_u32(mkey, (f2u(v0) << 1) + 0x01000000u, (f2u(v1) << 1) + 0x01000000u);      // (f16_maxkey of both)
+                }
+        };
+        if (all_in) transform(std::true_type{});
+        else transform(std::false_type{});
         // ---- the tile's scale: largest exponent over the four waves (the barrier also ends every wave's reads of the previous tile)
         int eb = 127;
         float sx = 1.f;
@@ -210,11 +235,7 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
                 for (int pl = 0; pl < PLANES; ++pl) *reinterpret_cast<uint2 *>(dst + pl * TPL) = make_uint2(d0[pl], d1[pl]);
             }
         }
-#pragma unroll
-        for (int j = 0; j < NT_W; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        // ---- weight fragments of the first step, then the conv
+        // ---- weight fragments of the first step, then the conv (the accumulators are cleared by the first step's zero C operand)
         const int d = p.dil[c];
         const int pad = d * (KT - 1) / 2;
         const u32x4 *const wbase = reinterpret_cast<const u32x4 *>(p.ws[c]) + (long long)wm * KT * p.nchunks * (PLANES * 64) + lane_c;
@@ -237,18 +258,20 @@ __device__ __forceinline__ void resblock_body(const ResblockParams &p) {
         const unsigned *const xlane = Tb + (lh * WT + MP + wn * (NT_W * 32) + l5 - pad) * 4;
         const int x_dtap = d * 4, x_dwrap = 2 * WT * 4 - (KT - 1) * d * 4;
         int xoff = 0;
-        auto step = [&](u32x4 (&acur)[PLANES], u32x4 (&apre)[PLANES]) __attribute__((always_inline)) {
+        auto step = [&](u32x4 (&acur)[PLANES], u32x4 (&apre)[PLANES], auto zc_c) __attribute__((always_inline)) {
             // (UNCONDITIONAL: behind `if (s + 1 < nsteps)` hipcc's wait in front of this step's first MFMA was vmcnt(0) -- the scoreboard merge of the two
             //  paths -- which also waited for the fragments requested on the line above: one exposed L2 round trip per step pair in every conv of
             //  every fused block.  Round 4, found in the ISA.)
             load_a(apre); advance();
-            mma_step(acur, xlane + xoff);
+            mma_step(acur, xlane + xoff, zc_c);
             if (++tap == KT) { tap = 0; xoff += x_dwrap; } else xoff += x_dtap;
             ++s;
         };
+        step(a0, a1, std::true_type{});                      // (nsteps >= 2: two chunks at 32 channels, three taps at least)
+        step(a1, a0, std::false_type{});
         while (s < nsteps) {
-            step(a0, a1);
-            if (s < nsteps) step(a1, a0);
+            step(a0, a1, std::false_type{});
+            if (s < nsteps) step(a1, a0, std::false_type{});
         }
         rb_stamp(p, 4 + 4 * c);
         // ---- scale out, bias in; the second conv of a pair adds the residual stream
