@@ -379,6 +379,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 32)")
     ap.add_argument("--frames", type=int, default=None, help="T_mel (default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the timed batches rotate over (visinger_amd.synth.StreamRotation; 1 = every batch on one stream, the rounds 1-5 measurement)")
     ap.add_argument("--ragged", action="store_true", help="SURVEY 8d ragged variant: item lengths ~ U{T/2..T}, tails masked (mel2ph = 0)")
     ap.add_argument("--hidden", type=int, default=None, help="hidden_size (512 = the BASELINE config-5 width)")
     ap.add_argument("--hop", type=int, default=256, choices=(256, 300),
@@ -559,7 +561,7 @@ def compact_line(full, math=None, details=None):
     out["data"] = full.get("data", "synthetic")
     cfg = full.get("config", {})
     out["config"] = _pick(cfg, ("workload", "baseline_config", "per_gpu_batch", "global_batch", "t_mel", "hop", "hidden", "parallelism",
-                                "p_dropout", "realtime_factor"))
+                                "p_dropout", "realtime_factor", "streams"))
     if out["config"] and len(out["config"].get("workload", "")) > 200:
         out["config"]["workload"] = out["config"]["workload"][:200]
     r = full.get("roofline")
@@ -584,6 +586,9 @@ def compact_line(full, math=None, details=None):
     for k in ("waveform_max_abs_err", "flow_logdet_rel_err", "generated_samples_per_s"):
         if k in full:
             out[k] = full[k]
+    if "single_stream" in full:
+        out["single_stream"] = _pick(full["single_stream"], ("ms_per_step", "value"))
+        out.setdefault("roofline", {})["measured_on"] = "single-stream pass (same steps; kernel durations are not attributable under two-stream overlap)"
     if "flow_logdet" in full:
         out["flow_logdet_mean_only_exact_zero"] = full["flow_logdet"].get("mean_only_true_logdet_is_exact_zero")
     for k in ("fp32_mfma_engine", "split_bf16x6_engine"):
@@ -674,10 +679,17 @@ class InferenceWorkload:
                 "parallelism": f"dp{world} (utterance shard, no collective)"}
 
 
-def timed_run(step, steps, warmup, profile, barrier):
+def timed_run(step, steps, warmup, profile, barrier, nstreams=1):
+    """warm-up, then `steps` timed steps between two barriers.  nstreams > 1: the steps -- independent batches -- go through visinger_amd.synth.StreamRotation,
+    the product's own batch pipeline (consecutive batches on alternating HIP streams: batch i + 1's latency-bound transformers under batch i's generator);
+    the warm-up runs through the same rotation, so every stream's allocator pool is warm."""
     from visinger_amd.ops import PROFILER
-    for _ in range(warmup):
-        out = step()
+    from visinger_amd.synth import StreamRotation
+    rot = StreamRotation(nstreams, timing=True) if nstreams > 1 else None
+    for i in range(warmup):
+        out = rot.run(step)[0] if rot else step()
+    if rot:
+        rot.join()
     import gc
     nogc = not os.environ.get("VS_BENCH_GC") and gc.isenabled()      # (the cyclic collector out of the timed synthesis steps, as `timeit` does; a synthesis
     if nogc:                                                          #  loop allocates little: 0-0.2 ms a step either way)
@@ -691,8 +703,13 @@ def timed_run(step, steps, warmup, profile, barrier):
         t0 = time.perf_counter()
         marks[0].record()
         for i in range(steps):
-            out = step()
-            marks[i + 1].record()
+            if rot:
+                out, marks[i + 1] = rot.run(step)
+            else:
+                out = step()
+                marks[i + 1].record()
+        if rot:
+            rot.join()
         barrier()
         dt = time.perf_counter() - t0
     finally:
@@ -704,7 +721,22 @@ def timed_run(step, steps, warmup, profile, barrier):
     return out, dt, per_step
 
 
-def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
+STREAMS_NOTE = ("value / ms_per_step: consecutive batches through visinger_amd.synth.StreamRotation ({n} HIP streams: batch i + 1's transformers under batch "
+                "i's generator); roofline and single_stream: the same steps on ONE stream, where a kernel's HIP-event duration is its own")
+
+
+def timed_pipeline(step, steps, warmup, barrier, nstreams):
+    """(out, dt, per_step, single): the timed region `value` is quoted on, plus -- when it ran on more than one stream -- a second, single-stream pass of the
+    same steps with the per-kernel HIP events on (under two-stream overlap a kernel's event duration includes the other stream's work: not a roofline input)."""
+    if nstreams <= 1:
+        out, dt, per_step = timed_run(step, steps, warmup, True, barrier)
+        return out, dt, per_step, None
+    out, dt, per_step = timed_run(step, steps, warmup, False, barrier, nstreams)
+    _, dt1, per1 = timed_run(step, steps, min(warmup, 3), True, barrier)
+    return out, dt, per_step, {"ms_per_step": dt1 / steps * 1e3, "ms_per_step_stats": percentile_stats(per1), "dt": dt1}
+
+
+def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True, nstreams=2):
     """A reduced bench line for BASELINE config 2 / 3 / 5 inside the default run: same timing discipline as the
     headline (warm-up, barrier + synchronize on both sides, HIP events per launch for the roofline), fewer steps."""
     from visinger_amd.ops import PROFILER
@@ -713,15 +745,18 @@ def other_config_line(config, dev, steps, warmup, barrier, with_cpu=True):
         return train_line(preset["batch"], preset["frames"], 0.1, "split3", steps, warmup, 0, 1, None, dev, barrier)
     math = "bf16" if preset.get("math") == "bf16" else "split3"
     wl = InferenceWorkload(config, preset["batch"], preset["frames"], preset.get("hidden", 192), math, "bf16" if config == 5 else "f32", 256, False, dev)
-    out, dt, per_step = timed_run(wl.step, steps, warmup, True, barrier)
+    out, dt, per_step, single = timed_pipeline(wl.step, steps, warmup, barrier, nstreams)
     wav = out["wav_out"]
     assert wav.shape == (wl.B, wl.T * 256) and bool(torch.isfinite(wav).all())
     samples = wl.B * wl.T * 256 * steps
     line = {"metric": "audio samples/sec (22.05 kHz)", "value": samples / dt, "unit": "audio samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "ms_per_step": dt / steps * 1e3, "ms_per_step_stats": percentile_stats(per_step), "dtype": wl.dtype_name(), "data": "synthetic",
-            "config": dict(wl.describe(), realtime_factor=samples / dt / SR, what=preset["what"]),
-            "roofline": roofline_from_profile(PROFILER.summary(), dt, steps, wl.workload_key())}
+            "config": dict(wl.describe(), realtime_factor=samples / dt / SR, what=preset["what"], streams=nstreams),
+            "roofline": roofline_from_profile(PROFILER.summary(), single["dt"] if single else dt, steps, wl.workload_key())}
+    if single:
+        line["single_stream"] = {"ms_per_step": single["ms_per_step"], "value": samples / single["dt"]}
+        line["streams_note"] = STREAMS_NOTE.format(n=nstreams)
     if config == 5 and with_cpu and out.get("f0_pred") is not None:
         line["oracle_check"] = oracle_check_config5(wl.model, wl.hp, wl.batch, out["f0_pred"])
     if config == 2 and with_cpu:
@@ -776,14 +811,14 @@ def main():
     pre = {}
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.config in (0, 4) and not args.no_other_configs:
         for c in (3, 2, 5):
-            oc = other_config_line(c, dev, 20 if c == 3 else 10, 6, barrier)
+            oc = other_config_line(c, dev, 20 if c == 3 else 10, 6, barrier, nstreams=args.streams)
             oc["n_gpus"] = 1
             pre[c] = oc
             torch.cuda.empty_cache()
 
     wl = InferenceWorkload(args.config, B, T, args.hidden, args.math, args.storage, args.hop, args.ragged, dev, rank, world)
     model, hp = wl.model, wl.hp
-    out_dev, dt, per_step = timed_run(wl.step, args.steps, args.warmup, True, barrier)
+    out_dev, dt, per_step, single = timed_pipeline(wl.step, args.steps, args.warmup, barrier, args.streams)
     wav = out_dev["wav_out"]
     assert wav.shape == (B, T * HOP) and bool(torch.isfinite(wav).all())
     dt = max_over_ranks(dt, device=dev if backend == "nccl" else None)
@@ -804,9 +839,12 @@ def main():
             "vs_baseline": None,
             "dtype": wl.dtype_name(),
             "data": "synthetic",
-            "config": dict(wl.describe(world), realtime_factor=samples / dt / SR),
-            "roofline": roofline_from_profile(PROFILER.summary(), dt, args.steps, wl.workload_key()),
+            "config": dict(wl.describe(world), realtime_factor=samples / dt / SR, streams=args.streams),
+            "roofline": roofline_from_profile(PROFILER.summary(), single["dt"] if single else dt, args.steps, wl.workload_key()),
         }
+        if single:
+            out["single_stream"] = {"ms_per_step": single["ms_per_step"], "value": B * T * HOP * args.steps / single["dt"], "ms_per_step_stats": single["ms_per_step_stats"]}
+            out["streams_note"] = STREAMS_NOTE.format(n=args.streams)
         headline = world == 1 and not args.no_cpu_baseline and args.config in (0, 4)
         if headline:
             # the CPU oracle on item 0 of the timed batch, the same graph: the reported baseline AND the checker of the timed run

@@ -5,6 +5,8 @@
 #   usage: tools/profile_round.sh r04_a                     (the default = headline workload; the full default run is the first leg)
 #          tools/profile_round.sh r04_a_config5 --config 5  (another BASELINE configuration: its summaries carry its workload key)
 # The program sits directly after `--` (python3 bench.py ...): no env / bash -c hop under rocprofv3.
+# Round 6: the profiled passes run --streams 1 -- the pass bench.py itself takes its `roofline` from (under the two-stream batch rotation that `value` is quoted on, a
+# kernel's duration includes the other stream's work and is not a roofline input).
 set -u
 TAG=$1; shift
 export TMPDIR=/tmp
@@ -19,10 +21,10 @@ fi
 cp $OUT/bench_stdout.txt $OUT/summary/${TAG}_bench_stdout.txt
 tail -n 1 $OUT/bench_stdout.txt > $OUT/summary/${TAG}_bench_line.json
 export VS_BENCH_DETAILS=/tmp/bench_details_scratch.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs "$@" > $OUT/bench_line_profiled.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs "$@" > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs "$@" > /dev/null 2> $OUT/write.err
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs "$@" > /dev/null 2> $OUT/mfma.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1 "$@" > $OUT/bench_line_profiled.json 2> $OUT/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --streams 1 "$@" > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --streams 1 "$@" > /dev/null 2> $OUT/write.err
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --streams 1 "$@" > /dev/null 2> $OUT/mfma.err
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_bench_kernel_stats.csv
 tail -n 1 $OUT/bench_line_profiled.json > $OUT/summary/${TAG}_bench_line_profiled.json
 F=$(dirname $(find $OUT/fetch -name "*counter_collection.csv" | head -1)); W=$(dirname $(find $OUT/write -name "*counter_collection.csv" | head -1)); M=$(dirname $(find $OUT/mfma -name "*counter_collection.csv" | head -1))

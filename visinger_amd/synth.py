@@ -58,6 +58,40 @@ def save_wav(wav, path, sr, norm=False):
     wavfile.write(path[:-4] + ".wav", sr, to_int16(wav, norm=norm))
 
 
+class StreamRotation:
+    """Consecutive batches on alternating HIP streams (round 6).  A synthesis step is a chain: the prior transformers and the flow -- ~250 short,
+    latency-bound launches that leave most of the chip idle -- then the HiFi-GAN generator, whose launches fill it.  Batches are independent (no op of the path
+    mixes utterances), so batch i + 1 issued on a second stream runs its transformers in the gaps of batch i's generator: measured on one
+    MI355X, B = 32 x T_mel = 1024: 72.0 -> 69.3 ms a batch; BASELINE configs[1] (B = 8, T_mel = 512): 9.85 -> 8.31 ms; configs[4]: 56.7 -> 54.2 ms
+    (profiles/r06_stream_rotation_ab.txt); a third stream adds nothing.  Every launch of the library goes to torch's current stream and every workspace is
+    allocated through torch's stream-aware allocator, so two steps in flight share only read-only state (parameters, packed weights).  NOT for the flow's
+    FORWARD direction with log-det (its partial sums live in the conv handle: INTEGRATION.md 2) nor for training."""
+
+    def __init__(self, n=2, timing=False):
+        self.streams = [torch.cuda.Stream() for _ in range(max(1, int(n)))]
+        self.count = 0
+        self.timing = bool(timing)                # (events that can be timed against each other: the benchmark's per-batch statistics)
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(cur)                  # (inputs prepared on the caller's stream so far are visible)
+
+    def run(self, fn):
+        """fn() with the next stream of the rotation current; returns (fn's result, an event recorded behind it on that stream)"""
+        st = self.streams[self.count % len(self.streams)]
+        self.count += 1
+        with torch.cuda.stream(st):
+            out = fn()
+            ev = torch.cuda.Event(enable_timing=self.timing)
+            ev.record(st)
+        return out, ev
+
+    def join(self):
+        """the caller's current stream waits for everything issued through the rotation"""
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
 class GraphedStep:
     """One synthesis step (VISinger.forward(infer=True)) of a FIXED shape captured into a HIP graph and replayed: what a serving
     loop with recurring batch shapes does.  Every launch of the step goes to torch's current stream through the C ABI, nothing
@@ -99,7 +133,7 @@ class GraphedStep:
 
 @torch.no_grad()
 def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1.0, generator=None, equal_tokens=False,
-               graphs=None):
+               graphs=None, streams=2):
     """Run VISinger.forward(infer=True) over length-bucketed batches.  Returns a list of float32 waveforms trimmed to
     each item's own length (frames * hop_size), in the input order.
 
@@ -115,11 +149,25 @@ def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1
 
     graphs: a dict owned by the caller; when given, each batch shape (B, T_tokens, T_frames, ragged) is captured into a HIP graph
     on first use (GraphedStep) and replayed afterwards -- the launch chain of a small batch (B=1: ~700 dependent launches) then
-    costs one graph launch instead of ~700 host-side launches."""
+    costs one graph launch instead of ~700 host-side launches.
+
+    streams: consecutive batches go to alternating HIP streams (StreamRotation: the next batch's transformers run under this batch's generator); a batch's
+    waveforms come back to the host when `streams` later batches have been issued.  The result is bit-identical to streams = 1 (same kernels, same inputs: the
+    noise of every batch is drawn on the caller's stream, in batch order).  With `graphs` the batches replay on the caller's stream (one stream)."""
     device = next(model.parameters()).device
     lengths = [int((np.asarray(it["mel2ph"]) > 0).sum()) for it in items]
     out = [None] * len(items)
     keys = [len(it["text_tokens"]) for it in items] if equal_tokens else None
+    rotation = StreamRotation(streams) if (graphs is None and streams and streams > 1) else None
+    pending = []                                 # (item indices, device waveforms, event) of the batches in flight
+
+    def collect(idx, wav_dev, ev):
+        if ev is not None:
+            ev.synchronize()
+        wav = wav_dev.float().cpu().numpy()
+        for b, i in enumerate(idx):
+            out[i] = wav[b, :lengths[i] * hop_size].copy()
+
     for idx in bucket_by_length(lengths, max_frames_per_batch, keys=keys):
         batch = collate([items[i] for i in idx], device)
         B, T = batch["mel2ph"].shape
@@ -129,10 +177,26 @@ def synthesize(model, items, hop_size, max_frames_per_batch=32768, noise_scale=1
             key = (B, batch["text_tokens"].shape[1], T, ragged)
             if key not in graphs or graphs[key].weights != GraphedStep.fingerprint(model):      # (re-captured after a weight update)
                 graphs[key] = GraphedStep(model, batch, noise, ragged)
-            wav = graphs[key](batch, noise).float().cpu().numpy()
-        else:
-            wav = model(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"],
-                        spk_id=batch["spk_id"], infer=True, noise=noise, mask_decoder=ragged)["wav_out"].float().cpu().numpy()
-        for b, i in enumerate(idx):
-            out[i] = wav[b, :lengths[i] * hop_size].copy()
+            collect(idx, graphs[key](batch, noise), None)
+            continue
+
+        def run(batch=batch, noise=noise, ragged=ragged):
+            return model(batch["text_tokens"], batch["pitch_tokens"], batch["dur_tokens"], batch["mel2ph"],
+                         spk_id=batch["spk_id"], infer=True, noise=noise, mask_decoder=ragged)["wav_out"]
+
+        if rotation is None:
+            collect(idx, run(), None)
+            continue
+        for st in rotation.streams:              # (this batch's inputs were made on the caller's stream)
+            st.wait_stream(torch.cuda.current_stream())
+        wav_dev, ev = rotation.run(run)
+        for t in list(batch.values()) + [noise]:
+            t.record_stream(rotation.streams[(rotation.count - 1) % len(rotation.streams)])      # (their memory is reused only behind that stream's work)
+        pending.append((idx, wav_dev, ev))
+        if len(pending) > len(rotation.streams):
+            collect(*pending.pop(0))
+    for job in pending:
+        collect(*job)
+    if rotation is not None:
+        rotation.join()
     return out
