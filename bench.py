@@ -103,6 +103,15 @@ def usable_cores():
     return n
 
 
+def library_source_hash():
+    """first 16 hex digits of the hash of the sources libvisinger_hip.so was built from (vs_source_hash; every committed profile summary carries it)"""
+    from visinger_amd import _lib as L
+    import ctypes
+    fn = L.lib().vs_source_hash
+    fn.restype = ctypes.c_char_p
+    return fn().decode()[:16]
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as f:
@@ -561,7 +570,7 @@ def compact_line(full, math=None, details=None):
     out["data"] = full.get("data", "synthetic")
     cfg = full.get("config", {})
     out["config"] = _pick(cfg, ("workload", "baseline_config", "per_gpu_batch", "global_batch", "t_mel", "hop", "hidden", "parallelism",
-                                "p_dropout", "realtime_factor", "streams"))
+                                "p_dropout", "realtime_factor", "streams", "vs_source_hash"))
     if out["config"] and len(out["config"].get("workload", "")) > 200:
         out["config"]["workload"] = out["config"]["workload"][:200]
     r = full.get("roofline")
@@ -676,7 +685,7 @@ class InferenceWorkload:
                             ("fp32 tensors" if self.storage == "f32" else "bf16-resident generator activations") + ", random-init weights",
                 "baseline_config": self.config or "headline (north_star: B=32, T_mel=1024, hop 256)",
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "t_mel": self.T, "hop": self.hop, "hidden": self.hidden,
-                "parallelism": f"dp{world} (utterance shard, no collective)"}
+                "parallelism": f"dp{world} (utterance shard, no collective)", "vs_source_hash": library_source_hash()}
 
 
 def timed_run(step, steps, warmup, profile, barrier, nstreams=1):
@@ -934,7 +943,8 @@ def train_line(B, T, dropout, math, steps, warmup, rank, world, dist, dev, barri
         "dtype": DTYPE[math], "data": "synthetic",
         "config": {"workload": f"VISinger GAN training step, B={B}/GPU T_mel={T} segment={tr.segment_size} hop={tr.hop}, reference-size "
                                "generator + MPD/MSD, AdamW x2, random-init weights", "baseline_config": 3, "p_dropout": dropout, "per_gpu_batch": B,
-                   "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)"},
+                   "global_batch": B * world, "t_mel": T, "parallelism": f"dp{world} (DDP gradient all-reduce over RCCL)",
+                   "vs_source_hash": library_source_hash()},
         "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": step_tflops, "peak": peak, "frac": step_tflops / peak,
                      "frac_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": (pmc_step_traffic(workload_key(3, B, T, 192, 256, "f32")) or {}).get("bytes_per_step"),

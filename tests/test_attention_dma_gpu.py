@@ -28,8 +28,16 @@ def test_dma_attention_matches_the_fp32_kernel_and_the_kernel_it_replaces(dk, nh
     old = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=False)
     assert L.lib().vs_last_kernel_name().decode().startswith("relattn_bf16_kernel<")
     vs_option("VS_NO_ATTN_DMA", 0)
-    got = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=False)
-    assert L.lib().vs_last_kernel_name().decode() == "relattn_dma_kernel<%d>" % (6 if dk <= 192 else 8)
+    vs_option("VS_ATTN_DMA_ONE_WAVE", 1)
+    one = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=False)        # the round-4 form: one wave per query group, all output tiles
+    assert L.lib().vs_last_kernel_name().decode() == "relattn_dma_kernel<%d, 1>" % (6 if dk <= 192 else 8)
+    vs_option("VS_ATTN_DMA_ONE_WAVE", 0)
+    got = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16, ksplit_auto=False)        # round 6: a wave pair splits the head's channels
+    assert L.lib().vs_last_kernel_name().decode() == "relattn_dma_kernel<%d, 2>" % (6 if dk <= 192 else 8)
+    # (the pair sums the score tile as (first half of the channels) + (second half) where the single wave sums even + odd k-steps: another fp32 order, the same
+    #  bf16 operands -- held to the bound between the two older kernels)
+    d1 = (got - one).abs()
+    assert float(d1.pow(2).mean().sqrt()) <= 1e-3 * float(ref.pow(2).mean().sqrt()) and float(d1.max()) <= 2e-2 * max(float(ref.pow(2).mean().sqrt()), 1e-3)
     assert torch.isfinite(got).all()
     scale = float(ref.pow(2).mean().sqrt())
     err = (got - ref).abs()

@@ -298,7 +298,7 @@ def test_config5_at_the_benched_batch_vs_bf16_operand_oracle(oracle, capsys):
     assert wav.shape == (B, T * 256) and bool(torch.isfinite(wav).all())
     # the benched dispatch: the LDS-DMA attention core, the plain-bf16 conv_ktap tiles, whole MRF blocks on bf16-resident tensors; every launch behind a
     # masked input transform (the transformers' convs, modules/rel_transformer.py:290-299, 336-345) on a conv_ktap instance
-    assert "relattn_dma_kernel<8>" in names, sorted(names)
+    assert "relattn_dma_kernel<8, 2>" in names, sorted(names)
     assert any(n.startswith("conv_ktap_kernel<9, 2, 1,") for n in names), sorted(names)          # FFN conv_1 (masked input, plain bf16)
     assert any(n.startswith("conv_ktap_kernel<11, 1, 1,") for n in names), sorted(names)         # generator k = 11 on bf16-resident tensors
     assert masked_launches and all(n.startswith("conv_ktap_kernel<") for n in masked_launches), sorted(set(masked_launches))
@@ -352,14 +352,14 @@ def test_config5_rel_encoder_on_the_benched_attention_kernel_vs_oracle(oracle, c
         y, names = dispatched(lambda: m(x.cuda(), mask.cuda()))
     finally:
         set_conv_math(m, None)
-    assert names.get("relattn_dma_kernel<8>") == nl, sorted(names)           # the kernel config 5 is benched on, once per layer
+    assert names.get("relattn_dma_kernel<8, 2>") == nl, sorted(names)           # the kernel config 5 is benched on, once per layer
     assert not any(n.startswith("relattn_bf16_kernel") or n.startswith("relattn_kernel") for n in names), sorted(names)
     oracle.set_threads(usable())
     ref = oracle.rel_encoder(sd, x.numpy(), mask.numpy(), None, n_heads=nh, n_layers=nl, kernel_size=ks, dtype=np.float32)
     emax, erms = err(y, ref)
     scale = float(np.sqrt((np.asarray(ref, np.float64) ** 2).mean()))
     with capsys.disabled():
-        print(f"\n   config 5 RelativeEncoder (hidden 512, T 4096, B 2, bf16) on relattn_dma_kernel<8>: rms err / rms {erms / scale:.2e}, "
+        print(f"\n   config 5 RelativeEncoder (hidden 512, T 4096, B 2, bf16) on relattn_dma_kernel<8, 2>: rms err / rms {erms / scale:.2e}, "
               f"max err / rms {emax / scale:.2e}; instances: " + ", ".join(sorted(names)))
     assert bool(torch.isfinite(y).all())
     assert float(y[1, :, 3000:].abs().max()) == 0.0                            # padded frames of the ragged item are exactly zero

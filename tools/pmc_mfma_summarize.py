@@ -15,6 +15,13 @@ import re
 import sys
 
 
+
+def _source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from visinger_amd.csrc import build
+    return build.source_hash()
+
+
 def main():
     pass_dir, prefix = sys.argv[1:3]
     workload = sys.argv[3] if len(sys.argv) > 3 else None
@@ -61,6 +68,7 @@ def main():
     if workload:
         out["workload"] = workload
     with open(f"{prefix}_pmc_mfma_busy.json", "w") as f:
+        out["vs_source_hash"] = _source_hash()      # the sources the profiled library was built from (a summary names its build)
         json.dump(out, f, indent=1)
 
 

@@ -37,6 +37,13 @@ def short(name):
     return m.group(1) + (m.group(2) or "").replace(" ", "")
 
 
+
+def _source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from visinger_amd.csrc import build
+    return build.source_hash()
+
+
 def main():
     fetch_dir, write_dir, prefix = sys.argv[1:4]
     workload = sys.argv[4] if len(sys.argv) > 4 else None      # bench.py --print-workload-key: the launch shapes these bytes belong to
@@ -78,6 +85,7 @@ def main():
                          "launches_fetch_pass": sum(n for (_, _), (n, tot) in fetch.items()), "steps_in_pass": steps_in_pass,
                          "hbm_bytes_corrected_per_step": (2 * tot_f + tot_w) / steps_in_pass if steps_in_pass else None}
     with open(f"{prefix}_pmc_traffic.json", "w") as f:
+        out["vs_source_hash"] = _source_hash()      # the sources the profiled library was built from (a summary names its build)
         json.dump(out, f, indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1) for k, v in out["kernels"].items()}, indent=1))
 

@@ -33,4 +33,5 @@ NSTEPS=2; case " $* " in *" --config 3 "*) NSTEPS=3;; esac
 python3 tools/pmc_summarize.py $F $W $OUT/summary/$TAG $KEY $NSTEPS > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma_summarize.py $M $OUT/summary/$TAG $KEY > $OUT/pmc_mfma.txt 2>&1
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma      # raw traces stay on the box (gpurun_out/ merges back <= 64 MiB)
+python3 -c "import json,sys; sys.path.insert(0,'.'); from visinger_amd.csrc import build; json.dump({'tag':'$TAG','vs_source_hash':build.source_hash(),'args':'$*','kernel_stats':'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1 $*'}, open('$OUT/summary/${TAG}_meta.json','w'), indent=1)"
 ls -la $OUT/summary; head -12 $OUT/summary/${TAG}_bench_kernel_stats.csv | cut -c1-150

@@ -35,8 +35,16 @@ namespace vs {
 #define ATT_SB 1        // 1: sched_barrier between (MFMA, next read) steps
 #endif
 
-template <int DT>
-__global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p) {
+// WPQ = waves per group of 32 queries.  1: the round-4 kernel, a wave owns all DT output tiles of its queries (128 accumulators at 256 channels: one wave per SIMD,
+// nothing to overlap its own S^T -> softmax -> P V chain with).  2 (round 6): a PAIR of waves (w, w + 4) shares a query group and splits the
+// head's channels: each holds HALF of the query fragments and accumulates HALF of the output tiles (DT / 2: 64 accumulators at 256 channels).  S^T = K^T Q
+// contracts over the channels, so each wave forms the partial scores of its half, the two exchange them through LDS (one more barrier per tile) and add --
+// a + b in one wave, b + a in the other: the same bits, so both run the SAME softmax and stay in step without exchanging anything else.  A workgroup is eight
+// waves, two per SIMD: the matrix pipe sees two independent MFMA chains, the VALU two softmax streams; all eight move the tile images (half the pieces each).
+template <int DT, int WPQ>
+__global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnParams p) {
+    static_assert(WPQ == 1 || (WPQ == 2 && DT % 2 == 0), "one wave per query group, or a pair splitting an even number of output tiles");
+    constexpr int DH = DT / WPQ;                     // output tiles (of 32 channels) per wave
     constexpr int AKT = 32;
     constexpr int DKR = DT * 32;                     // padded head dim
     constexpr int NKS = DKR / 16;                    // k-steps of S^T = K^T Q
@@ -45,12 +53,17 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
     constexpr int VPL = DKR * AVP;                   // dwords of the V image
     constexpr int IMG = KPL + VPL + AKT;             // dwords of a tile image: K, V, key mask
     constexpr int NU4 = IMG / 4;                     // 16-byte units of an image
-    constexpr int NFULL = NU4 / 256;                 // pieces every wave issues (one 16-byte unit per lane each)
-    constexpr int NTAIL = NU4 - NFULL * 256;         // units of the last, partial piece (lanes of wave 0)
-    static_assert(IMG % 4 == 0 && NTAIL >= 0 && NTAIL < 256 && NKS % 2 == 0, "image geometry");
+    constexpr int PIECE = 256 * WPQ;                 // 16-byte units of a piece: one per thread of the workgroup (round 6: ALL waves move the image -- with the pair
+                                                     // form four DMA waves kept their partners waiting at the score exchange for the ~600 cycles nine issues take)
+    constexpr int PBYTES = PIECE * 16;
+    constexpr int NFULL = NU4 / PIECE;               // pieces every wave issues (one 16-byte unit per lane each)
+    constexpr int NTAIL = NU4 - NFULL * PIECE;       // units of the last, partial piece (the first lanes of the workgroup)
+    static_assert(IMG % 4 == 0 && NTAIL >= 0 && NTAIL < PIECE && NKS % 2 == 0, "image geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3;                    // query group of the workgroup
+    const int dpart = wave_id >> 2;                  // which DH output tiles this wave accumulates (0 with WPQ = 1)
     const int half = lane >> 5, l31 = lane & 31;
     // XCD-aware placement (1-D grid): workgroup L runs on XCD L % 8 and workgroups are dispatched in order, so the query blocks of ONE
     // (batch, head) pair are given ids of one residue class -- they then run on one XCD at about the same time and stream the pair's
@@ -74,6 +87,7 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
     unsigned *const ring = reinterpret_cast<unsigned *>(smem);           // [3][IMG]
     float *const QRs = smem + 3 * IMG;                                    // [4][32][ATT_QRS] rel-key logits
     float *const Sws = QRs + 4 * 32 * ATT_QRS;                            // [4][32][ATT_QRS] in-window raw scores
+    float *const Xs = Sws + 4 * 32 * ATT_QRS;                             // WPQ = 2: [8 waves][16][64] partial scores of a tile, read by the partner wave
     float *const RVs = smem;                                              // [nrel][dk] relative value embeddings: over the ring, after the loop
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)ring);
 
@@ -91,13 +105,15 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         o.z = pack_hi(rne_bf16(v[4]), rne_bf16(v[5])); o.w = pack_hi(rne_bf16(v[6]), rne_bf16(v[7]));
         return o;
     };
-    u32x4 qf[NKS];
+    constexpr int NKW = NKS / WPQ;                   // k-steps of S^T this wave contracts (its half of the channels with WPQ = 2)
+    const int ks0 = dpart * NKW;
+    u32x4 qf[NKW];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int ks = 0; ks < NKW; ++ks) {
         float qv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int d = 16 * ks + 8 * half + j;
+            const int d = 16 * (ks0 + ks) + 8 * half + j;
             const float v = qb[(long long)min(d, dk - 1) * T + qic];
             qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
         }
@@ -137,9 +153,9 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         }
     }
 
-    f32x16 o[DT];
+    f32x16 o[DH];
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t = 0; t < DH; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_half = 0.f;
@@ -153,23 +169,25 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
     // unit of the slot), issued from ONE statement that saves M0 once: per piece an s_mov of the LDS address, the DMA, two scalar adds
     auto dma_tile = [&](int jt, int slot) __attribute__((always_inline)) {
         const char *src = imgb + (long long)jt * (IMG * 4);
-        unsigned dst = ring_lds + slot * (IMG * 4) + wave * 1024;
+        unsigned dst = ring_lds + slot * (IMG * 4) + wave_id * 1024;
         unsigned keep;
         // (two offset registers used alternately, each advanced only after the OTHER one's load has been issued: the add never follows
         //  the load that reads the register)
-        int va = lane16, vb = lane16 + 0x1000;
-#define VS_LD(v) "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " v ", %4\n\ts_add_u32 %1, %1, 0x1000\n\t"
-#define VS_PAIR VS_LD("%2") VS_LD("%3") "v_add_u32 %2, 0x2000, %2\n\tv_add_u32 %3, 0x2000, %3\n\t"
-        static_assert(NFULL == 6 || NFULL == 9, "pieces per tile image (192- / 256-channel heads)");
-        if constexpr (NFULL == 9)
-            asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR VS_PAIR VS_PAIR VS_LD("%2") "s_nop 1\n\tv_add_u32 %2, 0x1000, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep), "+s"(dst), "+v"(va), "+v"(vb) : "s"(src) : "memory", "scc");
-        else
-            asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR VS_PAIR "s_mov_b32 m0, %0"
-                         : "=&s"(keep), "+s"(dst), "+v"(va), "+v"(vb) : "s"(src) : "memory", "scc");
+        int va = lane16, vb = lane16 + PBYTES;
+#define VS_LD(v) "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 " v ", %4\n\ts_add_u32 %1, %1, %5\n\t"
+#define VS_PAIR VS_LD("%2") VS_LD("%3") "v_add_u32 %2, %6, %2\n\tv_add_u32 %3, %6, %3\n\t"
+#define VS_ODD VS_LD("%2") "s_nop 1\n\tv_add_u32 %2, %5, %2\n\t"
+#define VS_DMA_OPS : "=&s"(keep), "+s"(dst), "+v"(va), "+v"(vb) : "s"(src), "n"(PBYTES), "n"(2 * PBYTES) : "memory", "scc"
+        static_assert(NFULL == 3 || NFULL == 4 || NFULL == 6 || NFULL == 9, "pieces per tile image (192- / 256-channel heads, one or two waves per query group)");
+        if constexpr (NFULL == 9) asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR VS_PAIR VS_PAIR VS_ODD "s_mov_b32 m0, %0" VS_DMA_OPS);
+        else if constexpr (NFULL == 6) asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR VS_PAIR "s_mov_b32 m0, %0" VS_DMA_OPS);
+        else if constexpr (NFULL == 4) asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_PAIR "s_mov_b32 m0, %0" VS_DMA_OPS);
+        else asm volatile("s_mov_b32 %0, m0\n\t" VS_PAIR VS_ODD "s_mov_b32 m0, %0" VS_DMA_OPS);
+#undef VS_DMA_OPS
+#undef VS_ODD
 #undef VS_PAIR
 #undef VS_LD
-        const int voff = va;          // = lane16 + NFULL * 4096 in both cases
+        const int voff = va;          // = lane16 + NFULL * PBYTES in every case
         if (NTAIL && tid < NTAIL) glds16(voff, src, dst);      // (the last, partial piece: the first waves only)
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (nothing of the prologue's loads may be counted against the ring)
@@ -178,7 +196,7 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
 
 #define ASTAMP(k)                                                                                                    \
     do {                                                                                                             \
-        if (p.stamps && blockIdx.x == 0 && wave == 0 && jt < 120) {            \
+        if (p.stamps && blockIdx.x == 0 && wave_id == 0 && jt < 120) {            \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
             if (lane == 0) p.stamps[jt * 8 + (k)] = t_;                                                              \
         }                                                                                                            \
@@ -188,7 +206,7 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         ASTAMP(0);
         // this wave's pieces of tile jt have landed (those of tile jt + 1 -- NFULL, + 1 for the waves of the partial piece -- may stay in flight) ...
         if (jt + 1 < ntiles) {
-            if (NTAIL && wave * 64 < NTAIL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFULL + 1) : "memory");
+            if (NTAIL && wave_id * 64 < NTAIL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFULL + 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFULL) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -207,7 +225,7 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
         {
             auto readK = [&](int ks) __attribute__((always_inline)) {
-                return *reinterpret_cast<const u32x4 *>(Kb + ((2 * ks + half) * AKT + l31) * 4);
+                return *reinterpret_cast<const u32x4 *>(Kb + ((2 * (ks0 + ks) + half) * AKT + l31) * 4);
             };
             // (fragments eight k-steps ahead of their MFMA: one wave per SIMD has nothing else to cover an LDS round trip with)
             constexpr int KD = ATT_KD;
@@ -216,13 +234,23 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
             for (int i = 0; i < KD; ++i) kf[i] = readK(i);
             if (ATT_SB) __builtin_amdgcn_sched_barrier(0);          // (the scheduler may sink every read to its use to save registers: pin the order)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
+            for (int ks = 0; ks < NKW; ++ks) {
                 if (ATT_SB) __builtin_amdgcn_sched_barrier(0);
                 const u32x4 kc = kf[ks % KD];
-                if (ks + KD < NKS) kf[ks % KD] = readK(ks + KD);
+                if (ks + KD < NKW) kf[ks % KD] = readK(ks + KD);
                 if (ks & 1) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kc), __builtin_bit_cast(bf16x8, qf[ks]), s1, 0, 0, 0);
                 else s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kc), __builtin_bit_cast(bf16x8, qf[ks]), s0, 0, 0, 0);
             }
+        }
+        if constexpr (WPQ == 2) {
+            // the partial scores of this wave's channels -> LDS, the partner's back: s0 becomes the whole score tile (own + partner: commutative, so both waves of
+            // the pair hold the same bits), s1 zero.  Slot layout [register][lane]: a wave-instruction touches 256 consecutive bytes.
+            float *const mine = Xs + wave_id * (16 * 64), *const theirs = Xs + (wave_id ^ 4) * (16 * 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = s0[r] + s1[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = (s0[r] + s1[r]) + theirs[r * 64 + lane]; s1[r] = 0.f; }
         }
         ASTAMP(3);
         const bool near_diag = nrel && (j0 + AKT - 1 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
@@ -281,7 +309,7 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         // wave moved its maximum
         if (__any(alpha != 1.f)) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
+            for (int t = 0; t < DH; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
                 __builtin_amdgcn_sched_barrier(0);      // (one output tile at a time through the VGPRs: batching all eight costs 128 live registers)
@@ -291,20 +319,21 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         ASTAMP(4);
         // ---- O^T += V P^T: k-step s4 sums over the keys 16 s4 + 8 (j >> 2) + 4 half + (j & 3), the order of the V rows ----
         {
+            const unsigned *const Vw = Vb + dpart * (DH * 32 * AVP);          // this wave's DH output tiles (V rows dpart * DH * 32 ..)
             auto readV = [&](int s4, int t) __attribute__((always_inline)) {
-                return *reinterpret_cast<const u32x4 *>(Vb + (t * 32 + l31) * AVP + s4 * 8 + half * 4);
+                return *reinterpret_cast<const u32x4 *>(Vw + (t * 32 + l31) * AVP + s4 * 8 + half * 4);
             };
             constexpr int VD = ATT_VD;
             u32x4 vf[VD];
 #pragma unroll
-            for (int i = 0; i < VD; ++i) vf[i] = readV(i / DT, i % DT);
+            for (int i = 0; i < VD; ++i) vf[i] = readV(i / DH, i % DH);
             if (ATT_SB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 2 * DT; ++n) {
+            for (int n = 0; n < 2 * DH; ++n) {
                 if (ATT_SB) __builtin_amdgcn_sched_barrier(0);
                 const u32x4 vc = vf[n % VD];
-                if (n + VD < 2 * DT) vf[n % VD] = readV((n + VD) / DT, (n + VD) % DT);
-                o[n % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), __builtin_bit_cast(bf16x8, pf[n / DT]), o[n % DT], 0, 0, 0);
+                if (n + VD < 2 * DH) vf[n % VD] = readV((n + VD) / DH, (n + VD) % DH);
+                o[n % DH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), __builtin_bit_cast(bf16x8, pf[n / DH]), o[n % DH], 0, 0, 0);
             }
         }
         ASTAMP(5);
@@ -313,14 +342,15 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
 
     // ---- finish: normalise, add the relative-value term (fp32), store ----
     __syncthreads();                                     // every read of the ring has retired: its first bytes take the relative value table
-    for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
+    for (int e = tid; e < nrel * dk; e += 256 * WPQ) RVs[e] = relv[e];
     __syncthreads();
     const float l_tot = l_half + __shfl_xor(l_half, 32);
     const float inv = 1.0f / l_tot;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t = 0; t < DH; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] *= inv;
+    const int t_base = dpart * DH;                       // first output tile of this wave
     // sum_r p[i, i + r - ws] * rel_v[r]: the window index is the (rolled) outer loop so that every access to the output accumulators
     // has a compile-time index
 #pragma unroll 1
@@ -328,35 +358,35 @@ __global__ void __launch_bounds__(256, 1) relattn_dma_kernel(const AttnParams p)
         const float w = expf(Sww[l31 * ATT_QRS + rr] - m_run) * inv;
         const float *rv = RVs + rr * dk;
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+        for (int t = 0; t < DH; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
+            for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min((t_base + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
     }
     float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
+    for (int t = 0; t < DH; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int d = (t_base + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (d < dk && qi < T) ob[(long long)d * T + qi] = o[t][r];
         }
     }
 }
 
-template <int DT>
+template <int DT, int WPQ>
 static int launch_dma_dt(const AttnParams &p, hipStream_t s) {
     constexpr int DKR = DT * 32, IMG = (DKR / 8) * 32 * 4 + DKR * 20 + 32;
-    const size_t lds = 4 * ((size_t)3 * IMG + 2 * 4 * 32 * ATT_QRS);
-    auto kern = relattn_dma_kernel<DT>;
+    const size_t lds = 4 * ((size_t)3 * IMG + 2 * 4 * 32 * ATT_QRS + (WPQ == 2 ? 8 * 16 * 64 : 0));
+    auto kern = relattn_dma_kernel<DT, WPQ>;
     static bool attr_set = false;
     if (!attr_set) {
         VS_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     dim3 grid((unsigned)(ceil_div(p.T, 128) * p.nh * p.B), 1, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256 * WPQ), lds, s, p);
     VS_CHECK_HIP(hipGetLastError());
-    set_last_kernel("relattn_dma_kernel<%d>", DT);
+    set_last_kernel("relattn_dma_kernel<%d, %d>", DT, WPQ);
     return VS_OK;
 }
 
@@ -368,7 +398,8 @@ bool attn_dma_supported(const AttnParams &p) {
 
 int launch_attn_dma(const AttnParams &p, hipStream_t s) {
     const int DT = (int)ceil_div(p.dk, 32);
-    return DT <= 6 ? launch_dma_dt<6>(p, s) : launch_dma_dt<8>(p, s);
+    if (opt(OPT_ATTN_DMA_ONE_WAVE)) return DT <= 6 ? launch_dma_dt<6, 1>(p, s) : launch_dma_dt<8, 1>(p, s);      // (the round-4 form: A/B switch)
+    return DT <= 6 ? launch_dma_dt<6, 2>(p, s) : launch_dma_dt<8, 2>(p, s);
 }
 
 }  // namespace vs
