@@ -264,7 +264,7 @@ def flow_logdet_check(model, dev, B=2, T=256, seed=1234):
     return res
 
 
-PROFILE_TAGS = ("r05_c", "r05_b", "r05_a", "r04_f", "r04_e", "r04_d", "r04_c", "r04_b", "r04_a", "r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e",
+PROFILE_TAGS = ("r06_c", "r06_b", "r06_a", "r05_c", "r05_b", "r05_a", "r04_f", "r04_e", "r04_d", "r04_c", "r04_b", "r04_a", "r03_f", "r03_e", "r03_d", "r03_c", "r03_b", "r03_a", "r02_e", "r02_d", "r02_c", "r02_b", "r02_a", "r01_f", "r01_e",
                 "r01_c")      # newest first: profiles/<tag>[_<suffix>]_pmc_*.json
 HEADLINE_WORKLOAD = "B32_T1024_h192_hop256_f32"      # what a profiles/*_pmc_*.json without a "workload" field was recorded on (rounds 1-3)
 

@@ -37,8 +37,12 @@ REF = os.environ.get("VISINGER_REFERENCE", "/root/reference")
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 sys.dont_write_bytecode = True
+import importlib.util  # noqa: E402
+# torchaudio is what utils/audio/mel_processing.py wraps; it is absent from this image and from /root/reference, so SURVEY.md 8f-2 stays "parity unpinned".
+# The day it is importable in the build container, gen_mel_processing() below writes the pin (tests/test_audio_gpu.py picks the fixture up by itself).
+HAVE_TORCHAUDIO = importlib.util.find_spec("torchaudio") is not None
 for name in ("librosa", "librosa.filters", "pyloudnorm", "webrtcvad", "skimage", "skimage.transform",
-             "parselmouth", "pyworld", "torchaudio"):
+             "parselmouth", "pyworld") + (() if HAVE_TORCHAUDIO else ("torchaudio",)):
     sys.modules.setdefault(name, MagicMock())
 sys.path.insert(0, REF)
 
@@ -599,7 +603,28 @@ def gen_align_io():
     save("save_wav", **arrays)
 
 
+def gen_mel_processing():
+    """utils/audio/mel_processing.py:15-38 (SpectrogramFixed / MelSpectrogramFixed: torchaudio's transforms, the last frame dropped, log(mel + 1e-3)) with the
+    task's parameters (tasks/visinger.py:30-35, datasets/svs/csd/preprocess.yaml: n_fft 2048, win 1200, hop 300, 128 mels, 20-12000 Hz, 24 kHz) and the hop-256
+    variant on seeded waveforms -> mel_processing.npz.  Written only where the reference's dependency exists."""
+    if not HAVE_TORCHAUDIO:
+        print("mel_processing.npz: SKIPPED (torchaudio is not importable here: the mel transform stays parity-unpinned)")
+        return
+    from utils.audio.mel_processing import MelSpectrogramFixed, SpectrogramFixed
+    r = np.random.default_rng(77)
+    arrays = {}
+    for tag, sr, hop, win in (("hop300", 24000, 300, 1200), ("hop256", 22050, 256, 1024)):
+        wav = torch.from_numpy((r.standard_normal((2, hop * 40)) * 0.1).astype(np.float32))
+        spec = SpectrogramFixed(n_fft=2048, win_length=win, hop_length=hop, window_fn=torch.hann_window)(wav)
+        mel = MelSpectrogramFixed(sample_rate=sr, n_fft=2048, win_length=win, hop_length=hop, f_min=20.0, f_max=12000.0 if sr == 24000 else 11025.0, n_mels=128,
+                                  window_fn=torch.hann_window)(wav)
+        arrays.update({f"{tag}.wav": wav.numpy(), f"{tag}.spec": spec.numpy(), f"{tag}.mel": mel.numpy(),
+                       f"{tag}.params": np.array([sr, 2048, win, hop, 128, 20.0, 12000.0 if sr == 24000 else 11025.0])})
+    save("mel_processing", **arrays)
+
+
 if __name__ == "__main__":
+    gen_mel_processing()
     gen_wavenet()
     gen_posterior()
     gen_flow()

@@ -107,7 +107,7 @@ def test_round3_profile_split_f16_engine_and_whole_resblock_launches(tag):
     y + the halo columns of the tile under the doubled FETCH_SIZE, an upper bound) where the per-pair launches of round 2 moved 2.3 passes
     PER PAIR (three pairs per block)."""
     dom = "conv_split_kernel<1, 8, 4, 1, 3>"
-    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r05_")            # the newest committed summary of this workload is the one bench.py cites
+    assert bench_pmc("traffic", dom)["source"].startswith("recorded: profiles/r0")              # (a committed summary of this workload that still holds the round-3 instance)
     line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line_profiled.json")))
     r = line["roofline"]
     assert r["kernel"] == dom and r["bound"] == "mfma" and abs(r["peak"] - 2500.0 / 3.0) < 1e-6
@@ -222,7 +222,7 @@ def test_round5_profiles_parse_and_agree(tag):
     t3 = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_config3_pmc_traffic.json")))["pass_total"]
     assert t3["steps_in_pass"] == 3 and t3["hbm_bytes_corrected_per_step"] > 1e10
     assert bench.pmc_step_traffic("c3_B16_T512_h192_hop256_f32")["bytes_per_step"] > 1e10
-    assert bench.pmc_traffic(dom, "c2_B8_T512_h192_hop256_f32")["source"].startswith("recorded: profiles/r05_")       # config 2's own shapes
+    assert bench.pmc_traffic(dom, "c2_B8_T512_h192_hop256_f32")["source"].startswith("recorded: profiles/r0")         # config 2's own shapes (the newest round's summary)
     if tag == "r05_b":      # the committed end state: the transposed convs on their conv_ktap instance, the training step's launch census, DESIGN.md's numbers
         assert "void vs::conv_ktap_kernel<2, 1, 2, 4, 4, 1, 8, 1>(vs::ConvParams)" in rows and not any("conv_split_tr_kernel<1, 8, 4, 1, 3>" in n for n in rows)
         assert c3["ms_per_step"] < 92.0 and c3["steps"] == 20 and c3["warmup"] == 6      # (host- as much as device-bound: 82.6-90.0 ms by run and box)
@@ -234,5 +234,54 @@ def test_round5_profiles_parse_and_agree(tag):
         k3 = open(os.path.join(ROOT, "profiles", f"{tag}_config3_bench_kernel_stats.csv")).read()
         for name in ("pack_conv_multi_kernel", "weight_norm_multi_fwd_kernel", "weight_norm_multi_bwd_kernel", "wgrad_finish_kernel", "wn_step_fwd_kernel", "l1_mean_fwd_kernel"):
             assert name in k3, name
-        design = open(os.path.join(ROOT, "DESIGN.md")).read()
-        assert f"**{head['ms_per_step']:.1f} ms/step" in design and f"`frac` {r['frac']:.3f}" in design and f"{int(m.group(1)):,d}".replace(",", " ") + " launches" in design
+        # (round 5 tied DESIGN.md's numbers to these files; DESIGN.md describes round 6 now: test_round6_profiles_parse_agree_and_name_their_build)
+
+
+def test_round6_profiles_parse_agree_and_name_their_build():
+    """profiles/r06_a_* (`tools/profile_round.sh r06_a`, `r06_a_config{2,3,5} --config N`; the end state of round 6).  `value` is quoted on the two-stream batch rotation
+    (visinger_amd.synth.StreamRotation) and the roofline comes from the single-stream pass of the same process; the rocprofv3 summaries are of `--streams 1` runs, so
+    rocprofv3's average launch of the dominant instance equals the HIP-event average of the profiled line.  EVERY summary names the sources its library was built from
+    (VERDICT r5 #10) and that hash is the tree's: a kernel edit after the last profile fails here until the profile is redone.  DESIGN.md's round-6 numbers are these files'."""
+    import bench
+    from visinger_amd.csrc import build
+    tag = "r06_a"
+    tree = build.source_hash()
+    out = open(os.path.join(ROOT, "profiles", f"{tag}_bench_stdout.txt")).read()
+    lines = [x for x in out.splitlines() if x.strip()]
+    assert len(lines) == 4 and all(len(x) < 4096 for x in lines)
+    c2, c3, c5, head = (json.loads(x) for x in lines)
+    assert (c2["config"]["baseline_config"], c3["config"]["baseline_config"], c5["config"]["baseline_config"]) == (2, 3, 5)
+    for ln in (c2, c3, c5, head):
+        assert ln["config"]["vs_source_hash"] == tree[:16], "the committed profile was taken on other sources than the tree's: redo tools/profile_round.sh"
+    assert head["config"]["per_gpu_batch"] == 32 and head["config"]["t_mel"] == 1024 and head["steps"] == 30 and head["warmup"] == 10 and head["config"]["streams"] == 2
+    assert head["value"] > 115e6 and head["ms_per_step"] < 72.0 and head["waveform_max_abs_err"] <= 1e-4 and head["flow_logdet_rel_err"] <= 1e-4
+    assert head["single_stream"]["ms_per_step"] > head["ms_per_step"] and "single-stream" in head["roofline"]["measured_on"]
+    r = head["roofline"]
+    dom = "conv_ktap_kernel<11, 1, 2, 0, 4, 1, 8, 1>"
+    assert r["kernel"] == dom and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and abs(r["peak"] - 2500.0 / 3) < 1e-3 and r["frac"] > 0.45
+    cb = head["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["runs"] == 3 and cb["items"] == 1 and head["fp32_mfma_engine"]["ms_per_step"] > 1.8 * head["ms_per_step"]
+    assert c2["cpu_baseline"]["items"] == 8 and c2["cpu_baseline"]["of_items"] == 8 and c2["cpu_baseline"]["waveform_max_abs_err"] <= 1e-4
+    assert c5["oracle_check"]["layer_rms_rel_err"] <= c5["oracle_check"]["tolerance_rms_rel"] and c3["losses_finite"] is True
+    prof = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench_line_profiled.json")).read())
+    assert prof["config"]["streams"] == 1 and prof["config"]["vs_source_hash"] == tree[:16]
+    with open(os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv"), newline="") as f:
+        rows = {row["Name"]: row for row in csv.DictReader(f)}
+    avg_ms = float(rows["void vs::%s(vs::ConvParams)" % dom]["AverageNs"]) * 1e-6
+    assert prof["roofline"]["kernel"] == dom and abs(avg_ms - prof["roofline"]["avg_launch_ms"]) <= 0.02 * avg_ms
+    assert any("resblock_f16_kernel<4, 2, 4, 28>" in n for n in rows)                                  # 64 channels, wide halo: 512-column tiles
+    keys = {tag: bench.HEADLINE_WORKLOAD, tag + "_config2": "c2_B8_T512_h192_hop256_f32", tag + "_config3": "c3_B16_T512_h192_hop256_f32", tag + "_config5": "B8_T4096_h512_hop256_bf16"}
+    for tg, key in keys.items():
+        for kind in ("traffic", "mfma_busy"):
+            d = json.load(open(os.path.join(ROOT, "profiles", f"{tg}_pmc_{kind}.json")))
+            assert d["workload"] == key and d["vs_source_hash"] == tree, (tg, kind)
+        meta = json.load(open(os.path.join(ROOT, "profiles", f"{tg}_meta.json")))
+        assert meta["vs_source_hash"] == tree and "--streams 1" in meta["kernel_stats"]
+        assert os.path.getsize(os.path.join(ROOT, "profiles", f"{tg}_bench_kernel_stats.csv")) > 1000
+    assert bench.pmc_traffic(dom)["source"].startswith("recorded: profiles/r06_")                      # the newest summary is the one a bench line cites
+    t5 = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_config5_pmc_traffic.json")))["kernels"]
+    assert "relattn_dma_kernel<8,2>" in t5
+    m = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_busy.json")))["kernels"][dom.replace(" ", "")]
+    assert m["mfma_pipe_util"] >= 0.70 and m["gfx_clock_ghz"] < 1.7
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert f"**{head['ms_per_step']:.1f} ms/step" in design and f"`frac` {r['frac']:.3f}" in design
