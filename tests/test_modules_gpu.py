@@ -150,6 +150,11 @@ def test_mha(tag):
     with torch.no_grad():
         close(m(x, x, attn_mask), a["y"])              # the reference's 4-D mask argument
         close(m(x, x, frame_mask=mask), a["y"])
+        assert m.attn is None                          # the streaming kernel keeps no [T, T] tensor ...
+        m.store_attn = True                            # ... unless asked: the reference's `self.attn` (rel_transformer.py:143, 171), pinned to ITS probabilities
+        close(m(x, x, frame_mask=mask), a["y"])
+        assert m.attn.shape == a["p_attn"].shape
+        close(m.attn, a["p_attn"])
 
 
 @pytest.mark.parametrize("tag", ["mha_proximal", "mha_block", "mha_proximal_block"])

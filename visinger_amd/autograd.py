@@ -675,7 +675,7 @@ def attention(m, x, frame_mask):
     B, C, T = x.shape
     nh, dk, w = m.n_heads, m.k_channels, m.window_size
     plain_core = not getattr(m, "proximal_bias", False) and getattr(m, "block_length", None) is None      # (the streaming kernels carry neither option)
-    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and plain_core and not L.switch("VS_NO_TRAIN_ATTN"):
+    if x.is_cuda and dk <= 128 and (w is None or w <= 7) and T <= 65535 and plain_core and not m.__dict__.get("store_attn", False) and not L.switch("VS_NO_TRAIN_ATTN"):
         rel_k, rel_v = (m.emb_rel_k, m.emb_rel_v) if w is not None else (None, None)
         pd = m.drop.p if m.training else 0.0
         plain = all(not hasattr(c, "weight_g") and c.bias is not None and c.kernel_size[0] == 1 for c in (m.conv_q, m.conv_k, m.conv_v))
@@ -720,6 +720,8 @@ def attention(m, x, frame_mask):
             bm = torch.ones_like(scores).triu(-m.block_length).tril(m.block_length)
             scores = scores * bm + -1e4 * (1 - bm)
     p = m.drop(F.softmax(scores, dim=-1))
+    if m.__dict__.get("store_attn", False):
+        m.attn = p                     # (rel_transformer.py:143: `x, self.attn = self.attention(...)` -- the probabilities behind the dropout)
     out = torch.matmul(p, v)
     if w is not None:
         # relative weights p[i, i + r - w] (zero outside the sequence) @ emb_rel_v: the same strided view of the zero-padded probabilities

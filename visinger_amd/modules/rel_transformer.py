@@ -92,7 +92,11 @@ class MultiHeadAttention(nn.Module):
         self.block_length = block_length
         self.proximal_bias = proximal_bias
         self.p_dropout = p_dropout
-        self.attn = None     # the [B, h, T, T] probabilities are never materialised by the streaming kernel
+        # `attn` -- the reference's non-persistent module state, the [B, h, T, T] probabilities of the last forward (rel_transformer.py:143, 171) -- is not
+        # materialised by the streaming kernels (O(T^2) memory that nothing on the path reads).  `store_attn = True` (per module) routes the forward through the
+        # [T, T] core on PyTorch-ROCm ops and keeps them, as the reference does on every call; pinned to the reference's own `attn` (tests/test_modules_gpu.py).
+        self.attn = None
+        self.store_attn = False
 
         self.k_channels = channels // n_heads
         self.conv_q = HipConv1d(channels, channels, 1)
@@ -150,7 +154,7 @@ class MultiHeadAttention(nn.Module):
             return autograd.attention(self, x * frame_mask.reshape(B, 1, T) if (in_mask and frame_mask is not None) else x,
                                       None if frame_mask is None else frame_mask.reshape(B, T).float())
         _forward_only_guard(self)
-        if self.k_channels > 256 or self.proximal_bias or self.block_length is not None:
+        if self.k_channels > 256 or self.proximal_bias or self.block_length is not None or self.__dict__.get("store_attn", False):
             # (proximal_bias / block_length -- rel_transformer.py:163-170, never set by VISinger -- are not in the streaming kernels: the q / k / v / o convs on
             #  the HIP engine, the [T, T] core with the two options as PyTorch-ROCm ops, like the heads wider than 256 channels)
             # the streaming kernel covers heads of up to 256 channels (BASELINE config 5: hidden 512, 2 heads; the query tile
