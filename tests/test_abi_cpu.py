@@ -314,3 +314,31 @@ def test_build_gate_refuses_packed_fp32_op_sel_on_the_second_source(tmp_path):
         build.check_packed_opsel(str(src), str(obj))
     for unit in ("conv_split", "conv_backward", "resblock_f16"):          # (the units that held such instructions before round 6, and the one that packs by hand)
         assert build.packed_opsel_hits(build.device_isa(os.path.join(build.HERE, unit + ".o"))) == [], unit
+
+
+def test_weight_range_check_flags_convs_one_scale_cannot_carry():
+    """hipconv.select_math_by_weight_range (the load-time check for real checkpoints) on the host: the drop of the weakest output row below the
+    conv's largest weight, for plain and weight-normed Conv1d and for ConvTranspose1d (whose output channel is dim 1), all-zero rows ignored; convs beyond the
+    bound move to the exact bf16 x3 split, convs already on another arithmetic are left alone."""
+    import torch
+    from torch.nn.utils import weight_norm
+    from visinger_amd import _lib as L
+    from visinger_amd.modules.hipconv import HipConv1d, HipConvTranspose1d, select_math_by_weight_range, weight_row_drop_bits
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({
+        "plain": HipConv1d(16, 8, 3), "ranged": HipConv1d(16, 8, 3), "normed": weight_norm(HipConv1d(16, 8, 3)), "tr": weight_norm(HipConvTranspose1d(8, 6, 4, 2)),
+        "zero_row": HipConv1d(16, 8, 1), "other_math": HipConv1d(16, 8, 3)})
+    with torch.no_grad():
+        net["ranged"].weight[3] *= 2.0 ** -14                       # one output row 14 bits down
+        net["normed"].weight_g[5] *= 2.0 ** -12                     # a weight-norm gain does the same
+        net["tr"].weight_v[:, 2] *= 2.0 ** -11                      # ConvTranspose1d: output channel 2 (dim 1); weight norm runs over dim 0
+        net["zero_row"].weight[1] = 0.0                             # a pruned row is not a range problem
+        net["other_math"].weight[0] *= 2.0 ** -20
+    net["other_math"].__dict__["_hip_math"] = L.MATH_F32
+    drops = {k: weight_row_drop_bits(m) for k, m in net.items()}
+    assert drops["plain"] < 2 and 13 < drops["ranged"] < 16 and 11 < drops["normed"] < 14 and 10 < drops["tr"] < 13 and drops["zero_row"] < 2
+    switched = dict(select_math_by_weight_range(net))
+    assert set(switched) == {"ranged", "normed", "tr"}
+    assert all(net[k].__dict__["_hip_math"] == L.MATH_SPLIT6 for k in switched)
+    assert "_hip_math" not in net["plain"].__dict__ and net["other_math"].__dict__["_hip_math"] == L.MATH_F32
+    assert select_math_by_weight_range(net) == []                    # idempotent: what it moved is no longer on the split-f16 arithmetic
