@@ -242,6 +242,42 @@ def test_stream_rotation_gives_the_same_waveforms_as_one_stream(tiny):
     assert len(synth.bucket_by_length([len(it["mel2ph"]) for it in items], budget)) >= 6
 
 
+def test_inference_under_autocast_runs_the_bf16_operand_arithmetic(tiny):
+    """the reference's `amp: true` (config/models/base_config.yaml:5, utils/commons/trainer.py:325: autocast around the forward): inside torch.autocast("cuda") the
+    inference modules compute with bf16 operands and fp32 accumulation -- bit for bit what set_conv_math(model, L.MATH_BF16) gives wherever no aten matmul sits in
+    between (the generator), and the model returns to its own arithmetic afterwards; the training path refuses an autocast region."""
+    from visinger_amd import _lib as L
+    from visinger_amd.modules.hipconv import set_conv_math
+    m, a, hp, _ = tiny
+    cu = lambda k: torch.from_numpy(a[k]).cuda()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    z = torch.randn(2, m.hidden_size, 24, device="cuda", generator=g)
+    spk = m.speaker_embedding(None, cu("spk_id")).transpose(1, 2).contiguous()
+    with torch.no_grad():
+        plain = m.decoder(z, g=spk)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            amp = m.decoder(z, g=spk)
+            whole = m(cu("text"), cu("pitch"), cu("dur"), cu("mel2ph"), spk_id=cu("spk_id"), infer=True, noise=cu("noise"))["wav_out"]
+        again = m.decoder(z, g=spk)
+        set_conv_math(m.decoder, L.MATH_BF16)
+        try:
+            bf = m.decoder(z, g=spk)
+        finally:
+            set_conv_math(m.decoder, None)
+        last = m.decoder(z, g=spk)
+    assert amp.dtype == torch.float32 and torch.equal(amp, bf) and not torch.equal(amp, plain)
+    assert torch.equal(again, plain) and torch.equal(last, plain)                    # back on the arithmetic the handles were created with
+    assert float((amp - plain).abs().max()) <= 5e-2 * float(plain.abs().max()) + 1e-3
+    assert whole.dtype == torch.float32 and bool(torch.isfinite(whole).all())
+    m.train()
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with pytest.raises(NotImplementedError, match="autocast"):
+                m.decoder(z, g=spk)
+    finally:
+        m.eval()
+
+
 def test_batched_synthesis_driver_matches_single_items(tiny):
     """Length-bucketed batching is exact: an utterance synthesised inside a padded batch equals the same utterance
     synthesised alone (batch items are independent, padding is masked) -- what makes the utterance shard exact."""

@@ -307,7 +307,14 @@ def conv(m, x, lrelu=False, res=None):
 
 
 def training_path(module):
-    return module.training and torch.is_grad_enabled()
+    if module.training and torch.is_grad_enabled():
+        if torch.is_autocast_enabled("cuda"):
+            raise NotImplementedError(
+                "the HIP training path does not run inside a torch.autocast region (the reference's `amp: true`, utils/commons/trainer.py:325, default false): "
+                "its autograd Functions exchange fp32 tensors with aten ops that autocast would hand bf16 tensors to; inference modules do support autocast "
+                "(bf16 operands, fp32 accumulation: visinger_amd.modules.hipconv.apply_math)")
+        return True
+    return False
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -662,9 +669,8 @@ class _ConvHolder:
         ops = self.__dict__.setdefault("_hip_ops", {})
         if "fwd" not in ops:
             ops["fwd"] = ConvOp(L.CONV1D, self.in_channels, self.out_channels, self.kernel_size[0], self.dilation[0], self.padding[0], 0)
-        math = self.__dict__.get("_hip_math")
-        if math is not None and ops["fwd"].math != math:
-            ops["fwd"].set_math(math)
+        from .modules.hipconv import apply_math
+        apply_math(self.__dict__, ops["fwd"])
         return ops["fwd"]
 
 
@@ -728,7 +734,7 @@ def attention(m, x, frame_mask):
         pp = F.pad(p, (w, w))
         pw = pp.as_strided((B, nh, T, R), (pp.stride(0), pp.stride(1), T + 2 * w + 1, 1))
         out = out + torch.matmul(pw, m.emb_rel_v.unsqueeze(0))
-    out = out.transpose(2, 3).contiguous().view(B, C, T)
+    out = out.transpose(2, 3).contiguous().view(B, C, T).float()      # (.float(): inside an autocast region the matmuls above return bf16 tensors)
     return conv(m.conv_o, out)
 
 

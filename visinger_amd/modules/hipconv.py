@@ -23,6 +23,23 @@ def _forward_only_guard(module):
             "(which dispatches to visinger_amd.autograd) or call .eval() / torch.no_grad().")
 
 
+def apply_math(holder, op):
+    """Give handle `op` the arithmetic its module should run NOW: the module's explicit choice (set_conv_math); else, inside a `torch.autocast("cuda")` region,
+    bf16 operands with fp32 accumulation (L.MATH_BF16) -- the counterpart of the reference's `amp: true` (config/models/base_config.yaml:5,
+    utils/commons/trainer.py:325: its convs and matmuls then run in half precision; here the tensors stay fp32 and only the matrix-product operands are rounded,
+    with bfloat16's exponent range); else the arithmetic the handle was created with.  A handle re-packs its planes when its arithmetic changes, so a model that
+    alternates between autocast and full precision pays one re-pack per conv per switch.  INFERENCE modules only: the training path (visinger_amd.autograd)
+    refuses an autocast region (its Functions exchange fp32 tensors with aten ops that autocast would hand bf16 tensors to)."""
+    math = holder.get("_hip_math")
+    if math is None:
+        base = op.__dict__.get("_base_math")
+        if base is None:
+            base = op.__dict__["_base_math"] = op.math
+        math = L.MATH_BF16 if torch.is_autocast_enabled("cuda") else base
+    if op.math != math:
+        op.set_math(math)
+
+
 class _HipConvMixin:
     _kind = L.CONV1D
 
@@ -47,9 +64,7 @@ class _HipConvMixin:
                 ops[key] = ConvOp(kind, self.in_channels, self.out_channels, self.kernel_size[0],
                                   self.dilation[0], self.padding[0], flags)
         op = ops[key]
-        math = self.__dict__.get("_hip_math")
-        if math is not None and op.math != math:
-            op.set_math(math)
+        apply_math(self.__dict__, op)
         if bind:
             w, g = self._weights()
             op.set_weights(w, g, self.bias)
