@@ -342,3 +342,27 @@ def test_weight_range_check_flags_convs_one_scale_cannot_carry():
     assert all(net[k].__dict__["_hip_math"] == L.MATH_SPLIT6 for k in switched)
     assert "_hip_math" not in net["plain"].__dict__ and net["other_math"].__dict__["_hip_math"] == L.MATH_F32
     assert select_math_by_weight_range(net) == []                    # idempotent: what it moved is no longer on the split-f16 arithmetic
+
+
+def test_load_state_dict_runs_the_weight_range_check_by_itself():
+    """a checkpoint whose rows one scale per conv cannot carry switches THAT conv to the exact bf16 x3 split when it is loaded (HipConv*._load_from_state_dict ->
+    hipconv.auto_select_math); a later, ordinary checkpoint switches it back; an arithmetic the user chose explicitly is never touched"""
+    import torch
+    from torch.nn.utils import weight_norm
+    from visinger_amd import _lib as L
+    from visinger_amd.modules.hipconv import HipConv1d, set_conv_math
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(HipConv1d(16, 8, 3), weight_norm(HipConv1d(8, 8, 5)), HipConv1d(8, 4, 1))
+    ordinary = {k: v.clone() for k, v in net.state_dict().items()}
+    wide = {k: v.clone() for k, v in ordinary.items()}
+    wide["0.weight"][2] *= 2.0 ** -15
+    wide["1.weight_g"][4] *= 2.0 ** -13
+    net.load_state_dict(wide, strict=True)
+    assert net[0].__dict__.get("_hip_math") == L.MATH_SPLIT6 and net[1].__dict__.get("_hip_math") == L.MATH_SPLIT6 and "_hip_math" not in net[2].__dict__
+    net.load_state_dict(ordinary, strict=True)
+    assert all("_hip_math" not in m.__dict__ for m in net)
+    set_conv_math(net, L.MATH_F32)                                       # the user's choice ...
+    net.load_state_dict(wide, strict=True)
+    assert all(m.__dict__["_hip_math"] == L.MATH_F32 for m in net)       # ... survives a load
+    set_conv_math(net, None)
+    assert all("_hip_math" not in m.__dict__ and "_hip_math_auto" not in m.__dict__ for m in net)

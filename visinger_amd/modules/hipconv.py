@@ -84,6 +84,12 @@ class _HipConvMixin:
     def __getstate__(self):                      # handles are process-local (forward, backward-data and discriminator caches)
         return drop_process_local_state(self.__dict__.copy())
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        """nn.Module's loader for this conv's own tensors, then the weight-range check of INTEGRATION.md 4 on what was loaded (round 6): a real checkpoint whose
+        rows lie further apart than one power-of-two scale per conv can carry runs this conv on the exact bf16 x3 split without the user having to ask."""
+        super()._load_from_state_dict(*args, **kwargs)
+        auto_select_math(self)
+
 
 class HipConv1d(_HipConvMixin, nn.Conv1d):
     _kind = L.CONV1D
@@ -99,6 +105,7 @@ def set_conv_math(module, math):
     configuration).  None restores the library default for handles created afterwards."""
     for m in module.modules():
         if isinstance(m, _HipConvMixin):
+            m.__dict__.pop("_hip_math_auto", None)         # (an explicit choice replaces one the load-time weight-range check made)
             if math is None:
                 m.__dict__.pop("_hip_math", None)
             else:
@@ -137,8 +144,28 @@ def weight_row_drop_bits(conv):
     return float(torch.log2(row_max.max() / row_max.min()))
 
 
+def auto_select_math(conv, max_row_drop_bits=10.0):
+    """The per-conv form of select_math_by_weight_range, run by every HIP conv when a state dict is loaded into it.  An arithmetic chosen by the user
+    (set_conv_math) is left alone; a choice this function made earlier is re-made from the new weights."""
+    d = conv.__dict__
+    if "_hip_math" in d and not d.get("_hip_math_auto"):
+        return
+    try:
+        default = int(L.get_option("VS_CONV_MATH"))
+        drop = weight_row_drop_bits(conv)
+    except Exception:                      # (no library on this machine / parameters not materialised: nothing to decide at load time)
+        return
+    if default not in (-1, L.MATH_SPLIT3):
+        return
+    if drop > max_row_drop_bits:
+        d["_hip_math"], d["_hip_math_auto"] = int(L.MATH_SPLIT6), True
+    elif d.pop("_hip_math_auto", False):
+        d.pop("_hip_math", None)
+
+
 def select_math_by_weight_range(module, max_row_drop_bits=10.0, fallback=None):
-    """Load-time check for real checkpoints (call once after load_state_dict; it reads the weights on the host side of the stream: a synchronisation).
+    """Load-time check for real checkpoints.  `load_state_dict` runs it by itself, conv by conv (auto_select_math); call this after editing parameters in place, or
+    with another bound (it reads the weights on the host side of the stream: a synchronisation).
     Every HIP conv under `module` whose weakest output row sits more than `max_row_drop_bits` below its largest weight is switched from the split-f16
     arithmetic to `fallback` (default L.MATH_SPLIT6: three exact bf16 planes, no scale, any dynamic range, twice the matrix work).  With the default bound a
     weight 2^-13 below its ROW's largest still carries 17 significant bits.  Returns [(qualified module name, drop in bits)] of the convs it switched.
