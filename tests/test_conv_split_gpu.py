@@ -119,65 +119,11 @@ def test_set_conv_math_on_modules(oracle):
     assert 1e-6 < float((y1 - y0).abs().max()) <= 5e-2
 
 
-@pytest.mark.parametrize("dk,nh,T,ws,share", [(96, 2, 1024, 4, True), (64, 2, 260, 4, False), (128, 1, 516, None, True), (32, 4, 64, 4, True),
-                                              (192, 2, 300, 4, True), (256, 2, 1028, 4, True), (256, 1, 4, 1, True), (160, 1, 132, 7, False)])
-def test_bf16_attention_matches_fp32_kernel(dk, nh, T, ws, share):
-    """vs_relattn_fwd with math = VS_MATH_BF16 (csrc/attention_bf16.hip: q / sqrt(dk), k, v and the probabilities rounded to bf16, both
-    GEMMs on the bf16 MFMA, fp32 softmax statistics and relative terms) against the exact-fp32 kernel of the same entry point --
-    which tests/test_modules_gpu.py pins to the reference's golden vectors and the fuzzers to the fp64 oracle.  Ragged masks with an
-    all-padding item, key tiles cut by T, every head-width instance (DT 2, 3, 4: 64-key tiles; 6, 8: 32-key tiles).
-    Stated bf16 tolerance: operands carry 2^-9 relative error each -> scores off by ~2^-8 |q||k| / sqrt(dk) ~ 4e-3 absolute for N(0,1)
-    data, outputs (convex combinations of v) within ~1e-2 of the value scale."""
-    from visinger_amd.ops import rel_attention
-    g = torch.Generator().manual_seed(dk * 7 + T)
-    B, C = 3, dk * nh
-    qkv = torch.randn(B, 3 * C, T, generator=g).cuda()
+def _attention_fp64(qkv, nh, dk, rel_k, rel_v, mask, ws, share):
+    """fp64 restatement of the attention core (rel_transformer.py:148-179; masked rows attend uniformly: -1e4 fill) on a fused q|k|v buffer."""
+    B, C3, T = qkv.shape
+    C = C3 // 3
     nrel = 0 if ws is None else 2 * ws + 1
-    rel_k = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5).cuda() if nrel else None
-    rel_v = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5).cuda() if nrel else None
-    lens = torch.tensor([T, max(1, (2 * T) // 3), 0])
-    mask = (torch.arange(T)[None] < lens[:, None]).float().cuda()
-    ref = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_F32)
-    got = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=L.MATH_BF16)
-    assert torch.isfinite(got).all()
-    err = (got - ref).abs()
-    scale = float(ref.pow(2).mean().sqrt())
-    print(f"bf16 attention dk={dk} T={T}: max err {float(err.max()):.2e}, rms {float(err.pow(2).mean().sqrt()):.2e}, output rms {scale:.2e}")
-    assert float(err.pow(2).mean().sqrt()) <= 1e-2 * scale and float(err.max()) <= 0.1 * max(scale, 1e-3)
-    # the library reports which kernel ran: the bf16 one wherever the shape qualifies (T % 4 == 0 here)
-    from visinger_amd import _lib
-    assert _lib.lib().vs_last_kernel_name().decode().startswith(("relattn_bf16_kernel<", "relattn_dma_kernel<"))
-    # T not a multiple of 4: the bf16 request falls back to the exact-fp32 kernel (bit-identical to math = F32)
-    if T > 8:
-        q3 = qkv[:, :, :T - 1].contiguous()
-        m3 = mask[:, :T - 1].contiguous()
-        a = rel_attention(q3, nh, rel_k, rel_v, m3, ws, math=L.MATH_BF16)
-        assert _lib.lib().vs_last_kernel_name().decode().startswith("relattn_kernel<")
-        assert torch.equal(a, rel_attention(q3, nh, rel_k, rel_v, m3, ws, math=L.MATH_F32))
-
-
-@pytest.mark.parametrize("dk,nh,T,ws,share", [(96, 2, 1024, 4, True), (64, 2, 260, 4, False), (128, 1, 516, None, True), (32, 4, 64, 4, True),
-                                              (96, 2, 36, 4, True), (80, 3, 132, 7, False)])
-def test_split6_attention_is_fp32_class(oracle, dk, nh, T, ws, share):
-    """vs_relattn_fwd with math = VS_MATH_SPLIT6 (the default arithmetic of the path; csrc/attention_bf16.hip with TERMS = 6: q / sqrt(dk),
-    k, v and the probabilities split exactly into three bf16 planes, six cross products per product) against the exact-fp32 MFMA
-    kernel AND the fp64 oracle (rel_transformer.py:148-179): fp32-class agreement -- the same bar the fp32 kernel is held to."""
-    from visinger_amd.ops import rel_attention
-    from visinger_amd import _lib
-    g = torch.Generator().manual_seed(dk * 11 + T)
-    B, C = 3, dk * nh
-    qkv = torch.randn(B, 3 * C, T, generator=g)
-    nrel = 0 if ws is None else 2 * ws + 1
-    rel_k = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5) if nrel else None
-    rel_v = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5) if nrel else None
-    lens = torch.tensor([T, max(1, (2 * T) // 3), 0])
-    mask = (torch.arange(T)[None] < lens[:, None]).float()
-    cu = lambda t: None if t is None else t.cuda()
-    ref32 = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_F32)
-    got = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_SPLIT6)
-    assert _lib.lib().vs_last_kernel_name().decode().startswith("relattn_bf16_kernel<") and _lib.lib().vs_last_kernel_name().decode().endswith(", 6>")
-    assert float((got - ref32).abs().max()) <= 2e-5
-    # fp64 oracle of the same attention core (masked rows attend uniformly: -1e4 fill)
     q, k, v = (qkv[:, i * C:(i + 1) * C].double().view(B, nh, dk, T).transpose(2, 3) for i in range(3))
     sc = (q / dk ** 0.5) @ k.transpose(-1, -2)
     idx = torch.arange(T)
@@ -197,11 +143,92 @@ def test_split6_attention_is_fp32_class(oracle, dk, nh, T, ws, share):
         ok = (cols >= 0) & (cols < T)
         pw = torch.gather(pr, 3, cols.clamp(0, T - 1)[None, None].expand(B, nh, T, nrel)) * ok
         out = out + pw @ rv[None]
-    ref64 = out.transpose(2, 3).reshape(B, C, T)
+    return out.transpose(2, 3).reshape(B, C, T)
+
+
+@pytest.mark.parametrize("math", [L.MATH_SPLIT6, L.MATH_SPLIT3])
+@pytest.mark.parametrize("dk,nh,T,ws,share", [(96, 2, 1024, 4, True), (64, 2, 260, 4, False), (128, 1, 516, None, True), (32, 4, 64, 4, True),
+                                              (96, 2, 36, 4, True), (80, 3, 132, 7, False)])
+def test_split_attention_is_fp32_class(oracle, dk, nh, T, ws, share, math):
+    """vs_relattn_fwd in the two split arithmetics of csrc/attention_bf16.hip -- VS_MATH_SPLIT6 (TERMS = 6: q / sqrt(dk), k, v and the
+    probabilities split exactly into three bf16 planes, six cross products per product) and VS_MATH_SPLIT3 (TERMS = 3, the default
+    arithmetic of the path since round 6: two f16 planes under power-of-two scales -- per query, per K tile, running per V tile -- three
+    cross products) -- against the exact-fp32 MFMA kernel AND the fp64 restatement (rel_transformer.py:148-179): fp32-class agreement,
+    the same bar the fp32 kernel is held to."""
+    from visinger_amd.ops import rel_attention
+    from visinger_amd import _lib
+    g = torch.Generator().manual_seed(dk * 11 + T)
+    B, C = 3, dk * nh
+    qkv = torch.randn(B, 3 * C, T, generator=g)
+    nrel = 0 if ws is None else 2 * ws + 1
+    rel_k = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5) if nrel else None
+    rel_v = (torch.randn(1 if share else nh, nrel, dk, generator=g) * dk ** -0.5) if nrel else None
+    lens = torch.tensor([T, max(1, (2 * T) // 3), 0])
+    mask = (torch.arange(T)[None] < lens[:, None]).float()
+    cu = lambda t: None if t is None else t.cuda()
+    ref32 = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_F32)
+    got = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=math)
+    inst = _lib.lib().vs_last_kernel_name().decode()
+    assert inst.startswith("relattn_bf16_kernel<") and inst.endswith(", 6>" if math == L.MATH_SPLIT6 else ", 3>"), inst
+    assert float((got - ref32).abs().max()) <= 2e-5
+    ref64 = _attention_fp64(qkv, nh, dk, rel_k, rel_v, mask, ws, share)
     e6 = float((got.cpu().double() - ref64).abs().max())
     e32 = float((ref32.cpu().double() - ref64).abs().max())
-    print(f"attention dk={dk} T={T}: max err vs fp64 split6 {e6:.2e}, fp32 MFMA {e32:.2e}")
+    print(f"attention dk={dk} T={T} {inst}: max err vs fp64 split {e6:.2e}, fp32 MFMA {e32:.2e}")
     assert e6 <= 2e-5 and e6 <= 3.0 * e32 + 2e-6
+
+
+@pytest.mark.parametrize("case", ["ramp_up", "ramp_down", "channel_gains", "outlier_keys", "tiny", "huge"])
+def test_split_f16_attention_scales_follow_the_data(case):
+    """The power-of-two scales of the split-f16 attention (csrc/attention_bf16.hip, TERMS = 3) on inputs that move them: K / V magnitudes that
+    grow or shrink by 2^24 along the sequence (every K tile under its own scale; the V scale runs upwards and the output accumulators are
+    rescaled when a tile raises it), per-channel gains over 2^-8 .. 2^8, single keys 2^12 above their neighbours, inputs near 2^-60 and
+    near 2^40 (far outside the f16 range without the scales).  Bar: the fp32 MFMA kernel's own error against the fp64 restatement, three
+    times over, relative to the largest output of the (batch, head)."""
+    from visinger_amd.ops import rel_attention
+    from visinger_amd import _lib
+    dk, nh, T, ws, B = 96, 2, 516, 4, 2
+    C = dk * nh
+    g = torch.Generator().manual_seed(len(case))
+    qkv = torch.randn(B, 3 * C, T, generator=g)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    t = torch.arange(T, dtype=torch.float32) / (T - 1)
+    if case in ("ramp_up", "ramp_down"):
+        e = 24.0 * (t if case == "ramp_up" else 1 - t) - 12.0
+        v *= torch.exp2(e)[None, None]
+        k *= torch.exp2(e / 8)[None, None]                       # (scores stay in a range where several keys share a row's weight)
+        q *= 0.2
+    elif case == "channel_gains":
+        gain = torch.exp2(torch.rand(3 * C, generator=g) * 16 - 8)
+        gain[:C] = 1.0 / gain[C:2 * C]                            # q against k: the products stay O(1), the operands do not
+        qkv *= gain[None, :, None]
+    elif case == "outlier_keys":
+        pos = torch.randint(0, T, (12,), generator=g)
+        v[:, :, pos] *= 4096.0
+        k[:, :, pos] *= 4.0
+    elif case == "tiny":
+        v *= 2.0 ** -60
+        k *= 2.0 ** -30
+        q *= 2.0 ** 30
+    elif case == "huge":
+        v *= 2.0 ** 40
+        k *= 2.0 ** 20
+        q *= 2.0 ** -20
+    rel_k = torch.randn(1, 2 * ws + 1, dk, generator=g) * dk ** -0.5
+    rel_v = torch.randn(1, 2 * ws + 1, dk, generator=g) * dk ** -0.5 * float(v.abs().mean())
+    mask = torch.ones(B, T)
+    mask[1, (3 * T) // 4:] = 0
+    cu = lambda x: x.cuda().contiguous()
+    ref32 = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_F32)
+    got = rel_attention(cu(qkv), nh, cu(rel_k), cu(rel_v), cu(mask), ws, math=L.MATH_SPLIT3)
+    assert _lib.lib().vs_last_kernel_name().decode() == "relattn_bf16_kernel<3, 32, 3>"
+    assert bool(torch.isfinite(got).all())
+    ref64 = _attention_fp64(qkv, nh, dk, rel_k, rel_v, mask, ws, True)
+    scale = ref64.view(B, nh, dk, T).abs().amax(dim=(2, 3), keepdim=True).clamp_min(1e-300)
+    rel = lambda x: float(((x.cpu().double() - ref64).view(B, nh, dk, T).abs() / scale).max())
+    e3, e32 = rel(got), rel(ref32)
+    print(f"split-f16 attention, {case}: max err / max|out| of the head: split-f16 {e3:.2e}, fp32 MFMA {e32:.2e}")
+    assert e3 <= 3.0 * e32 + 1e-6
 
 
 @pytest.mark.parametrize("kind,Cin,Cout,k,d_or_u,T,B", [(L.CONV1D, 256, 256, 7, 3, 1024, 2), (L.CONV1D, 128, 128, 11, 5, 700, 1), (L.CONV1D, 512, 256, 3, 1, 261, 2),
@@ -301,6 +328,8 @@ def test_fused_pair_and_conv_post_on_bf16_resident_tensors(C, k, d, T, B):
 
 
 @pytest.mark.parametrize("dk,nh,T,ws,share,B,math", [(96, 2, 1024, 4, True, 1, L.MATH_SPLIT6), (96, 2, 516, 4, True, 2, L.MATH_SPLIT6), (64, 2, 260, 4, False, 1, L.MATH_SPLIT6),
+                                                     (96, 2, 1024, 4, True, 1, L.MATH_SPLIT3), (96, 2, 516, 4, True, 2, L.MATH_SPLIT3), (64, 2, 260, 4, False, 1, L.MATH_SPLIT3),
+                                                     (128, 1, 2048, None, True, 1, L.MATH_SPLIT3),
                                                      (128, 1, 2048, None, True, 1, L.MATH_SPLIT6), (96, 2, 1024, 4, True, 1, L.MATH_BF16),
                                                      (256, 2, 1024, 4, True, 1, L.MATH_BF16)])
 def test_key_split_attention_equals_one_pass(dk, nh, T, ws, share, B, math):
@@ -322,7 +351,7 @@ def test_key_split_attention_equals_one_pass(dk, nh, T, ws, share, B, math):
     inst = L.lib().vs_last_kernel_name().decode()
     split = rel_attention(qkv, nh, rel_k, rel_v, mask, ws, math=math, ksplit_auto=True)
     assert inst.startswith(("relattn_bf16_kernel<", "relattn_dma_kernel<")) and bool(torch.isfinite(split).all())
-    tol = 2e-6 if math == L.MATH_SPLIT6 else 2e-3
+    tol = 2e-6 if math in (L.MATH_SPLIT6, L.MATH_SPLIT3) else 2e-3
     assert float((split - one).abs().max()) <= tol * max(1.0, float(one.abs().max())), float((split - one).abs().max())
 
 

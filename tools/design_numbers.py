@@ -68,7 +68,7 @@ def values(tag):
         "INST_K11": one("conv_ktap_kernel<11, 1, 2, 0, 4, 1, 8, 1>"), "INST_K7": one("conv_ktap_kernel<7, 1, 2, 0, 4, 1, 8, 1>"),
         "INST_K9": one("conv_ktap_kernel<9, 2, 2, 0, 4, 1, 8, 1>"), "INST_K3": one("conv_ktap_kernel<3, 1, 2, 0, 4, 1, 8, 1>"),
         "INST_RB": f"{rb[0]:.1f} / {rb[1]:.0f}–{rb[2]:.0f}", "RB_MS": f"{rb[0]:.1f}", "INST_TR": f"{trc[0]:.1f} / {trc[1]:.0f}–{trc[2]:.0f}", "TR_MS": f"{trc[0]:.1f}",
-        "INST_ATT": one("relattn_bf16_kernel<3, 32, 6>"), "INST_GATE": one("conv_ktap_kernel<5, 0, 2, 0, 2, 2, 2, 2>"),
+        "INST_ATT": one("relattn_bf16_kernel<3, 32, 3>"), "INST_GATE": one("conv_ktap_kernel<5, 0, 2, 0, 2, 2, 2, 2>"),
         "C2_MS": f"{c2['ms_per_step']:.1f}", "C2_MSPS": f"{c2['value'] / 1e6:.1f}", "C3_MS": f"{c3['ms_per_step']:.1f}",
         "C3_LAUNCH": f"{launches3:,d}".replace(",", " "), "C3_RP_LAUNCH": f"{calls3 / steps3:,.0f}".replace(",", " "), "C3_ATEN": f"{1 - vs3 / tot3:.2f}", "C3_DEV": f"{dev3:.1f}",
         "C5_MS": f"{c5['ms_per_step']:.1f}", "C5_MSPS": f"{c5['value'] / 1e6:.1f}", "C5ERR": f"{c5['oracle_check']['layer_rms_rel_err']:.1e}",

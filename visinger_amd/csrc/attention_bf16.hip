@@ -30,17 +30,31 @@ namespace vs {
 // writes per thread, no conversion -- in place, the fp32 -> bf16 conversion of a tile (64 values per thread at 256 channels: ~300 VALU
 // instructions next to 32 MFMAs per wave, one wave per SIMD) and its 64 KB of fp32 loads were repeated by every one of the T / 128 query
 // blocks.
+// e^x for the softmax arguments (x <= 0; -inf gives an exact 0) in seven VALU instructions: x log2(e) as a rounded product plus its exact
+// residual and the low word of log2(e), v_exp_f32 of the product, a first-order correction for the residual -- within ~1.5 ulp of expf,
+// whose library form (range reduction, scaling, the overflow / underflow selects) costs ~16: at 17 exponentials per 32-key tile per lane
+// the split kernels below are VALU-bound, not matrix-bound (round 6: 3 300 of a tile's cycles per wave were VALU issue).
+template <bool GUARD>          // GUARD: the argument may be -inf
+__device__ __forceinline__ float exp_nonpos(float x) {
+    if constexpr (GUARD) x = fmaxf(x, -150.f);                               // (2^-216 -> 0: below the fp32 denormals; -inf would give inf - inf)
+    const float t = x * 1.44269502162933349609375f;
+    const float e = __builtin_fmaf(x, 1.9259629911266174681e-8f, __builtin_fmaf(x, 1.44269502162933349609375f, -t));
+    const float y = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(y, e * 0.693147182464599609375f, y);
+}
+
 template <int DT, int AKT, int TERMS, bool PK = false>
 __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(const AttnParams p) {
-    static_assert(TERMS == 1 || TERMS == 6, "plain bf16 or split-bf16 x6");
+    static_assert(TERMS == 1 || TERMS == 3 || TERMS == 6, "plain bf16, split-f16 x3 or split-bf16 x6");
     static_assert(!PK || TERMS == 1, "pre-packed tiles: plain-bf16 arithmetic");
-    constexpr int NPL = (TERMS == 6) ? 3 : 1;
-    constexpr int NBUF = (TERMS == 6) ? 1 : 2;
+    constexpr bool F16 = (TERMS == 3);
+    constexpr int NPL = (TERMS == 6) ? 3 : (F16 ? 2 : 1);
+    constexpr int NBUF = (TERMS == 1) ? 2 : 1;
     constexpr int DKR = DT * 32;                     // padded head dim
     constexpr int NKS = DKR / 16;                    // k-steps of S^T = K^T Q
     constexpr int NKT = AKT / 32;                    // S^T accumulator tiles per key tile
     constexpr int KQ = AKT / 4;                      // key quads per tile
-    constexpr int KW = (TERMS == 6) ? 2 : 4;         // keys per K staging cell (work per thread x planes: finer cells for the split)
+    constexpr int KW = (TERMS == 1) ? 4 : 2;         // keys per K staging cell (work per thread x planes: finer cells for the split)
     constexpr int KQW = AKT / KW;                    // K cells along the keys
     constexpr int AVP = AKT / 2 + 4;                 // V row pitch in dwords (AKT keys x 2 B + 16 B: conflict-free ds_read_b128 down a column)
     constexpr int KCELLS = (DKR / 8) * KQW;          // (d8, key group) cells of the K tile, 8 loads of KW floats each
@@ -62,11 +76,24 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     const int dk = p.dk, T = p.T;
     const int nrel = (p.ws >= 0 && p.rel_k) ? 2 * p.ws + 1 : 0;
 
+#ifdef VS_ATTN_STAMPS      // (tools/build_variant.py: shader-clock stamps of workgroup (0, 0, 0), wave 0 -- tools/attn_phase_stamps.py)
+#define BSTAMP(k)                                                                                                    \
+    do {                                                                                                             \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0) {                        \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+            if (lane == 0) p.stamps[(k)] = t_;                                                                       \
+        }                                                                                                            \
+    } while (0)
+#else
+#define BSTAMP(k) do { } while (0)
+#endif
+    BSTAMP(0);
     unsigned *Ks = reinterpret_cast<unsigned *>(smem);      // [NBUF][plane][DKR/8][AKT keys][4 dwords]
     unsigned *Vs = Ks + NBUF * KBUF;                         // [NBUF][plane][DKR][AVP]
     float *Ms = reinterpret_cast<float *>(Vs + NBUF * VBUF); // [2][AKT] key mask of the tile
     float *QRs = Ms + 2 * AKT;                               // [4][32][ATT_QRS] rel-key logits
     float *Sws = QRs + 4 * 32 * ATT_QRS;                     // [4][32][ATT_QRS] in-window raw scores
+    unsigned *Xs = reinterpret_cast<unsigned *>(Sws + 4 * 32 * ATT_QRS);   // [2][4] split-f16: each wave's largest exponent of the staged K / V tile; [8 + buffer]: tile without masked keys
     float *RVs = smem;                                       // [nrel][dk] relative value embeddings: over the K buffers, after the loop
 
     const float *qb = p.q + (long long)b * p.bs + (long long)h * dk * T;
@@ -83,7 +110,10 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     auto planes8 = [&](const float (&v)[8], u32x4 (&f)[NPL]) __attribute__((always_inline)) {
         unsigned d[4][NPL];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) split_pair<NPL>(v[2 * t], v[2 * t + 1], d[t]);
+        for (int t = 0; t < 4; ++t) {
+            if constexpr (F16) split_pair_h(v[2 * t], v[2 * t + 1], d[t]);
+            else split_pair<NPL>(v[2 * t], v[2 * t + 1], d[t]);
+        }
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
             u32x4 o; o.x = d[0][pl]; o.y = d[1][pl]; o.z = d[2][pl]; o.w = d[3][pl];
@@ -95,41 +125,85 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         auto mm = [&](int ta, int tb) __attribute__((always_inline)) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ta]), __builtin_bit_cast(bf16x8, bq[tb]), c, 0, 0, 0);
         };
+        auto mh = [&](int ta, int tb) __attribute__((always_inline)) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ta]), __builtin_bit_cast(f16x8, bq[tb]), c, 0, 0, 0);
+        };
+        if constexpr (F16) { mh(NPL - 1, 0); mh(0, NPL - 1); mh(0, 0); return; }
         if constexpr (TERMS == 6) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); }
         mm(0, 0);
     };
-    u32x4 qf[NKS][NPL];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        float qv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = 16 * ks + 8 * half + j;
-            const float v = qb[(long long)min(d, dk - 1) * T + qic];
-            qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
-        }
-        planes8(qv, qf[ks]);
-    }
-    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] from the fp32 query (a rolled loop: prologue code, kept off the
-    // register budget of the main loop); each lane half covers every other group of 8 channels
+    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] in fp32, from the very query values the fragments are made of: the table goes
+    // into LDS once per workgroup, transposed and zero-padded ([d][16], over the K buffer, which nothing has touched yet), and every lane
+    // walks the 8-channel groups of its half with one broadcast ds_read_b128 per four window positions.  (Round 6: the rolled loop this
+    // replaces -- a global load of q and nine of rel_k per channel, one channel in flight -- was 88 000 of the 325 000 cycles of a launch at
+    // T = 1024, tools/attn_phase_stamps.py.)
+    float *RKs = smem;
     float qr[ATT_MAXREL];
 #pragma unroll
     for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
     if (nrel) {
-#pragma unroll 1
-        for (int d8 = half; d8 < (dk + 7) / 8; d8 += 2) {
-#pragma unroll 1
-            for (int j = 0; j < 8; ++j) {
-                const int d = 8 * d8 + j;
-                if (d < dk && qi < T) {
-                    const float qs = qb[(long long)d * T + qic] * p.scale;
+        for (int e = tid; e < DKR * ATT_MAXREL; e += 256) {
+            const int d = e / ATT_MAXREL, r = e % ATT_MAXREL;
+            RKs[e] = (d < dk && r < nrel) ? relk[r * dk + d] : 0.f;
+        }
+    }
+    __syncthreads();
+    auto qr_add = [&](const float (&qv)[8], int ks) __attribute__((always_inline)) {
+        if (!nrel) return;
 #pragma unroll
-                    for (int r = 0; r < ATT_MAXREL; ++r)
-                        if (r < nrel) qr[r] += qs * relk[r * dk + d];
+        for (int j = 0; j < 8; ++j) {
+            const float4 *row = reinterpret_cast<const float4 *>(RKs + (16 * ks + 8 * half + j) * ATT_MAXREL);
+#pragma unroll
+            for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {
+                if (4 * c4 < nrel) {
+                    const float4 w = row[c4];
+                    qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
                 }
             }
         }
+    };
+    u32x4 qf[NKS][NPL];
+    float q_inv = 1.f;                               // split-f16: 1 / (the power-of-two scale of this lane's query)
+    if constexpr (F16) {
+        // every query under its own scale (largest |q| / sqrt(dk) over the head's channels just below 2^15): a scale per COLUMN of S^T
+        float qv[NKS][8];
+        unsigned key = 0;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * ks + 8 * half + j;
+                const float v = qb[(long long)min(d, dk - 1) * T + qic];
+                qv[ks][j] = (d < dk && qi < T) ? v * p.scale : 0.f;
+                key = f16_maxkey(key, qv[ks][j]);
+            }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qr_add(qv[ks], ks);
+        key = max(key, (unsigned)__shfl_xor((int)key, 32));
+        const int eq = max(f16_key_exponent(key), F16_EB_MIN);
+        const float sq = f16_scale(eq);
+        q_inv = f16_inv_scale(eq);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv[ks][j] *= sq;
+            planes8(qv[ks], qf[ks]);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            float qv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * ks + 8 * half + j;
+                const float v = qb[(long long)min(d, dk - 1) * T + qic];
+                qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
+            }
+            qr_add(qv, ks);
+            planes8(qv, qf[ks]);
+        }
     }
+    BSTAMP(1);
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
     for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
@@ -141,6 +215,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         }
     }
 
+    BSTAMP(2);
     // ---- K / V tile staging ----
     constexpr int KU4 = KPL / 4, VU4 = VPL / 4;                          // 16-byte units of the K / V images (PK)
     constexpr int KIPT = (KU4 + 255) / 256, VIPT = (VU4 + 255) / 256;
@@ -196,7 +271,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             vst[i] = *reinterpret_cast<const float4 *>(vb + (long long)d * T + jc);
         }
     };
-    auto store_k = [&](int jt, int buf) __attribute__((always_inline)) {
+    auto store_k = [&](int jt, int buf, float sk) __attribute__((always_inline)) {
         const int j0 = jt * AKT;
         unsigned *Kb = Ks + buf * KBUF;
         if constexpr (PK) {
@@ -204,6 +279,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             for (int i = 0; i < KIPT; ++i)
                 if (KU4 % 256 == 0 || tid + 256 * i < KU4) reinterpret_cast<u32x4 *>(Kb)[tid + 256 * i] = kimg[i];
             if (tid < AKT) Ms[buf * AKT + tid] = mst;
+            if (wave == 0) { const bool pl = __all(lane >= AKT || (mst != 0.f && j0 + lane < T)); if (lane == 0) Xs[8 + buf] = pl; }
             return;
         }
 #pragma unroll
@@ -216,7 +292,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
                 for (int e = 0; e < KW; ++e) {
                     float v[8];
 #pragma unroll
-                    for (int jd = 0; jd < 8; ++jd) v[jd] = (okj && 8 * d8 + jd < dk) ? kst[i][jd][e] : 0.f;
+                    for (int jd = 0; jd < 8; ++jd) v[jd] = (okj && 8 * d8 + jd < dk) ? (F16 ? kst[i][jd][e] * sk : kst[i][jd][e]) : 0.f;
                     u32x4 f[NPL];
                     planes8(v, f);
 #pragma unroll
@@ -225,8 +301,10 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             }
         }
         if (tid < AKT) Ms[buf * AKT + tid] = (j0 + tid < T) ? mst : 1.f;
+        // a tile wholly inside the sequence with no masked key: the score loop of its consumers skips the mask / range selects
+        if (wave == 0) { const bool pl = __all(lane >= AKT || (mst != 0.f && j0 + lane < T)); if (lane == 0) Xs[8 + buf] = pl; }
     };
-    auto store_v = [&](int jt, int buf) __attribute__((always_inline)) {
+    auto store_v = [&](int jt, int buf, float sv) __attribute__((always_inline)) {
         const int j0 = jt * AKT;
         unsigned *Vb = Vs + buf * VBUF;
         if constexpr (PK) {
@@ -242,8 +320,13 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             const bool ok = (j0 + 4 * kq < T) && (d < dk);
             const float4 t4 = vst[i];
             unsigned lo[NPL], hi[NPL];
-            split_pair<NPL>(ok ? t4.x : 0.f, ok ? t4.y : 0.f, lo);
-            split_pair<NPL>(ok ? t4.z : 0.f, ok ? t4.w : 0.f, hi);
+            if constexpr (F16) {
+                split_pair_h(ok ? t4.x * sv : 0.f, ok ? t4.y * sv : 0.f, lo);
+                split_pair_h(ok ? t4.z * sv : 0.f, ok ? t4.w * sv : 0.f, hi);
+            } else {
+                split_pair<NPL>(ok ? t4.x : 0.f, ok ? t4.y : 0.f, lo);
+                split_pair<NPL>(ok ? t4.z : 0.f, ok ? t4.w : 0.f, hi);
+            }
             // keys 4kq .. 4kq+3 of 16-group kq >> 2: quads (0, 1, 2, 3) of a group sit in slots (0, 2, 1, 3)
             const int slot = ((kq & 1) << 1) | ((kq >> 1) & 1);
 #pragma unroll
@@ -259,20 +342,58 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_half = 0.f;
     const float mi = (maskb && qi < T) ? maskb[qi] : 1.f;
+    const bool rows_plain = !__any(mi == 0.f);               // no masked query in this wave
 
     const int ntiles_all = (T + AKT - 1) / AKT;
     const int jt_lo = (int)((long long)ksi * ntiles_all / KSPL);
     const int ntiles = (int)((long long)(ksi + 1) * ntiles_all / KSPL);        // (end of this workgroup's key tiles)
+    // split-f16: the staged K tile and V tile each go under ONE power-of-two scale -- K's from the tile's own largest magnitude (a scale per
+    // tile is a common factor of a score tile), V's from the running maximum over the tiles so far (the output accumulators sum over tiles:
+    // when a tile raises it they are rescaled by the exact ratio, together with the softmax rescale).  Every wave reduces the exponents of
+    // what it staged (DPP), the four results cross through LDS under the barrier the single tile buffer needs anyway.
+    int ek_cur = F16_EB_MIN, ev_cur = F16_EB_MIN, ev_acc = F16_EB_MIN, ek_next = F16_EB_MIN, ev_run = F16_EB_MIN;
+    auto publish_exps = [&]() __attribute__((always_inline)) {
+        unsigned kk = 0, kv = 0;
+#pragma unroll
+        for (int i = 0; i < (PK ? 1 : KCPT); ++i)
+#pragma unroll
+            for (int jd = 0; jd < 8; ++jd)
+#pragma unroll
+                for (int e = 0; e < KW; ++e) kk = f16_maxkey(kk, kst[i][jd][e]);
+#pragma unroll
+        for (int i = 0; i < (PK ? 1 : VCPT); ++i) {
+            kv = f16_maxkey(kv, vst[i].x); kv = f16_maxkey(kv, vst[i].y); kv = f16_maxkey(kv, vst[i].z); kv = f16_maxkey(kv, vst[i].w);
+        }
+        const int wk = wave_max_u8(f16_key_exponent(kk)), wv = wave_max_u8(f16_key_exponent(kv));
+        if (lane == 0) { Xs[wave] = (unsigned)wk; Xs[4 + wave] = (unsigned)wv; }
+    };
+    auto collect_exps = [&]() __attribute__((always_inline)) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(Xs), c = *reinterpret_cast<const u32x4 *>(Xs + 4);
+        ek_next = __builtin_amdgcn_readfirstlane(max(max(max(a.x, a.y), max(a.z, a.w)), (unsigned)F16_EB_MIN));
+        ev_run = __builtin_amdgcn_readfirstlane(max(max(max(c.x, c.y), max(c.z, c.w)), (unsigned)ev_run));
+    };
     load_k(jt_lo);
     load_v(jt_lo);
-    store_k(jt_lo, 0);
-    store_v(jt_lo, 0);
+    if constexpr (F16) publish_exps();
+    __syncthreads();                                         // (every wave has read the rel-key table out of the K buffer)
+    if constexpr (F16) {
+        collect_exps();
+        ev_acc = ev_run;
+    }
+    store_k(jt_lo, 0, f16_scale(ek_next));
+    store_v(jt_lo, 0, f16_scale(ev_run));
     __syncthreads();
+    BSTAMP(3);
     for (int jt = jt_lo; jt < ntiles; ++jt) {
         const int j0 = jt * AKT;
         const int buf = (NBUF == 2) ? ((jt - jt_lo) & 1) : 0;
+#ifdef VS_ATTN_STAMPS
+        if (jt - jt_lo < 100) BSTAMP(16 + jt - jt_lo);
+#endif
         const unsigned *Kb = Ks + buf * KBUF, *Vb = Vs + buf * VBUF;
         const float *Mb = Ms + buf * AKT;
+        ek_cur = ek_next;
+        ev_cur = ev_run;
         // two buffers: the next tile's K is in flight under the S^T MFMAs and written once they have issued, its V is in flight under
         // the softmax and the P V MFMAs (the fp32 staging registers of a tile -- 64 KB of K + 64 KB of V at 256 channels -- are never
         // all live).  One buffer (split arithmetic): both are in flight under the whole tile and written between two barriers.
@@ -300,55 +421,94 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         }
         if constexpr (NBUF == 2) {
             if (jt + 1 < ntiles) {
-                store_k(jt + 1, buf ^ 1);
+                store_k(jt + 1, buf ^ 1, 1.f);
                 load_v(jt + 1);
             }
         }
         const bool near_diag = nrel && (j0 + AKT - 1 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
         float tmax = -INFINITY;
+        const float sfix = F16 ? f16_inv_scale(ek_cur) * q_inv : 1.f;      // (exact: powers of two)
+        // a tile wholly inside the sequence with no masked key, rows with no masked query (every tile of a full-length item): no selects
+        const bool plain = rows_plain && __builtin_amdgcn_readfirstlane((int)Xs[8 + buf]) != 0;
+        float mulf = 1.f;                                    // what the exponential's fma still has to multiply the scores by
+        if (plain && !near_diag) {
+            // away from the diagonal nothing is added to a score: the maximum of the raw accumulators (one v_max3 per pair) times the positive
+            // scale, and the scale itself rides in the fma that forms the exponential's argument
+            float mx = s[0][0];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int j = j0 + jj;
-                float sv = s[kt][r];
-                if (near_diag) {
-                    const int rel = j - qi;
-                    if (rel >= -p.ws && rel <= p.ws) sv += QRw[l31 * ATT_QRS + rel + p.ws];
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+            tmax = F16 ? mx * sfix : mx;
+            mulf = sfix;
+        } else if (plain) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sv = F16 ? s[kt][r] * sfix : s[kt][r];
+                    const int rel = j0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half - qi;
+                    if (rel >= -p.ws && rel <= p.ws) {
+                        sv += QRw[l31 * ATT_QRS + rel + p.ws];
+                        Sww[l31 * ATT_QRS + rel + p.ws] = sv;
+                    }
+                    s[kt][r] = sv;
+                    tmax = fmaxf(tmax, sv);
                 }
-                if (mi * Mb[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
-                if (j >= T) sv = -INFINITY;                  // beyond the sequence: not part of the softmax
-                if (near_diag) {
-                    const int rel = j - qi;
-                    if (rel >= -p.ws && rel <= p.ws && j < T) Sww[l31 * ATT_QRS + rel + p.ws] = sv;
+            }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int j = j0 + jj;
+                    float sv = F16 ? s[kt][r] * sfix : s[kt][r];
+                    if (near_diag) {
+                        const int rel = j - qi;
+                        if (rel >= -p.ws && rel <= p.ws) sv += QRw[l31 * ATT_QRS + rel + p.ws];
+                    }
+                    if (mi * Mb[jj] == 0.f) sv = -1e4f;          // masked_fill(mask == 0, -1e4)
+                    if (j >= T) sv = -INFINITY;                  // beyond the sequence: not part of the softmax
+                    if (near_diag) {
+                        const int rel = j - qi;
+                        if (rel >= -p.ws && rel <= p.ws && j < T) Sww[l31 * ATT_QRS + rel + p.ws] = sv;
+                    }
+                    s[kt][r] = sv;
+                    tmax = fmaxf(tmax, sv);
                 }
-                s[kt][r] = sv;
-                tmax = fmaxf(tmax, sv);
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
         float alpha;
-        if constexpr (TERMS == 6) alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+        if constexpr (TERMS != 1) alpha = (m_run == -INFINITY) ? 0.f : exp_nonpos<true>(m_run - m_new);
         else alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
         float psum = 0.f;
         u32x4 pf[2 * NKT][NPL];                              // P^T fragments of the 16-key k-steps
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             float pv[16];
+            if constexpr (TERMS != 1) {
+                if (plain) {                                 // (finite scores: no -inf to guard)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; ++r) pv[r] = exp_nonpos<false>(__builtin_fmaf(s[kt][r], mulf, -m_new));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pv[r] = exp_nonpos<true>(s[kt][r] - m_new);
+                }
+            } else {
                 // exp(-inf) = 0 for excluded keys; with one bf16 plane the result is rounded to 8 bits anyway: the fast exp
-                if constexpr (TERMS == 6) pv[r] = expf(s[kt][r] - m_new);
-                else pv[r] = __expf(s[kt][r] - m_new);
-                psum += pv[r];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = __expf(s[kt][r] - m_new);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += pv[r];
 #pragma unroll
             for (int sh = 0; sh < 2; ++sh) {
                 float v8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v8[e] = pv[8 * sh + e];
+                for (int e = 0; e < 8; ++e) v8[e] = F16 ? pv[8 * sh + e] * 16384.f : pv[8 * sh + e];      // (split-f16: p <= 1 under the scale 2^14)
                 planes8(v8, pf[2 * kt + sh]);
             }
         }
@@ -356,11 +516,19 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         m_run = m_new;
         // the running maximum of a row settles after a few tiles: skip the rescale of the output accumulators (a read-multiply-write
         // of DT * 16 registers per tile) whenever no query of the wave moved its maximum
-        if (__any(alpha != 1.f)) {
+        float oresc = alpha;
+        if constexpr (F16) {
+            if (ev_cur != ev_acc) {                          // this V tile sits under a smaller scale than the accumulators: bring them down to it
+                const int dl = ev_acc - ev_cur;              // < 0
+                oresc *= (dl < -126) ? 0.f : u2f((unsigned)(127 + dl) << 23);
+                ev_acc = ev_cur;
+            }
+        }
+        if (__any(oresc != 1.f)) {
 #pragma unroll
             for (int t = 0; t < DT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= oresc;
         }
 
         // ---- O^T += V P^T: k-step s4 sums over the keys 16 s4 + 8 (j >> 2) + 4 half + (j & 3), the order of the V rows ----
@@ -376,18 +544,24 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             }
         }
         if constexpr (NBUF == 2) {
-            if (jt + 1 < ntiles) store_v(jt + 1, buf ^ 1);
+            if (jt + 1 < ntiles) store_v(jt + 1, buf ^ 1, 1.f);
             __syncthreads();
         } else {
+            if constexpr (F16) {
+                if (jt + 1 < ntiles) publish_exps();
+            }
             __syncthreads();                                 // every wave is done with the (single) K / V buffer
             if (jt + 1 < ntiles) {
-                store_k(jt + 1, 0);
-                store_v(jt + 1, 0);
+                if constexpr (F16) collect_exps();
+                store_k(jt + 1, 0, f16_scale(ek_next));
+                store_v(jt + 1, 0, f16_scale(ev_run));
             }
             __syncthreads();
         }
     }
 
+    BSTAMP(4);
+    const float ounscale = F16 ? f16_inv_scale(ev_acc) : 1.f;      // split-f16: the accumulators hold V * 2^(141 - ev_acc) times P * 2^14
     if (KSPL > 1) {
         // key split: un-normalised rows (relative to this range's maximum), the maximum, the sum and the in-window raw scores of this key
         // range; launch_attn_combine() merges the ranges, adds the relative-value term and normalises
@@ -400,7 +574,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (d < dk) pb[(long long)d * T + qi] = o[t][r];
+                    if (d < dk) pb[(long long)d * T + qi] = F16 ? o[t][r] * (1.f / 16384.f) * ounscale : o[t][r];
                 }
             if (half == 0) {
                 pb[(long long)dk * T + qi] = m_run;
@@ -420,7 +594,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= inv;
+        for (int r = 0; r < 16; ++r) o[t][r] = F16 ? o[t][r] * (1.f / 16384.f) * ounscale * inv : o[t][r] * inv;
     // sum_r p[i, i + r - ws] * rel_v[r]: the window index is the (rolled) outer loop so that every access to the output accumulators
     // has a compile-time index (a runtime-indexed accumulator array lives in scratch memory)
 #pragma unroll 1
@@ -432,6 +606,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
     }
+    BSTAMP(5);
     float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
@@ -441,7 +616,9 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             if (d < dk && qi < T) ob[(long long)d * T + qi] = o[t][r];
         }
     }
+    BSTAMP(6);
 }
+#undef BSTAMP
 
 // The LDS images of the K / V tiles of one (batch, head), written once per launch (AttnParams::kvimg): exactly the bytes store_k / store_v
 // of relattn_bf16_kernel<DT, AKT, 1> put into LDS -- same cells, same key order, same zero fill beyond T and dk, RNE to bf16 -- followed
@@ -571,13 +748,13 @@ int launch_attn_combine(const AttnParams &p, hipStream_t s) {
 
 bool attn_bf16_supported(const AttnParams &p, int terms) {
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    return p.dk <= (terms == 6 ? 128 : 256) && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
+    return p.dk <= (terms == 1 ? 256 : 128) && p.T >= 4 && (p.T % 4) == 0 && al16(p.k) && al16(p.v) && (p.bs % 4) == 0 && ((long long)p.dk * p.T) % 4 == 0;
 }
 
 template <int DT, int AKT, int TERMS, bool PK = false>
 static int launch_bf16(const AttnParams &p, hipStream_t s) {
-    constexpr int DKR = DT * 32, AVP = AKT / 2 + 4, NPL = (TERMS == 6) ? 3 : 1, NBUF = (TERMS == 6) ? 1 : 2;
-    const size_t lds = 4 * ((size_t)NBUF * NPL * (DKR / 8) * AKT * 4 + (size_t)NBUF * NPL * DKR * AVP + 2 * AKT + 2 * 4 * 32 * ATT_QRS);
+    constexpr int DKR = DT * 32, AVP = AKT / 2 + 4, NPL = (TERMS == 6) ? 3 : (TERMS == 3 ? 2 : 1), NBUF = (TERMS == 1) ? 2 : 1;
+    const size_t lds = 4 * ((size_t)NBUF * NPL * (DKR / 8) * AKT * 4 + (size_t)NBUF * NPL * DKR * AVP + 2 * AKT + 2 * 4 * 32 * ATT_QRS + 12);
     auto kern = relattn_bf16_kernel<DT, AKT, TERMS, PK>;
     if constexpr (PK) {
         dim3 pgrid((unsigned)ceil_div(p.T, AKT), (unsigned)p.nh, (unsigned)p.B);
@@ -603,6 +780,11 @@ static int launch_bf16(const AttnParams &p, hipStream_t s) {
 
 int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s) {
     const int DT = (int)ceil_div(p.dk, 32);
+    if (terms == 3) {
+        if (DT <= 2) return launch_bf16<2, 32, 3>(p, s);
+        if (DT == 3) return launch_bf16<3, 32, 3>(p, s);
+        return launch_bf16<4, 32, 3>(p, s);
+    }
     if (terms == 6) {
         if (DT <= 2) return launch_bf16<2, 32, 6>(p, s);
         if (DT == 3) return launch_bf16<3, 32, 6>(p, s);

@@ -123,25 +123,46 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
         // to cover it with, so the K / V fragments are requested eight / six MFMAs ahead
         if (ATT_PIN) asm volatile("" : "+a"(qf[ks]));
     }
-    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] from the fp32 query (rolled loops: prologue code off the main loop's registers)
+    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] in fp32: the table goes into LDS once per workgroup, transposed and zero-padded
+    // ([d][16], over the ring, which no DMA has touched yet); every lane walks ALL the 8-channel groups of its half (a wave of a pair holds
+    // only its own half of the query as fragments) -- eight independent loads of q per step, one broadcast ds_read_b128 per four window
+    // positions.  (Round 6: the loop this replaces -- a load of q and nine of rel_k per channel, one channel in flight -- cost ~1 800 cycles
+    // per channel: a quarter of a launch of relattn_bf16_kernel at T = 1024, tools/attn_phase_stamps.py.)
+    float *RKs = smem;
     float qr[ATT_MAXREL];
 #pragma unroll
     for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
     if (nrel) {
+        for (int e = tid; e < DKR * ATT_MAXREL; e += 256 * WPQ) {
+            const int d = e / ATT_MAXREL, r = e % ATT_MAXREL;
+            RKs[e] = (d < dk && r < nrel) ? relk[r * dk + d] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (nrel) {
 #pragma unroll 1
-        for (int d8 = half; d8 < (dk + 7) / 8; d8 += 2) {
-#pragma unroll 1
-            for (int j = 0; j < 8; ++j) {
-                const int d = 8 * d8 + j;
-                if (d < dk && qi < T) {
-                    const float qs = qb[(long long)d * T + qic] * p.scale;
+        for (int ks = 0; ks < NKS; ++ks) {
+            float qv[8];
 #pragma unroll
-                    for (int r = 0; r < ATT_MAXREL; ++r)
-                        if (r < nrel) qr[r] += qs * relk[r * dk + d];
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * ks + 8 * half + j;
+                const float v = qb[(long long)min(d, dk - 1) * T + qic];
+                qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 *row = reinterpret_cast<const float4 *>(RKs + (16 * ks + 8 * half + j) * ATT_MAXREL);
+#pragma unroll
+                for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {
+                    if (4 * c4 < nrel) {
+                        const float4 w = row[c4];
+                        qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
+                    }
                 }
             }
         }
     }
+    __syncthreads();                                     // (the table is read: the ring may be written)
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
     for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;

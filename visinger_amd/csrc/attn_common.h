@@ -33,7 +33,8 @@ struct AttnParams {
 size_t attn_kv_work_bytes(long long B, int nh, int dk, long long T);
 
 // attention_bf16.hip: both GEMMs on the bf16 matrix instruction, fp32 softmax / accumulation; terms = 1: bf16 operands (dk <= 256),
-// terms = 6: the exact three-plane split with six cross products (fp32 class, dk <= 128).  Needs T % 4 == 0 and 16-byte aligned
+// terms = 6: the exact three-plane split with six cross products (fp32 class, dk <= 128); terms = 3: two f16 planes under power-of-two
+// scales, three cross products on the f16 matrix instruction (fp32 class, dk <= 128).  Needs T % 4 == 0 and 16-byte aligned
 // q / k / v rows: when attn_bf16_supported() says no, the caller runs the exact-fp32 MFMA kernel.
 bool attn_bf16_supported(const AttnParams &p, int terms);
 int launch_attn_bf16(const AttnParams &p, int terms, hipStream_t s);

@@ -50,7 +50,7 @@ static OptEntry g_opts[OPT_COUNT] = {
     {"VS_NO_SMALL_GRID", 0, 0}, {"VS_SMALL_GRID_T6", 512, 512}, {"VS_CONV_CFG", -1, -1}, {"VS_SPLIT_DBG", 0, 0}, {"VS_TRACE", 0, 0},
     {"VS_NO_BF16_ATTN", 0, 0}, {"VS_NO_SPLIT_ATTN", 0, 0}, {"VS_NO_WGRAD_SPLIT", 0, 0}, {"VS_RB_TILE256", 0, 0},
     {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_NO_KTAP", 0, 0}, {"VS_NO_ATTN_DMA", 0, 0},
-    {"VS_ATTN_DMA_ONE_WAVE", 0, 0},
+    {"VS_ATTN_DMA_ONE_WAVE", 0, 0}, {"VS_ATTN_SPLIT6", 0, 0},
 };
 static const bool g_opts_loaded = [] {
     for (OptEntry &e : g_opts) {

@@ -384,7 +384,15 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     p.part = nullptr; p.ksplit = 0; p.kvimg = nullptr; p.stamps = g_stamp_buf;
     hipStream_t s = as_stream(stream);
     VS_REQUIRE(math == VS_MATH_F32 || math == VS_MATH_BF16 || math == VS_MATH_SPLIT6 || math == VS_MATH_SPLIT3, "vs_relattn_fwd: unknown arithmetic %d", math);
-    if (math == VS_MATH_SPLIT3) math = VS_MATH_SPLIT6;      // (the attention core has no split-f16 instance: the fp32-class split-bf16 x6 kernel serves both)
+    // VS_MATH_SPLIT3 (the default arithmetic of the path): q / sqrt(dk), k, v and the probabilities as two f16 planes under power-of-two scales
+    // (per query, per K tile, running per V tile), three cross products per product on the f16 matrix instruction -- fp32-class like
+    // VS_MATH_SPLIT6 at half the executed matrix work (round 6; heads of up to 128 channels, else the split-bf16 x6 / fp32 kernels below)
+    if (math == VS_MATH_SPLIT3) {
+        if (work && ksplit > 1 && T / 64 >= ksplit) { p.part = work; p.ksplit = ksplit; }
+        if (attn_bf16_supported(p, 3) && !opt(OPT_ATTN_SPLIT6) && !opt(OPT_NO_SPLIT_ATTN)) return launch_attn_bf16(p, 3, s);
+        p.part = nullptr; p.ksplit = 0;
+        math = VS_MATH_SPLIT6;
+    }
     // VS_MATH_BF16: both GEMMs on the bf16 matrix instruction (attention_bf16.hip); any other arithmetic, and shapes that kernel does
     // not take (T % 4 != 0, unaligned rows), run the exact-fp32 MFMA kernel below
     // VS_MATH_SPLIT6 (the default arithmetic of the path): the same kernel with every operand split exactly into three bf16 planes and

@@ -40,6 +40,7 @@ enum Opt {
     OPT_NO_KTAP,          // VS_NO_KTAP: the wide stride-1 split-f16 convs on the tile kernel conv_split_kernel<1, 8, 4, 1, 3> instead of conv_ktap_kernel (taps unrolled, staging in the MFMA shadows; bit-identical: A/B switch)
     OPT_NO_ATTN_DMA,      // VS_NO_ATTN_DMA: wide-head plain-bf16 attention on relattn_bf16_kernel<.., true> (register-staged tiles) instead of relattn_dma_kernel
     OPT_ATTN_DMA_ONE_WAVE,  // VS_ATTN_DMA_ONE_WAVE: relattn_dma_kernel with one wave per query group (the round-4 form) instead of the wave pair that splits the head's channels
+    OPT_ATTN_SPLIT6,      // VS_ATTN_SPLIT6: VS_MATH_SPLIT3 attention on the split-bf16 x6 instance (the form of rounds 3-5) instead of relattn_bf16_kernel<.., 3> (split-f16 x3)
     OPT_COUNT
 };
 long long opt(Opt o);
