@@ -7,8 +7,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visinger_amd import _lib as L
 from visinger_amd.ops import rel_attention
-B, nh, dk, T = 32, 2, 96, 1024
-math = L.MATH_SPLIT6 if "--split6" in sys.argv else L.MATH_SPLIT3
+WIDE = "--wide" in sys.argv      # relattn_dma_kernel (BASELINE configs[4]'s heads, plain bf16): its phase stamps are compiled in (slots 1000 ..)
+B, nh, dk, T = (8, 2, 256, 4096) if WIDE else (32, 2, 96, 1024)
+math = L.MATH_BF16 if WIDE else (L.MATH_SPLIT6 if "--split6" in sys.argv else L.MATH_SPLIT3)
 qkv = torch.randn(B, 3 * nh * dk, T, device="cuda")
 rel_k = torch.randn(1, 9, dk, device="cuda") * dk ** -0.5
 rel_v = torch.randn(1, 9, dk, device="cuda") * dk ** -0.5
@@ -26,10 +27,22 @@ torch.cuda.synchronize()
 lib.vs_debug_set_stamp_buffer(None)
 print(lib.vs_last_kernel_name().decode(), "event interval %.1f us" % (e0.elapsed_time(e1) * 1e3))
 a = buf.cpu().numpy()
-names = ["start -> query fragments", "rel-key logits", "staging setup", "first tile staged", "tile loop", "finish (normalise, rel-value)", "output stores"]
+if WIDE:
+    w = a[1000:1007]
+    tot = w[6] - w[0]
+    for i, n in enumerate(["query fragments", "rel-key table + logits", "logits to LDS, first DMA", "tile loop", "finish (normalise, rel-value)", "output stores"]):
+        print("  %-32s %8d cycles  %5.1f %%" % (n, w[i + 1] - w[i], 100.0 * (w[i + 1] - w[i]) / tot))
+    print("  total %d cycles" % tot)
+    sys.exit(0)
+names = ["rel-key table, query fragments + logits", "logits to LDS", "first tile staged", "tile loop", "finish (normalise, rel-value)", "output stores"]
 tot = a[6] - a[0]
-for i, n in enumerate(names[:-1] if False else names[:6]):
+for i, n in enumerate(names):
     print("  %-32s %8d ticks  %5.1f %%" % (n, a[i + 1] - a[i], 100.0 * (a[i + 1] - a[i]) / tot))
 print("  total %d ticks (s_memtime: 100 MHz ticks -> %.1f us)" % (tot, tot / 100.0))
 per = np.diff(a[16:16 + T // 32])
 print("  tile period: median %d, first five %s" % (np.median(per), per[:5].tolist()))
+t = a[128:128 + 8 * (T // 32)].reshape(-1, 8)[2:-1]
+seg = np.diff(t, axis=1)
+print("  inside a tile (median cycles): S^T MFMAs %d | scores, softmax, P planes %d | P V MFMAs %d | tile exponents %d | barrier %d | convert + store next tile %d | barrier %d"
+      % tuple(np.median(seg, 0)))
+print("  next-tile loads issued at the top of the loop: %d" % np.median(t[:, 0] - a[16 + 2:16 + 2 + len(t)]))

@@ -5,6 +5,9 @@ tools/attn_scan.py`; `python3 tools/attn_scan.py --read DIR` then prints the med
 import os, sys, glob, csv, statistics
 N = 8
 SHAPES = [(128, 256), (64, 512), (32, 1024), (16, 2048), (8, 4096)]
+WIDE = "--wide" in sys.argv      # BASELINE configs[4]'s heads (2 x 256 channels) in the plain-bf16 arithmetic: relattn_dma_kernel<8, 2>
+if WIDE:
+    SHAPES = [(32, 1024), (16, 2048), (8, 4096)]
 if "--read" in sys.argv:
     d = sys.argv[sys.argv.index("--read") + 1]
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
@@ -12,7 +15,7 @@ if "--read" in sys.argv:
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     dur = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
     i = 0
-    for math in ("split-bf16 x6", "split-f16 x3"):
+    for math in (("plain bf16",) if WIDE else ("split-bf16 x6", "split-f16 x3")):
         pts = []
         for B, T in SHAPES:
             chunk = dur[i:i + N + 2][2:]
@@ -27,8 +30,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visinger_amd import _lib as L
 from visinger_amd.ops import rel_attention
-nh, C = 2, 192
-for math in (L.MATH_SPLIT6, L.MATH_SPLIT3):
+nh, C = (2, 512) if WIDE else (2, 192)
+for math in ((L.MATH_BF16,) if WIDE else (L.MATH_SPLIT6, L.MATH_SPLIT3)):
     for B, T in SHAPES:
         qkv = torch.randn(B, 3 * C, T, device="cuda")
         rk = torch.randn(1, 9, C // nh, device="cuda") * 0.1

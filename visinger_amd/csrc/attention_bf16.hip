@@ -142,9 +142,11 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 #pragma unroll
     for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
     if (nrel) {
+#pragma unroll      // (consecutive lanes read consecutive channels of one window position: coalesced, all loads of a thread in flight)
         for (int e = tid; e < DKR * ATT_MAXREL; e += 256) {
-            const int d = e / ATT_MAXREL, r = e % ATT_MAXREL;
-            RKs[e] = (d < dk && r < nrel) ? relk[r * dk + d] : 0.f;
+            const int r = e / DKR, d = e % DKR;
+            const float w = relk[min(r, nrel - 1) * dk + min(d, dk - 1)];      // (unconditional load on a clamped index: the loads of a thread overlap)
+            RKs[d * ATT_MAXREL + r] = (d < dk && r < nrel) ? w : 0.f;
         }
     }
     __syncthreads();
@@ -154,11 +156,9 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         for (int j = 0; j < 8; ++j) {
             const float4 *row = reinterpret_cast<const float4 *>(RKs + (16 * ks + 8 * half + j) * ATT_MAXREL);
 #pragma unroll
-            for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {
-                if (4 * c4 < nrel) {
-                    const float4 w = row[c4];
-                    qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
-                }
+            for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {          // (all 16 columns of the zero-padded table: straight-line code)
+                const float4 w = row[c4];
+                qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
             }
         }
     };
@@ -389,7 +389,11 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
         const int buf = (NBUF == 2) ? ((jt - jt_lo) & 1) : 0;
 #ifdef VS_ATTN_STAMPS
         if (jt - jt_lo < 100) BSTAMP(16 + jt - jt_lo);
+#define TSTAMP(k) do { if (jt - jt_lo < 100) BSTAMP(128 + 8 * (jt - jt_lo) + (k)); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
 #endif
+        TSTAMP(0);
         const unsigned *Kb = Ks + buf * KBUF, *Vb = Vs + buf * VBUF;
         const float *Mb = Ms + buf * AKT;
         ek_cur = ek_next;
@@ -425,6 +429,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
                 load_v(jt + 1);
             }
         }
+        TSTAMP(1);
         const bool near_diag = nrel && (j0 + AKT - 1 >= i0 - p.ws) && (j0 <= i0 + 31 + p.ws);
         float tmax = -INFINITY;
         const float sfix = F16 ? f16_inv_scale(ek_cur) * q_inv : 1.f;      // (exact: powers of two)
@@ -531,6 +536,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
                 for (int r = 0; r < 16; ++r) o[t][r] *= oresc;
         }
 
+        TSTAMP(2);
         // ---- O^T += V P^T: k-step s4 sums over the keys 16 s4 + 8 (j >> 2) + 4 half + (j & 3), the order of the V rows ----
 #pragma unroll
         for (int s4 = 0; s4 < 2 * NKT; ++s4) {
@@ -547,16 +553,21 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
             if (jt + 1 < ntiles) store_v(jt + 1, buf ^ 1, 1.f);
             __syncthreads();
         } else {
+            TSTAMP(3);
             if constexpr (F16) {
                 if (jt + 1 < ntiles) publish_exps();
             }
+            TSTAMP(4);
             __syncthreads();                                 // every wave is done with the (single) K / V buffer
+            TSTAMP(5);
             if (jt + 1 < ntiles) {
                 if constexpr (F16) collect_exps();
                 store_k(jt + 1, 0, f16_scale(ek_next));
                 store_v(jt + 1, 0, f16_scale(ev_run));
             }
+            TSTAMP(6);
             __syncthreads();
+            TSTAMP(7);
         }
     }
 
@@ -587,7 +598,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 
     // ---- finish: normalise, add the relative-value term (fp32), store ----
     // (the loop's last barrier has retired every read of the K / V buffers: 2 * KBUF dwords >= 16 rows x 256 channels)
-    for (int e = tid; e < nrel * dk; e += 256) RVs[e] = relv[e];
+    for (int e = tid; e < nrel * DKR; e += 256) RVs[e] = (e % DKR < dk) ? relv[(e / DKR) * dk + e % DKR] : 0.f;      // rows of DKR: float4 reads below
     __syncthreads();
     const float l_tot = l_half + __shfl_xor(l_half, 32);
     const float inv = 1.0f / l_tot;
@@ -600,11 +611,14 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
 #pragma unroll 1
     for (int rr = 0; rr < nrel; ++rr) {
         const float w = expf(Sww[l31 * ATT_QRS + rr] - m_run) * inv;
-        const float *rv = RVs + rr * dk;
+        const float *rv = RVs + rr * DKR;
 #pragma unroll
         for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(rv + t * 32 + 8 * r4 + 4 * half);
+                o[t][4 * r4 + 0] += w * v4.x; o[t][4 * r4 + 1] += w * v4.y; o[t][4 * r4 + 2] += w * v4.z; o[t][4 * r4 + 3] += w * v4.w;
+            }
     }
     BSTAMP(5);
     float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
@@ -619,6 +633,7 @@ __global__ void __launch_bounds__(256, (DT <= 4) ? 2 : 1) relattn_bf16_kernel(co
     BSTAMP(6);
 }
 #undef BSTAMP
+#undef TSTAMP
 
 // The LDS images of the K / V tiles of one (batch, head), written once per launch (AttnParams::kvimg): exactly the bytes store_k / store_v
 // of relattn_bf16_kernel<DT, AKT, 1> put into LDS -- same cells, same key order, same zero fill beyond T and dk, RNE to bf16 -- followed

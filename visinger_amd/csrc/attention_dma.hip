@@ -96,6 +96,15 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
     const float *relk = nrel ? p.rel_k + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
     const float *relv = nrel ? p.rel_v + (long long)(p.nh_rel == 1 ? 0 : h) * nrel * dk : nullptr;
 
+    // (debug, tools/attn_phase_stamps.py --wide: shader-clock stamps of the phases of workgroup (0, 0, 0), wave 0; p.stamps is null in production)
+#define PSTAMP(k)                                                                                                    \
+    do {                                                                                                             \
+        if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave_id == 0) {                     \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+            if (lane == 0) p.stamps[1000 + (k)] = t_;                                                                \
+        }                                                                                                            \
+    } while (0)
+    PSTAMP(0);
     // ---- query fragments: B operand of S^T = K^T Q, element j of k-step ks = Q[d = 16 ks + 8 half + j][query l31], RNE to bf16 ----
     const int qi = i0 + l31;
     const int qic = min(qi, T - 1);
@@ -123,6 +132,7 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
         // to cover it with, so the K / V fragments are requested eight / six MFMAs ahead
         if (ATT_PIN) asm volatile("" : "+a"(qf[ks]));
     }
+    PSTAMP(1);
     // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] in fp32: the table goes into LDS once per workgroup, transposed and zero-padded
     // ([d][16], over the ring, which no DMA has touched yet); every lane walks ALL the 8-channel groups of its half (a wave of a pair holds
     // only its own half of the query as fragments) -- eight independent loads of q per step, one broadcast ds_read_b128 per four window
@@ -133,14 +143,16 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
 #pragma unroll
     for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
     if (nrel) {
+#pragma unroll      // (consecutive lanes read consecutive channels of one window position: coalesced, all loads of a thread in flight)
         for (int e = tid; e < DKR * ATT_MAXREL; e += 256 * WPQ) {
-            const int d = e / ATT_MAXREL, r = e % ATT_MAXREL;
-            RKs[e] = (d < dk && r < nrel) ? relk[r * dk + d] : 0.f;
+            const int r = e / DKR, d = e % DKR;
+            const float w = relk[min(r, nrel - 1) * dk + min(d, dk - 1)];      // (unconditional load on a clamped index: the loads of a thread overlap)
+            RKs[d * ATT_MAXREL + r] = (d < dk && r < nrel) ? w : 0.f;
         }
     }
     __syncthreads();
     if (nrel) {
-#pragma unroll 1
+#pragma unroll 2      // (16 loads of q in flight per lane: a rolled loop waited ~3 400 cycles per k-step at launch start, when every workgroup of the chip is in its prologue)
         for (int ks = 0; ks < NKS; ++ks) {
             float qv[8];
 #pragma unroll
@@ -153,16 +165,15 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
             for (int j = 0; j < 8; ++j) {
                 const float4 *row = reinterpret_cast<const float4 *>(RKs + (16 * ks + 8 * half + j) * ATT_MAXREL);
 #pragma unroll
-                for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {
-                    if (4 * c4 < nrel) {
-                        const float4 w = row[c4];
-                        qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
-                    }
+                for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {      // (all 16 columns of the zero-padded table: straight-line code, every load of q hoisted)
+                    const float4 w = row[c4];
+                    qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
                 }
             }
         }
     }
     __syncthreads();                                     // (the table is read: the ring may be written)
+    PSTAMP(2);
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
     for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
@@ -222,6 +233,7 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
             if (lane == 0) p.stamps[jt * 8 + (k)] = t_;                                                              \
         }                                                                                                            \
     } while (0)
+    PSTAMP(3);
     for (int jt = 0; jt < ntiles; ++jt) {
         const int j0 = jt * AKT;
         ASTAMP(0);
@@ -360,10 +372,11 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
         ASTAMP(5);
     }
 #undef ASTAMP
+    PSTAMP(4);
 
     // ---- finish: normalise, add the relative-value term (fp32), store ----
     __syncthreads();                                     // every read of the ring has retired: its first bytes take the relative value table
-    for (int e = tid; e < nrel * dk; e += 256 * WPQ) RVs[e] = relv[e];
+    for (int e = tid; e < nrel * DKR; e += 256 * WPQ) RVs[e] = (e % DKR < dk) ? relv[(e / DKR) * dk + e % DKR] : 0.f;      // rows of DKR: float4 reads below
     __syncthreads();
     const float l_tot = l_half + __shfl_xor(l_half, 32);
     const float inv = 1.0f / l_tot;
@@ -377,12 +390,16 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
 #pragma unroll 1
     for (int rr = 0; rr < nrel; ++rr) {
         const float w = expf(Sww[l31 * ATT_QRS + rr] - m_run) * inv;
-        const float *rv = RVs + rr * dk;
+        const float *rv = RVs + rr * DKR;
 #pragma unroll
         for (int t = 0; t < DH; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] += w * rv[min((t_base + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, dk - 1)];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v4 = *reinterpret_cast<const float4 *>(rv + (t_base + t) * 32 + 8 * r4 + 4 * half);
+                o[t][4 * r4 + 0] += w * v4.x; o[t][4 * r4 + 1] += w * v4.y; o[t][4 * r4 + 2] += w * v4.z; o[t][4 * r4 + 3] += w * v4.w;
+            }
     }
+    PSTAMP(5);
     float *ob = p.out + (long long)b * p.out_bs + (long long)h * dk * T;
 #pragma unroll
     for (int t = 0; t < DH; ++t) {
@@ -392,6 +409,8 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
             if (d < dk && qi < T) ob[(long long)d * T + qi] = o[t][r];
         }
     }
+    PSTAMP(6);
+#undef PSTAMP
 }
 
 template <int DT, int WPQ>
