@@ -238,13 +238,13 @@ def test_round5_profiles_parse_and_agree(tag):
 
 
 def test_round6_profiles_parse_agree_and_name_their_build():
-    """profiles/r06_a_* (`tools/profile_round.sh r06_a`, `r06_a_config{2,3,5} --config N`; the end state of round 6).  `value` is quoted on the two-stream batch rotation
+    """profiles/r06_b_* (`tools/profile_round.sh r06_b`, `r06_b_config{2,3,5} --config N`; the end state of round 6).  `value` is quoted on the two-stream batch rotation
     (visinger_amd.synth.StreamRotation) and the roofline comes from the single-stream pass of the same process; the rocprofv3 summaries are of `--streams 1` runs, so
     rocprofv3's average launch of the dominant instance equals the HIP-event average of the profiled line.  EVERY summary names the sources its library was built from
     (VERDICT r5 #10) and that hash is the tree's: a kernel edit after the last profile fails here until the profile is redone.  DESIGN.md's round-6 numbers are these files'."""
     import bench
     from visinger_amd.csrc import build
-    tag = "r06_a"
+    tag = "r06_b"
     tree = build.source_hash()
     out = open(os.path.join(ROOT, "profiles", f"{tag}_bench_stdout.txt")).read()
     lines = [x for x in out.splitlines() if x.strip()]
@@ -270,6 +270,8 @@ def test_round6_profiles_parse_agree_and_name_their_build():
     avg_ms = float(rows["void vs::%s(vs::ConvParams)" % dom]["AverageNs"]) * 1e-6
     assert prof["roofline"]["kernel"] == dom and abs(avg_ms - prof["roofline"]["avg_launch_ms"]) <= 0.02 * avg_ms
     assert any("resblock_f16_kernel<4, 2, 4, 28>" in n for n in rows)                                  # 64 channels, wide halo: 512-column tiles
+    att = rows["void vs::relattn_bf16_kernel<3, 32, 3, false>(vs::AttnParams)"]                       # the attention core on split-f16 x3 (VERDICT r5 #3b: <= 1.6 ms a step)
+    assert int(att["Calls"]) == 16 * 7 and float(att["TotalDurationNs"]) / 7 < 1.75e6 and not any("relattn_bf16_kernel<3, 32, 6" in n for n in rows)
     keys = {tag: bench.HEADLINE_WORKLOAD, tag + "_config2": "c2_B8_T512_h192_hop256_f32", tag + "_config3": "c3_B16_T512_h192_hop256_f32", tag + "_config5": "B8_T4096_h512_hop256_bf16"}
     for tg, key in keys.items():
         for kind in ("traffic", "mfma_busy"):
@@ -281,6 +283,9 @@ def test_round6_profiles_parse_agree_and_name_their_build():
     assert bench.pmc_traffic(dom)["source"].startswith("recorded: profiles/r06_")                      # the newest summary is the one a bench line cites
     t5 = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_config5_pmc_traffic.json")))["kernels"]
     assert "relattn_dma_kernel<8,2>" in t5
+    with open(os.path.join(ROOT, "profiles", f"{tag}_config5_bench_kernel_stats.csv"), newline="") as f:
+        dma = [row for row in csv.DictReader(f) if "relattn_dma_kernel<8, 2>" in row["Name"]][0]
+    assert float(dma["AverageNs"]) < 0.66e6                                                            # (0.78 ms before its rel-key prologue was rewritten)
     m = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_mfma_busy.json")))["kernels"][dom.replace(" ", "")]
     assert m["mfma_pipe_util"] >= 0.70 and m["gfx_clock_ghz"] < 1.7
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
