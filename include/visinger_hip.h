@@ -209,15 +209,18 @@ VS_API int64_t vs_conv_out_len(const vs_conv_t *h, int64_t T);
  *     Streaming softmax: no [T, T] tensor is materialised (the reference's `self.attn` is not produced).
  *     math (enum vs_conv_math, declared below): VS_MATH_BF16 rounds q / sqrt(dk), k, v and the probabilities to bf16 and runs both
  *     GEMMs on the bf16 matrix instruction with fp32 accumulation (softmax statistics and relative terms stay fp32) -- BASELINE.json's
- *     long-form bf16 configuration; VS_MATH_F32 / VS_MATH_SPLIT6: the exact-fp32 matrix instruction.                  */
+ *     long-form bf16 configuration; VS_MATH_SPLIT3 (the default arithmetic of the path) / VS_MATH_SPLIT6: the same operands as two f16
+ *     planes under power-of-two scales (per query, per K tile, running per V tile) with three cross products / as three bf16 planes with
+ *     six -- fp32-class results on the f16 / bf16 matrix instruction, heads of up to 128 channels; VS_MATH_F32, and every shape those
+ *     kernels do not take (T % 4 != 0, unaligned rows, wider heads in the split arithmetics): the exact-fp32 matrix instruction.        */
 VS_API int vs_relattn_fwd(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                           const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B,
                           int n_heads, int k_channels, int64_t T, int window_size, int n_heads_rel, int math, void *stream);
 
 /* The same with the KEYS of every (batch, head) cut into `ksplit` ranges (1..16) that run as separate workgroups and are merged by a
  * second kernel: for launches too small to fill the chip (a single utterance is 16 workgroups of 32 serial key tiles).  `work`:
- * B * n_heads * ksplit * (k_channels + 2 + 2 * window + 1) * T floats of scratch.  Only the bf16-pipe kernels (VS_MATH_SPLIT6 /
- * VS_MATH_BF16 on shapes they take) split; any other case runs exactly as vs_relattn_fwd.                                          */
+ * B * n_heads * ksplit * (k_channels + 2 + 2 * window + 1) * T floats of scratch.  Only the f16- / bf16-pipe kernels (VS_MATH_SPLIT3 /
+ * VS_MATH_SPLIT6 / VS_MATH_BF16 on shapes they take) split; any other case runs exactly as vs_relattn_fwd.                           */
 VS_API int vs_relattn_fwd_ksplit(const float *q, const float *k, const float *v, int64_t qkv_batch_stride, const float *rel_k,
                                  const float *rel_v, const float *mask, float *out, int64_t out_batch_stride, int64_t B, int n_heads,
                                  int k_channels, int64_t T, int window_size, int n_heads_rel, int math, float *work, int ksplit,

@@ -48,6 +48,45 @@ def test_split6_error_not_above_fp32_mfma(oracle, vs_option, C, k, d, T):
     assert 1e-4 < errs[L.MATH_BF16] <= 6e-3, errs          # bf16 operands: ~2^-9 per product, fp32 accumulate
 
 
+@pytest.mark.parametrize("Cin,Cout,B,with_bias", [(256, 1536, 32, True), (256, 192, 32, True), (256, 512, 3, False), (200, 70, 40, True), (16, 5, 1, True),
+                                                   (512, 64, 33, False)])
+def test_single_frame_1x1_conv(oracle, vs_option, Cin, Cout, B, with_bias):
+    """conv_t1_kernel (round 6): 1 x 1 convs over ONE frame per item -- the conditioning vectors (WN.cond_layer 256 -> 2 * hidden * n_layers on the speaker
+    embedding, the g-convs of the flow and the generator) -- leave the tile kernels (one valid column in 128, 63 us for 256 -> 1536 at B = 32) for a workgroup
+    per 32-row tile of W over up to 32 items: against the fp64 oracle in the fp32-class arithmetics, against the oracle on bf16-rounded operands in
+    VS_MATH_BF16, and against the tile kernel it replaces (VS_NO_T1_CONV=1); a per-item bias and an output scale ride along; T = 2 stays on the tile kernels."""
+    from visinger_amd.ops import ConvOp
+    r = np.random.default_rng(Cin + 3 * Cout + B)
+    x = r.standard_normal((B, Cin, 1)).astype(np.float32)
+    w = (r.standard_normal((Cout, Cin, 1)) / np.sqrt(Cin)).astype(np.float32)
+    bias = r.standard_normal(Cout).astype(np.float32) if with_bias else None
+    ref = oracle.conv1d(x.astype(np.float64), w, bias)
+    for math in (L.MATH_SPLIT3, L.MATH_SPLIT6, L.MATH_BF16):
+        op = ConvOp(L.CONV1D, Cin, Cout, 1, 1, 0).set_math(math)
+        op.set_weights(dev(w), None, None if bias is None else dev(bias))
+        y = op.forward(dev(x))
+        assert op.kernel_instance() == "conv_t1_kernel" and y.shape == (B, Cout, 1)
+        vs_option("VS_NO_T1_CONV", 1)
+        y_tile = op.forward(dev(x))
+        assert op.kernel_instance() != "conv_t1_kernel"
+        vs_option("VS_NO_T1_CONV", 0)
+        if math == L.MATH_BF16:
+            with oracle.operand_rounding("bf16"):
+                ref16 = oracle.conv1d(x.astype(np.float64), w, bias)
+            assert rel_rms(y, ref16) <= 2e-6 and rel_rms(y_tile, ref16) <= 2e-6
+        else:
+            assert rel_rms(y, ref) <= 4e-7, (math, rel_rms(y, ref))
+            assert float((y - y_tile).abs().max()) <= 2e-5
+    op = ConvOp(L.CONV1D, Cin, Cout, 1, 1, 0)
+    op.set_weights(dev(w), None, None if bias is None else dev(bias))
+    bb = r.standard_normal((B, Cout)).astype(np.float32)
+    y3 = op.forward(dev(x), bias_b=dev(bb), scale=0.5)
+    assert op.kernel_instance() == "conv_t1_kernel" and rel_rms(y3, 0.5 * (ref + bb[:, :, None].astype(np.float64))) <= 3e-7
+    x2 = r.standard_normal((B, Cin, 2)).astype(np.float32)
+    y2 = op.forward(dev(x2))
+    assert op.kernel_instance() != "conv_t1_kernel" and rel_rms(y2, oracle.conv1d(x2.astype(np.float64), w, bias)) <= 3e-6
+
+
 def test_split_kernel_instances_and_repack(oracle):
     """vs_conv_set_math on a handle whose weights are already packed re-packs the bf16 planes; the three arithmetics of one
     handle agree with the oracle in turn"""

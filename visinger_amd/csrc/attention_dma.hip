@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
     for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
     if (nrel) {
 #pragma unroll      // (consecutive lanes read consecutive channels of one window position: coalesced, all loads of a thread in flight)
-        for (int e = tid; e < DKR * ATT_MAXREL; e += 256 * WPQ) {
+        for (int i = 0; i < DKR * ATT_MAXREL / (256 * WPQ); ++i) {
+            const int e = tid + i * (256 * WPQ);
             const int r = e / DKR, d = e % DKR;
             const float w = relk[min(r, nrel - 1) * dk + min(d, dk - 1)];      // (unconditional load on a clamped index: the loads of a thread overlap)
             RKs[d * ATT_MAXREL + r] = (d < dk && r < nrel) ? w : 0.f;

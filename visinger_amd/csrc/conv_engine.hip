@@ -50,7 +50,7 @@ static OptEntry g_opts[OPT_COUNT] = {
     {"VS_NO_SMALL_GRID", 0, 0}, {"VS_SMALL_GRID_T6", 512, 512}, {"VS_CONV_CFG", -1, -1}, {"VS_SPLIT_DBG", 0, 0}, {"VS_TRACE", 0, 0},
     {"VS_NO_BF16_ATTN", 0, 0}, {"VS_NO_SPLIT_ATTN", 0, 0}, {"VS_NO_WGRAD_SPLIT", 0, 0}, {"VS_RB_TILE256", 0, 0},
     {"VS_NO_ATTN_KVPACK", 0, 0}, {"VS_NO_TR_EPI", 0, 0}, {"VS_NO_KTAP", 0, 0}, {"VS_NO_ATTN_DMA", 0, 0},
-    {"VS_ATTN_DMA_ONE_WAVE", 0, 0}, {"VS_ATTN_SPLIT6", 0, 0},
+    {"VS_ATTN_DMA_ONE_WAVE", 0, 0}, {"VS_ATTN_SPLIT6", 0, 0}, {"VS_NO_T1_CONV", 0, 0},
 };
 static const bool g_opts_loaded = [] {
     for (OptEntry &e : g_opts) {
@@ -1031,6 +1031,77 @@ struct SmallParams {
     int x_bf16;          // x holds bf16 elements (bf16-resident activations: the generator's last stage in BASELINE config 5); x_bs in elements
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1 x 1 convs over ONE frame per item (the conditioning vectors: WN.cond_layer 256 -> 2 * hidden * n_layers on the speaker embedding,
+// modules/visinger/wavenet.py cond_layer; the g-convs of the flow and the generator, decoder.py:38-39): y[b][m] = bias[m] + sum_c W[m][c] x[b][c].
+// On the tile kernels the items are grid.z and the time axis the tile's columns -- one valid column in 128 or 256, a full K loop per
+// item and row tile: 63 us for 256 -> 1536 at B = 32 (tools/conv_census.py, round 6).  Here a workgroup takes one 32-row tile of W for up
+// to 32 items: x staged once in LDS (zero-padded to the chunk grid), the weights read straight from the fp32 fragment buffer Wp (lane =
+// row: consecutive rows are consecutive float4s), fp32 FMAs; VS_MATH_BF16 rounds both operands to bf16 first, as its matrix kernels do.
+struct T1Params {
+    const float *x;
+    long long x_bs;
+    const float *wp;     // Wp[m_tile][chunk][quad(2)][64][4] (k = 1: one tap)
+    const float *biasp;  // packed bias [MT_alloc * 32]
+    const float *bias_b;
+    long long bias_b_bs;
+    float *y;
+    long long y_bs;
+    int B, Cin, c_out, nchunks, bf16;
+    float scale;
+};
+__global__ void __launch_bounds__(256) conv_t1_kernel(const T1Params p) {
+    extern __shared__ __attribute__((aligned(16))) float t1_xs[];       // [items of this workgroup][nchunks * 16]
+    const int tid = threadIdx.x, row = tid & 31, bg = tid >> 5;
+    const int mt = blockIdx.x, b0 = blockIdx.y * 32;
+    const int nb = min(32, p.B - b0), CP = p.nchunks * 16;
+    for (int e = tid; e < nb * CP; e += 256) {
+        const int bi = e / CP, c = e - bi * CP;
+        float v = (c < p.Cin) ? p.x[(long long)(b0 + bi) * p.x_bs + c] : 0.f;
+        if (p.bf16) v = u2f(rne_bf16(v) & 0xffff0000u);
+        t1_xs[e] = v;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 *w = reinterpret_cast<const float4 *>(p.wp) + (long long)mt * p.nchunks * 128;
+    for (int ch = 0; ch < p.nchunks; ++ch, w += 128) {
+        float4 wq[4] = {w[row], w[row + 32], w[64 + row], w[64 + row + 32]};      // (quad, parity): channels 8 quad + 2 i + parity of the chunk
+        if (p.bf16) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                wq[t].x = u2f(rne_bf16(wq[t].x) & 0xffff0000u); wq[t].y = u2f(rne_bf16(wq[t].y) & 0xffff0000u);
+                wq[t].z = u2f(rne_bf16(wq[t].z) & 0xffff0000u); wq[t].w = u2f(rne_bf16(wq[t].w) & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bi = bg + 8 * i;
+            if (bi < nb) {
+                const float4 *xv = reinterpret_cast<const float4 *>(t1_xs + bi * CP + ch * 16);
+                const float4 x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3];
+                float a = 0.f;                                     // (a chunk's sixteen products first, then onto the running sum: shorter rounding chains)
+                a += wq[0].x * x0.x; a += wq[1].x * x0.y; a += wq[0].y * x0.z; a += wq[1].y * x0.w;
+                a += wq[0].z * x1.x; a += wq[1].z * x1.y; a += wq[0].w * x1.z; a += wq[1].w * x1.w;
+                a += wq[2].x * x2.x; a += wq[3].x * x2.y; a += wq[2].y * x2.z; a += wq[3].y * x2.w;
+                a += wq[2].z * x3.x; a += wq[3].z * x3.y; a += wq[2].w * x3.z; a += wq[3].w * x3.w;
+                acc[i] += a;
+            }
+        }
+    }
+    const int m = mt * 32 + row;
+    if (m >= p.c_out) return;
+    const float bias = p.biasp[m];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int bi = bg + 8 * i;
+        if (bi < nb) {
+            float v = acc[i] + bias;
+            if (p.bias_b) v += p.bias_b[(long long)(b0 + bi) * p.bias_b_bs + m];
+            p.y[(long long)(b0 + bi) * p.y_bs + m] = v * p.scale;
+        }
+    }
+}
+
 // KT > 0: compile-time taps KT and padding PAD (PAD <= 4, KT-1-PAD <= 4), dilation 1, T % 4 == 0, 16-B aligned rows: each thread
 // produces 4 consecutive frames from three aligned float4 loads per input channel (its own 16 bytes, coalesced, plus
 // its two neighbours' through L1), activates every value once and keeps the window in registers for all taps.
@@ -1745,6 +1816,21 @@ int vs_conv_forward(vs_conv_t *h, const vs_conv_io_t *io, void *stream) {
         else VS_SMALL(4);
 #undef VS_SMALL
         VS_CHECK_HIP(hipGetLastError());
+        return VS_OK;
+    }
+
+    // one frame per item, k = 1 (conditioning vectors): conv_t1_kernel -- the tile kernels would compute one valid column in 128
+    if (h->kind == VS_CONV1D && h->k == 1 && io->T == 1 && h->flags == 0 && !p.split_row && !p.x_bf16 && !p.y_bf16 && io->in_act == VS_IN_NONE &&
+        !io->out[0].res && !io->out[0].acc && io->out[0].mode == VS_OUT_LINEAR && io->out[0].out_act == VS_OUT_NONE && !io->out[0].out_mask &&
+        h->nchunks * 16 * 32 * 4 <= 64 * 1024 && !opt(OPT_NO_T1_CONV)) {
+        T1Params q;
+        q.x = static_cast<const float *>(p.x); q.x_bs = p.x_bs; q.wp = h->wp.as<float>(); q.biasp = p.biasp; q.bias_b = p.bias_b; q.bias_b_bs = p.bias_b_bs;
+        q.y = static_cast<float *>(p.out[0].y); q.y_bs = p.out[0].y_bs; q.B = p.B; q.Cin = h->c_in; q.c_out = h->c_out; q.nchunks = h->nchunks;
+        q.bf16 = (h->math == VS_MATH_BF16); q.scale = p.out[0].scale;
+        const int nbmax = std::min(32, p.B);
+        hipLaunchKernelGGL(conv_t1_kernel, dim3((unsigned)h->MT, (unsigned)ceil_div(p.B, 32)), dim3(256), (size_t)nbmax * h->nchunks * 16 * sizeof(float), s, q);
+        VS_CHECK_HIP(hipGetLastError());
+        set_last_kernel("conv_t1_kernel");
         return VS_OK;
     }
 

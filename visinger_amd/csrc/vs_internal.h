@@ -41,6 +41,7 @@ enum Opt {
     OPT_NO_ATTN_DMA,      // VS_NO_ATTN_DMA: wide-head plain-bf16 attention on relattn_bf16_kernel<.., true> (register-staged tiles) instead of relattn_dma_kernel
     OPT_ATTN_DMA_ONE_WAVE,  // VS_ATTN_DMA_ONE_WAVE: relattn_dma_kernel with one wave per query group (the round-4 form) instead of the wave pair that splits the head's channels
     OPT_ATTN_SPLIT6,      // VS_ATTN_SPLIT6: VS_MATH_SPLIT3 attention on the split-bf16 x6 instance (the form of rounds 3-5) instead of relattn_bf16_kernel<.., 3> (split-f16 x3)
+    OPT_NO_T1_CONV,       // VS_NO_T1_CONV: 1 x 1 convs over a single frame per item (conditioning vectors) on the tile kernels instead of conv_t1_kernel
     OPT_COUNT
 };
 long long opt(Opt o);
