@@ -238,13 +238,13 @@ def test_round5_profiles_parse_and_agree(tag):
 
 
 def test_round6_profiles_parse_agree_and_name_their_build():
-    """profiles/r06_b_* (`tools/profile_round.sh r06_b`, `r06_b_config{2,3,5} --config N`; the end state of round 6).  `value` is quoted on the two-stream batch rotation
+    """profiles/r06_c_* (`tools/profile_round.sh r06_c`, `r06_c_config{2,3,5} --config N`; the end state of round 6).  `value` is quoted on the two-stream batch rotation
     (visinger_amd.synth.StreamRotation) and the roofline comes from the single-stream pass of the same process; the rocprofv3 summaries are of `--streams 1` runs, so
     rocprofv3's average launch of the dominant instance equals the HIP-event average of the profiled line.  EVERY summary names the sources its library was built from
     (VERDICT r5 #10) and that hash is the tree's: a kernel edit after the last profile fails here until the profile is redone.  DESIGN.md's round-6 numbers are these files'."""
     import bench
     from visinger_amd.csrc import build
-    tag = "r06_b"
+    tag = "r06_c"
     tree = build.source_hash()
     out = open(os.path.join(ROOT, "profiles", f"{tag}_bench_stdout.txt")).read()
     lines = [x for x in out.splitlines() if x.strip()]

@@ -1055,36 +1055,60 @@ __global__ void __launch_bounds__(256) conv_t1_kernel(const T1Params p) {
     const int tid = threadIdx.x, row = tid & 31, bg = tid >> 5;
     const int mt = blockIdx.x, b0 = blockIdx.y * 32;
     const int nb = min(32, p.B - b0), CP = p.nchunks * 16;
-    for (int e = tid; e < nb * CP; e += 256) {
-        const int bi = e / CP, c = e - bi * CP;
-        float v = (c < p.Cin) ? p.x[(long long)(b0 + bi) * p.x_bs + c] : 0.f;
-        if (p.bf16) v = u2f(rne_bf16(v) & 0xffff0000u);
-        t1_xs[e] = v;
+    // (sixteen loads per thread in flight, unconditional on clamped indices: one load per loop trip was 32 round trips to a cold L2, 22 of the
+    //  launch's 27 us)
+    for (int e0 = 0; e0 < nb * CP; e0 += 256 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = min(e0 + tid + 256 * u, nb * CP - 1), bi = e / CP, c = e - bi * CP;
+            v[u] = p.x[(long long)(b0 + bi) * p.x_bs + min(c, p.Cin - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + tid + 256 * u;
+            if (e < nb * CP) {
+                float t = (e % CP < p.Cin) ? v[u] : 0.f;
+                if (p.bf16) t = u2f(rne_bf16(t) & 0xffff0000u);
+                t1_xs[e] = t;
+            }
+        }
     }
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float4 *w = reinterpret_cast<const float4 *>(p.wp) + (long long)mt * p.nchunks * 128;
-    for (int ch = 0; ch < p.nchunks; ++ch, w += 128) {
-        float4 wq[4] = {w[row], w[row + 32], w[64 + row], w[64 + row + 32]};      // (quad, parity): channels 8 quad + 2 i + parity of the chunk
-        if (p.bf16) {
+    // the weights of eight chunks are requested before any is used: the launch is a few dozen workgroups, each a chain of loads from a cold L2
+    for (int c0 = 0; c0 < p.nchunks; c0 += 8) {
+        float4 wq[8][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                wq[t].x = u2f(rne_bf16(wq[t].x) & 0xffff0000u); wq[t].y = u2f(rne_bf16(wq[t].y) & 0xffff0000u);
-                wq[t].z = u2f(rne_bf16(wq[t].z) & 0xffff0000u); wq[t].w = u2f(rne_bf16(wq[t].w) & 0xffff0000u);
-            }
+        for (int u = 0; u < 8; ++u) {
+            const float4 *wc = w + min(c0 + u, p.nchunks - 1) * 128;
+            wq[u][0] = wc[row]; wq[u][1] = wc[row + 32]; wq[u][2] = wc[64 + row]; wq[u][3] = wc[64 + row + 32];      // (quad, parity): channels 8 quad + 2 i + parity
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int bi = bg + 8 * i;
-            if (bi < nb) {
-                const float4 *xv = reinterpret_cast<const float4 *>(t1_xs + bi * CP + ch * 16);
-                const float4 x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3];
-                float a = 0.f;                                     // (a chunk's sixteen products first, then onto the running sum: shorter rounding chains)
-                a += wq[0].x * x0.x; a += wq[1].x * x0.y; a += wq[0].y * x0.z; a += wq[1].y * x0.w;
-                a += wq[0].z * x1.x; a += wq[1].z * x1.y; a += wq[0].w * x1.z; a += wq[1].w * x1.w;
-                a += wq[2].x * x2.x; a += wq[3].x * x2.y; a += wq[2].y * x2.z; a += wq[3].y * x2.w;
-                a += wq[2].z * x3.x; a += wq[3].z * x3.y; a += wq[2].w * x3.z; a += wq[3].w * x3.w;
-                acc[i] += a;
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u < p.nchunks) {
+                if (p.bf16) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        wq[u][t].x = u2f(rne_bf16(wq[u][t].x) & 0xffff0000u); wq[u][t].y = u2f(rne_bf16(wq[u][t].y) & 0xffff0000u);
+                        wq[u][t].z = u2f(rne_bf16(wq[u][t].z) & 0xffff0000u); wq[u][t].w = u2f(rne_bf16(wq[u][t].w) & 0xffff0000u);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bi = bg + 8 * i;
+                    if (bi < nb) {
+                        const float4 *xv = reinterpret_cast<const float4 *>(t1_xs + bi * CP + (c0 + u) * 16);
+                        const float4 x0 = xv[0], x1 = xv[1], x2 = xv[2], x3 = xv[3];
+                        float a = 0.f;                                     // (a chunk's sixteen products first, then onto the running sum: shorter rounding chains)
+                        a += wq[u][0].x * x0.x; a += wq[u][1].x * x0.y; a += wq[u][0].y * x0.z; a += wq[u][1].y * x0.w;
+                        a += wq[u][0].z * x1.x; a += wq[u][1].z * x1.y; a += wq[u][0].w * x1.z; a += wq[u][1].w * x1.w;
+                        a += wq[u][2].x * x2.x; a += wq[u][3].x * x2.y; a += wq[u][2].y * x2.z; a += wq[u][3].y * x2.w;
+                        a += wq[u][2].z * x3.x; a += wq[u][3].z * x3.y; a += wq[u][2].w * x3.z; a += wq[u][3].w * x3.w;
+                        acc[i] += a;
+                    }
+                }
             }
         }
     }
