@@ -24,8 +24,12 @@ namespace vs {
 // registers of a tile scale with DT * AKT: at 256 channels a 64-key tile does not fit next to 128 output accumulators).
 // TERMS = 1: bf16 operands (VS_MATH_BF16).  TERMS = 6: the split-bf16 x6 arithmetic of conv_split.hip -- q / sqrt(dk), k, v and the
 // probabilities split EXACTLY into three bf16 planes, six cross products per product: fp32-class scores and outputs at 16/6 of the
-// fp32 matrix rate (VS_MATH_SPLIT6, the default arithmetic of the path); three times the LDS per tile, so 32-key tiles, ONE K / V
-// buffer (two barriers per tile) and two workgroups per CU that overlap each other; heads of up to 128 channels.
+// fp32 matrix rate (VS_MATH_SPLIT6); three times the LDS per tile, so 32-key tiles, ONE K / V buffer (two barriers per tile) and two
+// workgroups per CU that overlap each other; heads of up to 128 channels.  TERMS = 3 (round 6; VS_MATH_SPLIT3, the default arithmetic
+// of the path): the same four operands as TWO f16 planes under power-of-two scales -- one per query (a factor of a column of S^T), one per
+// staged K tile (a factor of the score tile, applied in the fma that forms the exponential's argument), a running one for V (the output
+// accumulators are rescaled by the exact ratio when a tile raises it), 2^14 for the probabilities -- and three cross products on
+// v_mfma_f32_32x32x16_f16: the same fp32 class at half the matrix work; same tile shape and buffer scheme as TERMS = 6.
 // PK: the K / V tiles arrive as ready LDS images (AttnParams::kvimg, attn_pack_kv_kernel): a tile is 9 (DT = 8) 16-byte loads and LDS
 // writes per thread, no conversion -- in place, the fp32 -> bf16 conversion of a tile (64 values per thread at 256 channels: ~300 VALU
 // instructions next to 32 MFMAs per wave, one wave per SIMD) and its 64 KB of fp32 loads were repeated by every one of the T / 128 query

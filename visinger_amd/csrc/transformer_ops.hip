@@ -395,7 +395,7 @@ static int relattn_fwd_impl(const float *q, const float *k, const float *v, int6
     }
     // VS_MATH_BF16: both GEMMs on the bf16 matrix instruction (attention_bf16.hip); any other arithmetic, and shapes that kernel does
     // not take (T % 4 != 0, unaligned rows), run the exact-fp32 MFMA kernel below
-    // VS_MATH_SPLIT6 (the default arithmetic of the path): the same kernel with every operand split exactly into three bf16 planes and
+    // VS_MATH_SPLIT6 (the default of rounds 3-5, selectable): the same kernel with every operand split exactly into three bf16 planes and
     // six cross products per product -- fp32-class scores and outputs at 16/6 of the fp32 matrix rate; VS_MATH_F32: the kernel below
     // (key split: only the bf16-pipe kernels take it; the number of ranges is capped by the key tiles of the kernel, 32 keys each at least)
     if (work && ksplit > 1 && T / 64 >= ksplit) { p.part = work; p.ksplit = ksplit; }
