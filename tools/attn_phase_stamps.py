@@ -30,7 +30,7 @@ a = buf.cpu().numpy()
 if WIDE:
     w = a[1000:1007]
     tot = w[6] - w[0]
-    for i, n in enumerate(["query fragments", "rel-key table + logits", "logits to LDS, first DMA", "tile loop", "finish (normalise, rel-value)", "output stores"]):
+    for i, n in enumerate(["rel-key table to LDS", "query fragments + logits (+ pair exchange)", "first DMA pieces", "tile loop", "finish (normalise, rel-value)", "output stores"]):
         print("  %-32s %8d cycles  %5.1f %%" % (n, w[i + 1] - w[i], 100.0 * (w[i + 1] - w[i]) / tot))
     print("  total %d cycles" % tot)
     sys.exit(0)

@@ -114,6 +114,28 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
         o.z = pack_hi(rne_bf16(v[4]), rne_bf16(v[5])); o.w = pack_hi(rne_bf16(v[6]), rne_bf16(v[7]));
         return o;
     };
+    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] in fp32: the table goes into LDS once per workgroup, transposed and zero-padded
+    // ([d][16], over the ring, which no DMA has touched yet); every wave sums over ITS k-steps -- sixteen loads of q in flight, one broadcast
+    // ds_read_b128 per four window positions -- and the two waves of a pair, which hold complementary halves of the head's channels, add their
+    // halves through the logits' own LDS rows (0 + 1 in both: the same bits).
+    // (Round 6, in two steps: the loop this replaces -- a load of q and nine of rel_k per channel, one channel in flight -- cost ~1 800 cycles
+    // per channel, a fifth of this kernel's launch; then every wave walking ALL the k-steps, still 50 000 cycles per workgroup at launch
+    // start: tools/attn_phase_stamps.py --wide.)
+    float *RKs = smem;
+    float qr[ATT_MAXREL];
+#pragma unroll
+    for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
+    if (nrel) {
+#pragma unroll      // (consecutive lanes read consecutive channels of one window position: coalesced, all loads of a thread in flight)
+        for (int i = 0; i < DKR * ATT_MAXREL / (256 * WPQ); ++i) {
+            const int e = tid + i * (256 * WPQ);
+            const int r = e / DKR, d = e % DKR;
+            const float w = relk[min(r, nrel - 1) * dk + min(d, dk - 1)];      // (unconditional load on a clamped index: the loads of a thread overlap)
+            RKs[d * ATT_MAXREL + r] = (d < dk && r < nrel) ? w : 0.f;
+        }
+    }
+    __syncthreads();
+    PSTAMP(1);
     constexpr int NKW = NKS / WPQ;                   // k-steps of S^T this wave contracts (its half of the channels with WPQ = 2)
     const int ks0 = dpart * NKW;
     u32x4 qf[NKW];
@@ -132,59 +154,51 @@ __global__ void __launch_bounds__(256 * WPQ, WPQ) relattn_dma_kernel(const AttnP
         // to cover it with, so the K / V fragments are requested eight / six MFMAs ahead
         if (ATT_PIN) asm volatile("" : "+a"(qf[ks]));
     }
-    PSTAMP(1);
-    // rel-key logits QR[i][r] = (q_i / sqrt(dk)) . rel_k[r] in fp32: the table goes into LDS once per workgroup, transposed and zero-padded
-    // ([d][16], over the ring, which no DMA has touched yet); every lane walks ALL the 8-channel groups of its half (a wave of a pair holds
-    // only its own half of the query as fragments) -- eight independent loads of q per step, one broadcast ds_read_b128 per four window
-    // positions.  (Round 6: the loop this replaces -- a load of q and nine of rel_k per channel, one channel in flight -- cost ~1 800 cycles
-    // per channel: a quarter of a launch of relattn_bf16_kernel at T = 1024, tools/attn_phase_stamps.py.)
-    float *RKs = smem;
-    float qr[ATT_MAXREL];
-#pragma unroll
-    for (int r = 0; r < ATT_MAXREL; ++r) qr[r] = 0.f;
+    // (the logits in a pass of their own over the wave's k-steps -- q comes back from L1 / L2 --, sixteen loads in flight: forming them inside the fully
+    //  unrolled fragment loop above left the prologue 16 registers short, and a spill is not allowed beside the hand-counted waits of the ring)
     if (nrel) {
-#pragma unroll      // (consecutive lanes read consecutive channels of one window position: coalesced, all loads of a thread in flight)
-        for (int i = 0; i < DKR * ATT_MAXREL / (256 * WPQ); ++i) {
-            const int e = tid + i * (256 * WPQ);
-            const int r = e / DKR, d = e % DKR;
-            const float w = relk[min(r, nrel - 1) * dk + min(d, dk - 1)];      // (unconditional load on a clamped index: the loads of a thread overlap)
-            RKs[d * ATT_MAXREL + r] = (d < dk && r < nrel) ? w : 0.f;
-        }
-    }
-    __syncthreads();
-    if (nrel) {
-#pragma unroll 2      // (16 loads of q in flight per lane: a rolled loop waited ~3 400 cycles per k-step at launch start, when every workgroup of the chip is in its prologue)
-        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll 2
+        for (int ks = 0; ks < NKW; ++ks) {
             float qv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int d = 16 * ks + 8 * half + j;
+                const int d = 16 * (ks0 + ks) + 8 * half + j;
                 const float v = qb[(long long)min(d, dk - 1) * T + qic];
                 qv[j] = (d < dk && qi < T) ? v * p.scale : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float4 *row = reinterpret_cast<const float4 *>(RKs + (16 * ks + 8 * half + j) * ATT_MAXREL);
+                const float4 *row = reinterpret_cast<const float4 *>(RKs + (16 * (ks0 + ks) + 8 * half + j) * ATT_MAXREL);
 #pragma unroll
-                for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {      // (all 16 columns of the zero-padded table: straight-line code, every load of q hoisted)
+                for (int c4 = 0; c4 < ATT_MAXREL / 4; ++c4) {      // (all 16 columns of the zero-padded table: straight-line code)
                     const float4 w = row[c4];
                     qr[4 * c4 + 0] += qv[j] * w.x; qr[4 * c4 + 1] += qv[j] * w.y; qr[4 * c4 + 2] += qv[j] * w.z; qr[4 * c4 + 3] += qv[j] * w.w;
                 }
             }
         }
     }
-    __syncthreads();                                     // (the table is read: the ring may be written)
-    PSTAMP(2);
     float *QRw = QRs + wave * 32 * ATT_QRS;
     float *Sww = Sws + wave * 32 * ATT_QRS;
     for (int e = lane; e < 32 * ATT_QRS; e += 64) Sww[e] = -INFINITY;
     if (nrel) {
 #pragma unroll
-        for (int r = 0; r < ATT_MAXREL; ++r) {
-            const float tot = qr[r] + __shfl_xor(qr[r], 32);      // the two lane halves hold complementary d's
-            if (half == 0) QRw[l31 * ATT_QRS + r] = tot;
+        for (int r = 0; r < ATT_MAXREL; ++r) qr[r] += __shfl_xor(qr[r], 32);      // the two lane halves hold complementary d's
+        if (WPQ == 1 || dpart == 0) {
+            if (half == 0) {
+#pragma unroll
+                for (int r = 0; r < ATT_MAXREL; ++r) QRw[l31 * ATT_QRS + r] = qr[r];
+            }
+        }
+        if constexpr (WPQ == 2) {
+            __syncthreads();
+            if (dpart == 1 && half == 0) {
+#pragma unroll
+                for (int r = 0; r < ATT_MAXREL; ++r) QRw[l31 * ATT_QRS + r] += qr[r];
+            }
         }
     }
+    __syncthreads();                                     // (the table is read, the logits are complete: the ring may be written)
+    PSTAMP(2);
 
     f32x16 o[DH];
 #pragma unroll
